@@ -1,0 +1,19 @@
+"""pytest configuration: `gpu` marker + repo root on sys.path."""
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+    return np.load(ROOT / "tests" / "golden" / "loss_side.npz", allow_pickle=False)
