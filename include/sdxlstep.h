@@ -1,0 +1,150 @@
+/* libsdxlstep -- C ABI of the MI355X-native SDXL training step.
+ *
+ * Drop-in boundary for the hot path of DataCTE/SDXL-Training-Improvements (reference is 100 % Python and
+ * has no native interface of its own; each entry point cites the reference call it replaces, paths under
+ * /root/reference/src).  Plain pointers and sizes only -- no torch types.  All device pointers are raw HIP
+ * device addresses (e.g. torch.Tensor.data_ptr()); `stream` is a hipStream_t passed as void*.
+ *
+ * Conventions: every function returns 0 on success, non-zero on failure (1 = bad argument, 2 = HIP error,
+ * 3 = wrong state); sdxl_last_error() returns a thread-local message.  One handle per rank/GPU; a handle is not
+ * thread-safe.  Calls are stream-ordered and do not synchronise unless stated.
+ */
+#ifndef SDXLSTEP_H
+#define SDXLSTEP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sdxl_handle sdxl_handle;
+
+/* UNet2DConditionModel config (the fields of diffusers' unet/config.json that determine the arithmetic;
+ * loaded by the reference at models/sdxl.py:25-40). */
+typedef struct {
+  int in_channels, out_channels;       /* 4, 4 */
+  int block_out_channels[3];           /* 320, 640, 1280 */
+  int layers_per_block;                /* 2 */
+  int transformer_layers[3];           /* 0, 2, 10 */
+  int head_dim;                        /* 64 (only value supported) */
+  int cross_attention_dim;             /* 2048 */
+  int norm_num_groups;                 /* 32 */
+  int addition_time_embed_dim;         /* 256 */
+  int pooled_dim;                      /* 1280 */
+  float resnet_eps, tf_gn_eps, ln_eps; /* 1e-5, 1e-6, 1e-5 */
+} sdxl_unet_config;
+
+/* Loss configuration: config.yaml keys read by the path (training.method, training.prediction_type,
+ * model.min_snr_gamma, model.use_ztsnr; ddpm_trainer.py:328,336, novelai_v3.py:106,117). */
+typedef struct {
+  int method;            /* 0 = ddpm (ddpm_trainer.py:280-405), 1 = flow_matching (flow_matching_trainer.py:267-356) */
+  int prediction_type;   /* ddpm: 0 = epsilon, 1 = v_prediction */
+  int use_min_snr;       /* model.min_snr_gamma is not None */
+  float min_snr_gamma;
+  int use_ztsnr;         /* clamp noisy latents to +-20000 */
+} sdxl_loss_config;
+
+/* One micro-batch, all device pointers.  RNG is the caller's: `noise` and `sigma_or_t` are inputs so that
+ * fixtures are exact (reference draws them at ddpm_trainer.py:303-304 / flow_matching_trainer.py:298-306). */
+typedef struct {
+  int B, H, W;                 /* latent batch / height / width (pixels / 8) */
+  int ctx_len;                 /* 77 */
+  const float* latents;        /* [B,4,H,W] fp32 NCHW : batch["vae_latents"] (x for ddpm, x1 for flow matching) */
+  const float* noise;          /* [B,4,H,W] fp32      : ddpm noise / flow-matching x0 */
+  const float* sigma_or_t;     /* [B] fp32            : ddpm sigma = karras[timestep] ; flow matching t in (0,1) */
+  const float* timestep;       /* [B] fp32            : value fed to the UNet time embedding (ddpm: index; fm: t) */
+  const void* prompt_embeds;   /* [B,ctx_len,cross_attention_dim] bf16 : batch["prompt_embeds"] */
+  const void* pooled;          /* [B,pooled_dim] bf16                 : batch["pooled_prompt_embeds"] */
+  const float* time_ids;       /* [B,6] fp32                          : batch["time_ids"] */
+  const float* tag_weights;    /* optional [B] fp32 (NULL = none)     : batch["tag_weights"] */
+} sdxl_batch;
+
+const char* sdxl_last_error(void);
+int sdxl_version(void);
+
+/* ---- lifetime ---------------------------------------------------------------------------------------------- */
+int sdxl_default_config(sdxl_unet_config* cfg);                 /* SDXL-base-1.0 */
+int sdxl_create(const sdxl_unet_config* cfg, int device, sdxl_handle** out);
+int sdxl_destroy(sdxl_handle* h);
+
+/* ---- parameters (replaces model.unet.parameters()/state_dict(), models/sdxl.py:237-240) ---------------------- */
+/* bytes of the packed bf16 weight arena and the fp32 gradient arena */
+int sdxl_param_bytes(sdxl_handle* h, size_t* weight_bytes, size_t* grad_bytes);
+/* bind caller-allocated arenas (NULL = library allocates with hipMalloc) */
+int sdxl_bind_params(sdxl_handle* h, void* weights_dev, void* grads_dev);
+int sdxl_num_params(sdxl_handle* h);                            /* diffusers state-dict tensors */
+int sdxl_param_info(sdxl_handle* h, int i, char* name, int name_cap, int* ndim, long shape[4]);
+/* copy one tensor in PyTorch layout ([out,in] / [cout,cin,kh,kw]) from device memory into the packed arena
+ * (dtype: 0 = fp32, 1 = bf16).  Caller keeps ownership of src. */
+int sdxl_load_weight(sdxl_handle* h, const char* name, const void* src_dev, int dtype, void* stream);
+int sdxl_export_weight(sdxl_handle* h, const char* name, void* dst_dev, int dtype, void* stream);
+int sdxl_export_grad(sdxl_handle* h, const char* name, void* dst_dev, int dtype, void* stream);
+
+/* ---- plan: static execution plan for one bucket shape (B, H, W) ------------------------------------------------ */
+int sdxl_plan(sdxl_handle* h, int B, int H, int W, int ctx_len, size_t* workspace_bytes);
+int sdxl_bind_workspace(sdxl_handle* h, void* ws_dev, size_t bytes);   /* NULL = library allocates */
+
+/* ---- the step (replaces compute_loss()/training_step() + loss.backward()) -------------------------------------- */
+/* grads = 0 for the parameters that accumulate atomically; the rest are overwritten by the first micro-step */
+int sdxl_zero_grads(sdxl_handle* h, void* stream);
+/* loss preparation + UNet forward + loss.  Leaves loss/metrics on device. */
+int sdxl_forward_loss(sdxl_handle* h, const sdxl_loss_config* lc, const sdxl_batch* b, void* stream);
+/* backward, split into segments (reverse execution order) so the caller can overlap gradient all-reduce of a
+ * finished segment with the remaining backward (replaces DDP hooks, core/distributed.py:153-157).
+ * first_micro != 0: gradients are overwritten (first micro-step after sdxl_zero_grads); else accumulated. */
+int sdxl_num_segments(sdxl_handle* h);
+int sdxl_segment_range(sdxl_handle* h, int seg, size_t* grad_elem_offset, size_t* grad_elems);
+int sdxl_backward_segment(sdxl_handle* h, int seg, float grad_scale, int first_micro, void* stream);
+/* convenience: forward + all backward segments */
+int sdxl_loss_fwd_bwd(sdxl_handle* h, const sdxl_loss_config* lc, const sdxl_batch* b, float grad_scale,
+                      int first_micro, void* stream);
+/* synchronises `stream`; out[0]=loss out[1]=sum w*(pred-target)^2 out[2]=sum|pred| out[3]=sum pred^2
+ * out[4]=sum|noise| out[5]=sum noise^2 (x0) out[6]=sum latents^2 (x1) out[7]=gradient gate */
+int sdxl_read_loss(sdxl_handle* h, float out[8], void* stream);
+
+/* UNet only: sample_nhwc8 [B*H*W][8] bf16 in (channels 4..7 ignored) -> pred [B*H*W][8] bf16 out.
+ * (replaces unet(sample, t, ehs, added_cond_kwargs).sample, ddpm_trainer.py:320-325) */
+int sdxl_unet_forward(sdxl_handle* h, const void* sample_nhwc8, const sdxl_batch* cond, void* pred_nhwc8, void* stream);
+/* d(pred) in -> runs every backward segment; d(sample) is not produced (inputs carry no gradient) */
+int sdxl_unet_backward(sdxl_handle* h, const void* dpred_nhwc8, int first_micro, void* stream);
+
+/* fp32 grads -> bf16 (scaled) for the gradient exchange; global L2 norm of the fp32 grads */
+int sdxl_grads_to_bf16(sdxl_handle* h, size_t elem_offset, size_t elems, void* dst_bf16, float scale, void* stream);
+int sdxl_grad_sumsq(sdxl_handle* h, float* out_dev, void* stream);
+
+/* ---- single-kernel entry points (parity tests call these; same kernels the plan launches) --------------------- */
+/* C[M,N] = A.B ; form 0: A[M,K],B[N,K] ; 1: A[M,K],B[K,N] ; 2: A[K,M],B[K,N] -> fp32 C (+= if accumulate) */
+int sdxl_op_gemm(int form, const void* A, const void* B, void* C, int M, int N, int K, const void* bias,
+                 const void* resid, int accumulate, int splitk, void* stream);
+/* 3x3 conv, pad 1, token-major: x [B,H,W,Cin], w [Cout][9][Cin] ; y [B,Ho,Wo,Cout] */
+int sdxl_op_conv3x3_fwd(const void* x, const void* w, const void* bias, void* y, int B, int H, int W, int Cin,
+                        int Cout, int stride, void* stream);
+int sdxl_op_conv3x3_dgrad(const void* dy, const void* w, void* dx, int B, int H, int W, int Cin, int Cout,
+                          int stride, void* stream);
+int sdxl_op_conv3x3_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout,
+                          int stride, int splitk, void* stream);
+int sdxl_op_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int heads,
+                          int Nq, int Nk, long ldq, long ldk, long ldv, long ldo, void* stream);
+int sdxl_op_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                          const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int heads, int Nq,
+                          int Nk, long ldq, long ldk, long ldv, long ldo, void* stream);
+int sdxl_op_groupnorm_fwd(const void* x, void* y, const void* gamma, const void* beta, float* stats, float* ws,
+                          int B, int HW, int C, int G, float eps, int silu, void* stream);
+int sdxl_op_groupnorm_bwd(const void* x, const void* dy, const void* gamma, const void* beta, const float* stats,
+                          void* dx, float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int G, int silu,
+                          int accumulate, void* stream);
+int sdxl_op_layernorm_fwd(const void* x, void* y, const void* gamma, const void* beta, float* stats, int M, int C,
+                          float eps, void* stream);
+int sdxl_op_layernorm_bwd(const void* x, const void* dy, const void* gamma, const float* stats, void* dx,
+                          float* dgamma, float* dbeta, int M, int C, int accumulate, void* stream);
+int sdxl_op_geglu_fwd(const void* u, void* g, int M, int C4, void* stream);
+int sdxl_op_geglu_bwd(const void* u, const void* dg, void* du, int M, int C4, void* stream);
+int sdxl_op_loss(const sdxl_loss_config* lc, const sdxl_batch* b, void* unet_in, const void* pred, void* dpred,
+                 float grad_scale, float* out8_dev, int phase /*0 prepare,1 loss,2 dpred*/, void* stream);
+/* debug: run ds_read_b64_tr_b16 / MFMA layout probes (used by tests/test_gpu_layout.py) */
+int sdxl_probe_layout(void* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,73 @@
+"""Build libsdxlstep.so (all HIP kernels + plan engine + C ABI) for gfx950, in-tree.
+
+    python sdxl-training-improvements_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with the snapshot.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+OBJ = HERE / "build"
+LIB = HERE / "libsdxlstep.so"
+SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "elementwise.hip", "loss.hip", "engine.hip", "capi.hip"]
+HEADERS = ["common.h", "kernels.h", "engine.h", "../../include/sdxlstep.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target: Path, deps) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> Path:
+    OBJ.mkdir(exist_ok=True)
+    hipcc = _hipcc()
+    hdrs = [CSRC / h for h in HEADERS]
+    jobs = []
+    for s in SOURCES:
+        src, obj = CSRC / s, OBJ / (s + ".o")
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        cmd = [hipcc] + FLAGS + ["-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
+        if r.stderr.strip() and verbose:
+            print(r.stderr, file=sys.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(cc, jobs))
+    objs = [OBJ / (s + ".o") for s in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + [str(o) for o in objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,481 @@
+// Flash attention (head_dim 64, no mask, softmax scale 1/8) forward + backward for gfx950.
+//
+// Orientation trick (wave64 MFMA 16x16x32): scores are produced TRANSPOSED, S^T = K . Q^T, so each
+// lane owns one query column (lane & 15) and 4 consecutive keys per 16-key block.  Row max / sum
+// are then an in-lane reduction plus two cross-lane steps (xor 16, 32), the bf16 P^T fragments feed
+// the second MFMA (O^T = V^T . P^T) as its B operand without any data movement, and the running
+// (m, l) live in the same lanes as the O^T columns they rescale.  V^T (and K^T / Q^T / dO^T in the
+// backward) are read from row-major LDS tiles with the gfx950 transpose read ds_read_b64_tr_b16.
+//
+// Slot convention for a 32-deep MFMA step built from two 16-row score blocks (2t, 2t+1):
+//   slot (g, j<4)  <-> row 32t + 4g + j         slot (g, j>=4) <-> row 32t + 16 + 4g + (j-4)
+// used identically by the register operand (packed scores) and the transpose-read operand.
+//
+// Kernels: attn_fwd (O, LSE) ; attn_delta (rowsum dO*O) ; attn_bwd_dq ; attn_bwd_dkv.
+#include "kernels.h"
+
+#define HD 64
+#define LDT 72  // LDS row stride (bf16) of every [rows][64] tile: 144 B
+#define SCALE 0.125f
+#define LOG2E 1.4426950408889634f
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bf16x8 z8() {
+  bf16x8 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z[i] = (bf16)0.f;
+  return z;
+}
+// b128 fragment: row r, 8 contiguous columns at c
+__device__ __forceinline__ bf16x8 ld_frag(const bf16* t, int r, int c) { return *(const bf16x8*)(t + r * LDT + c); }
+// transpose-read fragment for one 32-deep step t over tile rows: block rows per the slot convention,
+// 16 columns at col0; lane16 = lane & 15, g = lane >> 4
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int t, int col0, int lane16, int g) {
+  const bf16* p0 = tile + (t * 32 + g * 4 + (lane16 >> 2)) * LDT + col0 + (lane16 & 3) * 4;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 16 * LDT));
+  union { s16x4 s[2]; bf16x8 v; } u;
+  u.s[0] = lo;
+  u.s[1] = hi;
+  return u.v;
+}
+__device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
+  bf16x8 o;
+  o[0] = (bf16)a[0]; o[1] = (bf16)a[1]; o[2] = (bf16)a[2]; o[3] = (bf16)a[3];
+  o[4] = (bf16)b[0]; o[5] = (bf16)b[1]; o[6] = (bf16)b[2]; o[7] = (bf16)b[3];
+  return o;
+}
+// cooperative load of a [64][64] bf16 tile (rows row0.., zero beyond nrows) into 2 regs per thread
+__device__ __forceinline__ void tile_load(const bf16* base, long ld, int row0, int nrows, int tid, bf16x8 (&r)[2]) {
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    int id = v * 256 + tid;
+    int row = row0 + (id >> 3);
+    r[v] = row < nrows ? *(const bf16x8*)(base + (long)row * ld + (id & 7) * 8) : z8();
+  }
+}
+__device__ __forceinline__ void tile_store(bf16* tile, int tid, const bf16x8 (&r)[2]) {
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    int id = v * 256 + tid;
+    *(bf16x8*)(tile + (id >> 3) * LDT + (id & 7) * 8) = r[v];
+  }
+}
+
+#define TILE_ELEMS (64 * LDT)
+
+// ------------------------------------------------------------------------------------------------
+// forward: block = 128 queries (4 waves x 32), loop over 64-key tiles
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
+  __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE_ELEMS];  // K0 V0 K1 V1
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const bf16* Qb = p.Q + (long)b * p.Nq * p.ldq + h * HD;
+  const bf16* Kb = p.K + (long)b * p.Nk * p.ldk + h * HD;
+  const bf16* Vb = p.V + (long)b * p.Nk * p.ldv + h * HD;
+
+  // Q^T B-operand fragments: [qb][ks], lane = query column, 8 contiguous d
+  bf16x8 qf[2][2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    int q = q0 + qb * 16 + l16;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      qf[qb][ks] = q < p.Nq ? *(const bf16x8*)(Qb + (long)q * p.ldq + ks * 32 + g * 8) : z8();
+  }
+  f32x4 ot[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ot[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float mrow[2] = {-1e30f, -1e30f}, lrow[2] = {0.f, 0.f};
+  const float c = SCALE * LOG2E;
+
+  const int ntiles = (p.Nk + 63) / 64;
+  bf16x8 rk[2], rv[2];
+  tile_load(Kb, p.ldk, 0, p.Nk, tid, rk);
+  tile_load(Vb, p.ldv, 0, p.Nk, tid, rv);
+  tile_store(sm, tid, rk);
+  tile_store(sm + TILE_ELEMS, tid, rv);
+  __syncthreads();
+  int buf = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const bool more = t + 1 < ntiles;
+    if (more) {
+      tile_load(Kb, p.ldk, (t + 1) * 64, p.Nk, tid, rk);
+      tile_load(Vb, p.ldv, (t + 1) * 64, p.Nk, tid, rv);
+    }
+    const bf16* Kt = sm + (buf * 2) * TILE_ELEMS;
+    const bf16* Vt = Kt + TILE_ELEMS;
+    // S^T[key][q] = K . Q^T
+    f32x4 st[4][2];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      bf16x8 k0 = ld_frag(Kt, kb * 16 + l16, g * 8);
+      bf16x8 k1 = ld_frag(Kt, kb * 16 + l16, 32 + g * 8);
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qb][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qb][1], a, 0, 0, 0);
+        st[kb][qb] = a;
+      }
+    }
+    // mask keys beyond Nk (last tile only)
+    if ((t + 1) * 64 > p.Nk) {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int key = t * 64 + kb * 16 + g * 4 + r;
+          if (key >= p.Nk) { st[kb][0][r] = -1e30f; st[kb][1][r] = -1e30f; }
+        }
+    }
+    // online softmax per query column
+    bf16x8 pf[2][2];  // [step t2][qb]
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float mx = -1e30f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kb][qb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float mnew = fmaxf(mrow[qb], mx);
+      float alpha = exp2f((mrow[qb] - mnew) * c);
+      mrow[qb] = mnew;
+      float ls = 0.f;
+      float mc = mnew * c;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float e = exp2f(st[kb][qb][r] * c - mc);
+          st[kb][qb][r] = e;
+          ls += e;
+        }
+      lrow[qb] = lrow[qb] * alpha + ls;  // per-lane partial (reduced over g at the end)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        ot[db][qb][0] *= alpha; ot[db][qb][1] *= alpha; ot[db][qb][2] *= alpha; ot[db][qb][3] *= alpha;
+      }
+      pf[0][qb] = pack8(st[0][qb], st[1][qb]);
+      pf[1][qb] = pack8(st[2][qb], st[3][qb]);
+    }
+    // O^T[d][q] += V^T . P^T
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        bf16x8 vf = tr_frag(Vt, t2, db * 16, l16, g);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+          ot[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t2][qb], ot[db][qb], 0, 0, 0);
+      }
+    if (more) {
+      tile_store(sm + ((buf ^ 1) * 2) * TILE_ELEMS, tid, rk);
+      tile_store(sm + ((buf ^ 1) * 2 + 1) * TILE_ELEMS, tid, rv);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+  // finalize
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    float l = lrow[qb];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    float inv = 1.f / l;
+    int q = q0 + qb * 16 + l16;
+    if (q < p.Nq) {
+      bf16* orow = p.O + ((long)b * p.Nq + q) * p.ldo + h * HD;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        bf16x4 o;
+        o[0] = (bf16)(ot[db][qb][0] * inv); o[1] = (bf16)(ot[db][qb][1] * inv);
+        o[2] = (bf16)(ot[db][qb][2] * inv); o[3] = (bf16)(ot[db][qb][3] * inv);
+        *(bf16x4*)(orow + db * 16 + g * 4) = o;
+      }
+      if (g == 0 && p.LSE) p.LSE[(long)bh * p.Nq + q] = mrow[qb] * SCALE + logf(l);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Delta[bh][q] = sum_d dO[q][d] * O[q][d]   (one 16-lane group per row: 4 elements per lane)
+// ------------------------------------------------------------------------------------------------
+__global__ void attn_delta_kernel(const AttnP p) {
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);  // over B*H*Nq
+  const int sub = threadIdx.x & 15;
+  const long total = (long)p.B * p.H * p.Nq;
+  float s = 0.f;
+  long bh = 0; int q = 0;
+  if (row < total) {
+    bh = row / p.Nq; q = row - bh * p.Nq;
+    int b = bh / p.H, h = bh - b * p.H;
+    bf16x4 o = *(const bf16x4*)(p.O + ((long)b * p.Nq + q) * p.ldo + h * HD + sub * 4);
+    bf16x4 d = *(const bf16x4*)(p.dO + ((long)b * p.Nq + q) * p.lddo + h * HD + sub * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += (float)o[e] * (float)d[e];
+  }
+  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+  if (row < total && sub == 0) p.Delta[row] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dQ: same orientation as forward.  dQ^T[d][q] = scale * K^T . dS^T,  dS^T = P^T o (dP^T - Delta)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
+  __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE_ELEMS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const bf16* Qb = p.Q + (long)b * p.Nq * p.ldq + h * HD;
+  const bf16* dOb = p.dO + (long)b * p.Nq * p.lddo + h * HD;
+  const bf16* Kb = p.K + (long)b * p.Nk * p.ldk + h * HD;
+  const bf16* Vb = p.V + (long)b * p.Nk * p.ldv + h * HD;
+
+  bf16x8 qf[2][2], df[2][2];
+  float lse2[2], delta[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    int q = q0 + qb * 16 + l16;
+    bool ok = q < p.Nq;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[qb][ks] = ok ? *(const bf16x8*)(Qb + (long)q * p.ldq + ks * 32 + g * 8) : z8();
+      df[qb][ks] = ok ? *(const bf16x8*)(dOb + (long)q * p.lddo + ks * 32 + g * 8) : z8();
+    }
+    lse2[qb] = ok ? p.LSE[(long)bh * p.Nq + q] * LOG2E : 0.f;
+    delta[qb] = ok ? p.Delta[(long)bh * p.Nq + q] : 0.f;
+  }
+  f32x4 dq[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dq[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float c = SCALE * LOG2E;
+
+  const int ntiles = (p.Nk + 63) / 64;
+  bf16x8 rk[2], rv[2];
+  tile_load(Kb, p.ldk, 0, p.Nk, tid, rk);
+  tile_load(Vb, p.ldv, 0, p.Nk, tid, rv);
+  tile_store(sm, tid, rk);
+  tile_store(sm + TILE_ELEMS, tid, rv);
+  __syncthreads();
+  int buf = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const bool more = t + 1 < ntiles;
+    if (more) {
+      tile_load(Kb, p.ldk, (t + 1) * 64, p.Nk, tid, rk);
+      tile_load(Vb, p.ldv, (t + 1) * 64, p.Nk, tid, rv);
+    }
+    const bf16* Kt = sm + (buf * 2) * TILE_ELEMS;
+    const bf16* Vt = Kt + TILE_ELEMS;
+    bf16x8 dsf[2][2];
+    f32x4 st[4][2], dp[4][2];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      bf16x8 k0 = ld_frag(Kt, kb * 16 + l16, g * 8), k1 = ld_frag(Kt, kb * 16 + l16, 32 + g * 8);
+      bf16x8 v0 = ld_frag(Vt, kb * 16 + l16, g * 8), v1 = ld_frag(Vt, kb * 16 + l16, 32 + g * 8);
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qb][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qb][1], a, 0, 0, 0);
+        st[kb][qb] = a;
+        f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, df[qb][0], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, df[qb][1], d, 0, 0, 0);
+        dp[kb][qb] = d;
+      }
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int key = t * 64 + kb * 16 + g * 4 + r;
+          float pr = key < p.Nk ? exp2f(st[kb][qb][r] * c - lse2[qb]) : 0.f;
+          st[kb][qb][r] = pr * (dp[kb][qb][r] - delta[qb]) * SCALE;
+        }
+      dsf[0][qb] = pack8(st[0][qb], st[1][qb]);
+      dsf[1][qb] = pack8(st[2][qb], st[3][qb]);
+    }
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        bf16x8 kf = tr_frag(Kt, t2, db * 16, l16, g);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+          dq[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf[t2][qb], dq[db][qb], 0, 0, 0);
+      }
+    if (more) {
+      tile_store(sm + ((buf ^ 1) * 2) * TILE_ELEMS, tid, rk);
+      tile_store(sm + ((buf ^ 1) * 2 + 1) * TILE_ELEMS, tid, rv);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    int q = q0 + qb * 16 + l16;
+    if (q < p.Nq) {
+      bf16* row = p.dQ + ((long)b * p.Nq + q) * p.lddq + h * HD;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        bf16x4 o;
+        o[0] = (bf16)dq[db][qb][0]; o[1] = (bf16)dq[db][qb][1]; o[2] = (bf16)dq[db][qb][2]; o[3] = (bf16)dq[db][qb][3];
+        *(bf16x4*)(row + db * 16 + g * 4) = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dK, dV: block = 64 keys (4 waves x 16), loop over 64-query tiles.  Scores un-transposed here:
+// S[q][key] = Q . K^T so that each lane owns one key column; P / dS feed dV^T = dO^T . P and
+// dK^T = Q^T . dS as B operands, dO^T / Q^T come from transpose reads of the row-major tiles.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
+  __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE_ELEMS];  // Q0 dO0 Q1 dO1
+  __shared__ __attribute__((aligned(16))) float sstat[2][2][64];                                   // [buf][lse2|delta][q]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  const int key = blockIdx.x * 64 + wave * 16 + l16;  // this lane's key column
+  const bf16* Qb = p.Q + (long)b * p.Nq * p.ldq + h * HD;
+  const bf16* dOb = p.dO + (long)b * p.Nq * p.lddo + h * HD;
+  const bf16* Kb = p.K + (long)b * p.Nk * p.ldk + h * HD;
+  const bf16* Vb = p.V + (long)b * p.Nk * p.ldv + h * HD;
+  const bool kok = key < p.Nk;
+  bf16x8 kf[2], vf[2];  // B operands: [k=d][col=key]
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    kf[ks] = kok ? *(const bf16x8*)(Kb + (long)key * p.ldk + ks * 32 + g * 8) : z8();
+    vf[ks] = kok ? *(const bf16x8*)(Vb + (long)key * p.ldv + ks * 32 + g * 8) : z8();
+  }
+  f32x4 dk[4], dv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  const float c = SCALE * LOG2E;
+
+  const int ntiles = (p.Nq + 63) / 64;
+  bf16x8 rq[2], rd[2];
+  float rs = 0.f;
+  auto load_stats = [&](int t) {
+    if (tid < 128) {
+      int q = t * 64 + (tid & 63);
+      float v = 0.f;
+      if (q < p.Nq) v = tid < 64 ? p.LSE[(long)bh * p.Nq + q] * LOG2E : p.Delta[(long)bh * p.Nq + q];
+      rs = v;
+    }
+  };
+  tile_load(Qb, p.ldq, 0, p.Nq, tid, rq);
+  tile_load(dOb, p.lddo, 0, p.Nq, tid, rd);
+  load_stats(0);
+  tile_store(sm, tid, rq);
+  tile_store(sm + TILE_ELEMS, tid, rd);
+  if (tid < 128) sstat[0][tid >> 6][tid & 63] = rs;
+  __syncthreads();
+  int buf = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const bool more = t + 1 < ntiles;
+    if (more) {
+      tile_load(Qb, p.ldq, (t + 1) * 64, p.Nq, tid, rq);
+      tile_load(dOb, p.lddo, (t + 1) * 64, p.Nq, tid, rd);
+      load_stats(t + 1);
+    }
+    const bf16* Qt = sm + (buf * 2) * TILE_ELEMS;
+    const bf16* Dt = Qt + TILE_ELEMS;
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      bf16x8 a0 = ld_frag(Qt, qb * 16 + l16, g * 8), a1 = ld_frag(Qt, qb * 16 + l16, 32 + g * 8);
+      bf16x8 d0 = ld_frag(Dt, qb * 16 + l16, g * 8), d1 = ld_frag(Dt, qb * 16 + l16, 32 + g * 8);
+      f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, kf[0], a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, kf[1], a, 0, 0, 0);
+      s[qb] = a;
+      f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, vf[0], d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, vf[1], d, 0, 0, 0);
+      dp[qb] = d;
+    }
+    f32x4 pr[4];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      f32x4 l2 = *(const f32x4*)&sstat[buf][0][qb * 16 + g * 4];
+      f32x4 dl = *(const f32x4*)&sstat[buf][1][qb * 16 + g * 4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int q = t * 64 + qb * 16 + g * 4 + r;
+        float e = (q < p.Nq && kok) ? exp2f(s[qb][r] * c - l2[r]) : 0.f;
+        pr[qb][r] = e;
+        s[qb][r] = e * (dp[qb][r] - dl[r]) * SCALE;
+      }
+    }
+    bf16x8 pf[2] = {pack8(pr[0], pr[1]), pack8(pr[2], pr[3])};
+    bf16x8 dsf[2] = {pack8(s[0], s[1]), pack8(s[2], s[3])};
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        bf16x8 dot = tr_frag(Dt, t2, db * 16, l16, g);
+        dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf[t2], dv[db], 0, 0, 0);
+        bf16x8 qt = tr_frag(Qt, t2, db * 16, l16, g);
+        dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf[t2], dk[db], 0, 0, 0);
+      }
+    if (more) {
+      tile_store(sm + ((buf ^ 1) * 2) * TILE_ELEMS, tid, rq);
+      tile_store(sm + ((buf ^ 1) * 2 + 1) * TILE_ELEMS, tid, rd);
+      if (tid < 128) sstat[buf ^ 1][tid >> 6][tid & 63] = rs;
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+  if (kok) {
+    bf16* kr = p.dK + ((long)b * p.Nk + key) * p.lddk + h * HD;
+    bf16* vr = p.dV + ((long)b * p.Nk + key) * p.lddv + h * HD;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      bf16x4 a, c2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { a[r] = (bf16)dk[db][r]; c2[r] = (bf16)dv[db][r]; }
+      *(bf16x4*)(kr + db * 16 + g * 4) = a;
+      *(bf16x4*)(vr + db * 16 + g * 4) = c2;
+    }
+  }
+}
+
+static int check_attn(const AttnP& p) {
+  ARG_CHECK(p.B > 0 && p.H > 0 && p.Nq > 0 && p.Nk > 0, "attention: empty problem");
+  ARG_CHECK(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0,
+            "attention: row strides must be multiples of 8 elements");
+  return 0;
+}
+
+int launch_attn_fwd(const AttnP& p, hipStream_t st) {
+  if (int e = check_attn(p)) return e;
+  dim3 grid(cdiv(p.Nq, 128), p.B * p.H);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, st, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_attn_bwd(const AttnP& p, hipStream_t st) {
+  if (int e = check_attn(p)) return e;
+  ARG_CHECK(p.dO && p.dQ && p.dK && p.dV && p.LSE && p.Delta, "attention bwd: missing buffers");
+  ARG_CHECK(!p.accumulate, "attention bwd: accumulate not implemented");
+  long rows = (long)p.B * p.H * p.Nq;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(rows, 16)), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(cdiv(p.Nq, 128), p.B * p.H), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(cdiv(p.Nk, 64), p.B * p.H), dim3(256), 0, st, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,459 @@
+// extern "C" surface of libsdxlstep (see include/sdxlstep.h for the contract of every entry point).
+#include "engine.h"
+
+const char* sdxl_get_error();
+
+struct StepState {  // what backward needs from the preceding forward
+  sdxl_loss_config lc;
+  sdxl_batch b;
+  bool valid = false;
+};
+struct sdxl_handle {
+  Engine e;
+  StepState step;
+};
+
+#define H_CHECK(h) ARG_CHECK((h) != nullptr, "null handle")
+#define CHK(x)         \
+  do {                 \
+    int _r = (x);      \
+    if (_r) return _r; \
+  } while (0)
+
+extern "C" {
+
+const char* sdxl_last_error(void) { return sdxl_get_error(); }
+int sdxl_version(void) { return 1; }
+
+int sdxl_default_config(sdxl_unet_config* c) {
+  ARG_CHECK(c, "null config");
+  c->in_channels = 4; c->out_channels = 4;
+  c->block_out_channels[0] = 320; c->block_out_channels[1] = 640; c->block_out_channels[2] = 1280;
+  c->layers_per_block = 2;
+  c->transformer_layers[0] = 0; c->transformer_layers[1] = 2; c->transformer_layers[2] = 10;
+  c->head_dim = 64; c->cross_attention_dim = 2048; c->norm_num_groups = 32;
+  c->addition_time_embed_dim = 256; c->pooled_dim = 1280;
+  c->resnet_eps = 1e-5f; c->tf_gn_eps = 1e-6f; c->ln_eps = 1e-5f;
+  return 0;
+}
+
+int sdxl_create(const sdxl_unet_config* cfg, int device, sdxl_handle** out) {
+  ARG_CHECK(cfg && out, "null argument");
+  ARG_CHECK(cfg->head_dim == 64, "head_dim must be 64 (got %d)", cfg->head_dim);
+  ARG_CHECK(cfg->in_channels == 4 && cfg->out_channels == 4, "in/out channels must be 4");
+  ARG_CHECK(cfg->transformer_layers[0] == 0, "level 0 must not have attention");
+  for (int i = 0; i < 3; ++i) {
+    int c = cfg->block_out_channels[i];
+    ARG_CHECK(c % cfg->norm_num_groups == 0 && c % 8 == 0, "block_out_channels[%d]=%d unsupported", i, c);
+    if (cfg->transformer_layers[i] > 0) ARG_CHECK(c % 128 == 0, "attention level width %d must be a multiple of 128", c);
+  }
+  ARG_CHECK(cfg->cross_attention_dim % 8 == 0 && cfg->pooled_dim % 8 == 0 && cfg->addition_time_embed_dim % 8 == 0,
+            "conditioning widths must be multiples of 8");
+  int ndev = 0;
+  HIP_CHECK_RET(hipGetDeviceCount(&ndev));
+  ARG_CHECK(device >= 0 && device < ndev, "device %d out of range (have %d)", device, ndev);
+  HIP_CHECK_RET(hipSetDevice(device));
+  sdxl_handle* h = new sdxl_handle();
+  h->e.cfg = *cfg;
+  h->e.device = device;
+  h->e.build(nullptr);
+  *out = h;
+  return 0;
+}
+
+int sdxl_destroy(sdxl_handle* h) {
+  if (!h) return 0;
+  if (h->e.own_weights && h->e.weights) (void)hipFree(h->e.weights);
+  if (h->e.own_grads && h->e.grads) (void)hipFree(h->e.grads);
+  if (h->e.own_ws && h->e.ws) (void)hipFree(h->e.ws);
+  delete h;
+  return 0;
+}
+
+int sdxl_param_bytes(sdxl_handle* h, size_t* wb, size_t* gb) {
+  H_CHECK(h);
+  if (wb) *wb = h->e.param_elems * sizeof(bf16);
+  if (gb) *gb = h->e.param_elems * sizeof(float);
+  return 0;
+}
+
+int sdxl_bind_params(sdxl_handle* h, void* w, void* g) {
+  H_CHECK(h);
+  Engine& e = h->e;
+  if (w) { e.weights = (bf16*)w; e.own_weights = false; }
+  else {
+    HIP_CHECK_RET(hipMalloc((void**)&e.weights, e.param_elems * sizeof(bf16)));
+    HIP_CHECK_RET(hipMemset(e.weights, 0, e.param_elems * sizeof(bf16)));
+    e.own_weights = true;
+  }
+  if (g) { e.grads = (float*)g; e.own_grads = false; }
+  else {
+    HIP_CHECK_RET(hipMalloc((void**)&e.grads, e.param_elems * sizeof(float)));
+    HIP_CHECK_RET(hipMemset(e.grads, 0, e.param_elems * sizeof(float)));
+    e.own_grads = true;
+  }
+  ARG_CHECK(((uintptr_t)e.weights & 255) == 0 && ((uintptr_t)e.grads & 255) == 0, "arenas must be 256-byte aligned");
+  return 0;
+}
+
+int sdxl_num_params(sdxl_handle* h) { return h ? (int)h->e.src.size() : -1; }
+
+int sdxl_param_info(sdxl_handle* h, int i, char* name, int cap, int* ndim, long shape[4]) {
+  H_CHECK(h);
+  ARG_CHECK(i >= 0 && i < (int)h->e.src.size(), "parameter index %d out of range", i);
+  const SrcParam& s = h->e.src[i];
+  if (name && cap > 0) snprintf(name, cap, "%s", s.name.c_str());
+  if (ndim) *ndim = s.ndim;
+  if (shape) for (int k = 0; k < 4; ++k) shape[k] = s.shape[k];
+  return 0;
+}
+
+int sdxl_load_weight(sdxl_handle* h, const char* name, const void* src, int dtype, void* st) {
+  H_CHECK(h);
+  ARG_CHECK(name && src, "null argument");
+  return engine_load_weight(h->e, name, src, dtype, (hipStream_t)st);
+}
+int sdxl_export_weight(sdxl_handle* h, const char* name, void* dst, int dtype, void* st) {
+  H_CHECK(h);
+  ARG_CHECK(name && dst, "null argument");
+  return engine_export(h->e, name, dst, dtype, false, (hipStream_t)st);
+}
+int sdxl_export_grad(sdxl_handle* h, const char* name, void* dst, int dtype, void* st) {
+  H_CHECK(h);
+  ARG_CHECK(name && dst, "null argument");
+  return engine_export(h->e, name, dst, dtype, true, (hipStream_t)st);
+}
+
+int sdxl_plan(sdxl_handle* h, int B, int H, int W, int ctx, size_t* ws_bytes) {
+  H_CHECK(h);
+  ARG_CHECK(B > 0 && H > 0 && W > 0 && ctx > 0, "bad plan shape B=%d H=%d W=%d ctx=%d", B, H, W, ctx);
+  ARG_CHECK(H % 4 == 0 && W % 4 == 0, "latent H=%d W=%d must be multiples of 4 (two stride-2 levels)", H, W);
+  Engine& e = h->e;
+  auto key = std::make_tuple(B, H, W, ctx);
+  auto it = e.plans.find(key);
+  if (it == e.plans.end()) {
+    std::unique_ptr<Plan> p(new Plan());
+    p->eng = &e;
+    p->B = B; p->H = H; p->W = W; p->ctx = ctx;
+    e.build(p.get());
+    it = e.plans.emplace(key, std::move(p)).first;
+  }
+  e.cur = it->second.get();
+  if (ws_bytes) *ws_bytes = e.cur->ws_bytes;
+  return 0;
+}
+
+int sdxl_bind_workspace(sdxl_handle* h, void* ws, size_t bytes) {
+  H_CHECK(h);
+  Engine& e = h->e;
+  if (ws) {
+    if (e.own_ws && e.ws) (void)hipFree(e.ws);
+    e.ws = (char*)ws; e.ws_cap = bytes; e.own_ws = false;
+  } else {
+    size_t need = bytes;
+    for (auto& kv : e.plans) if (kv.second->ws_bytes > need) need = kv.second->ws_bytes;
+    if (e.own_ws && e.ws && e.ws_cap >= need) return 0;
+    if (e.own_ws && e.ws) (void)hipFree(e.ws);
+    HIP_CHECK_RET(hipMalloc((void**)&e.ws, need));
+    e.ws_cap = need; e.own_ws = true;
+  }
+  ARG_CHECK(((uintptr_t)e.ws & 255) == 0, "workspace must be 256-byte aligned");
+  return 0;
+}
+
+static int ready(Engine& e) {
+  if (!e.cur) { sdxl_set_error("no plan: call sdxl_plan first"); return 3; }
+  if (!e.weights || !e.grads) { sdxl_set_error("parameters are not bound: call sdxl_bind_params"); return 3; }
+  if (!e.ws || e.ws_cap < e.cur->ws_bytes) {
+    sdxl_set_error("workspace too small: have %zu bytes, plan needs %zu", e.ws_cap, e.cur->ws_bytes);
+    return 3;
+  }
+  return 0;
+}
+
+int sdxl_zero_grads(sdxl_handle* h, void* st) {
+  H_CHECK(h);
+  ARG_CHECK(h->e.grads, "grads are not bound");
+  HIP_CHECK_RET(hipMemsetAsync(h->e.grads, 0, h->e.param_elems * sizeof(float), (hipStream_t)st));
+  return 0;
+}
+
+static int check_batch(Engine& e, const sdxl_batch* b) {
+  Plan& p = *e.cur;
+  ARG_CHECK(b, "null batch");
+  ARG_CHECK(b->B == p.B && b->H == p.H && b->W == p.W && b->ctx_len == p.ctx,
+            "batch shape (B=%d,H=%d,W=%d,ctx=%d) does not match the current plan (B=%d,H=%d,W=%d,ctx=%d)", b->B, b->H,
+            b->W, b->ctx_len, p.B, p.H, p.W, p.ctx);
+  ARG_CHECK(b->timestep && b->prompt_embeds && b->pooled && b->time_ids, "batch is missing conditioning pointers");
+  return 0;
+}
+
+static int upload_cond(Engine& e, const sdxl_batch* b, hipStream_t st) {
+  Plan& p = *e.cur;
+  const sdxl_unet_config& c = e.cfg;
+  HIP_CHECK_RET(hipMemcpyAsync(p.P(p.ehs), b->prompt_embeds, (size_t)p.B * p.ctx * c.cross_attention_dim * sizeof(bf16),
+                               hipMemcpyDeviceToDevice, st));
+  HIP_CHECK_RET(hipMemcpyAsync(p.F(p.t_off), b->timestep, sizeof(float) * p.B, hipMemcpyDeviceToDevice, st));
+  HIP_CHECK_RET(hipMemcpyAsync(p.F(p.tid_off), b->time_ids, sizeof(float) * p.B * 6, hipMemcpyDeviceToDevice, st));
+  CHK(launch_copy_cols((const bf16*)b->pooled, c.pooled_dim, p.P(p.aug_in), c.pooled_dim + 6L * c.addition_time_embed_dim,
+                       p.B, c.pooled_dim, st));
+  return 0;
+}
+
+static void fill_loss(Engine& e, const sdxl_loss_config* lc, const sdxl_batch* b, float grad_scale, LossP& L) {
+  Plan& p = *e.cur;
+  memset(&L, 0, sizeof(L));
+  L.method = lc->method; L.prediction_type = lc->prediction_type; L.use_min_snr = lc->use_min_snr;
+  L.min_snr_gamma = lc->min_snr_gamma; L.use_ztsnr = lc->use_ztsnr;
+  L.B = p.B; L.HW = p.H * p.W; L.C = 4;
+  L.latents = b->latents; L.noise = b->noise; L.sigma = b->sigma_or_t; L.tag_w = b->tag_weights;
+  L.unet_in = p.P(p.x_in); L.pred = p.P(p.pred); L.dpred = p.G(p.pred);
+  L.grad_scale = grad_scale;
+  L.out = p.F(p.loss_off);
+}
+
+
+static int run_forward_ops(Engine& e, hipStream_t st) {
+  Plan& p = *e.cur;
+  for (auto& op : p.ops) CHK(op->fwd(p, st));
+  return 0;
+}
+
+int sdxl_forward_loss(sdxl_handle* h, const sdxl_loss_config* lc, const sdxl_batch* b, void* stp) {
+  H_CHECK(h);
+  Engine& e = h->e;
+  hipStream_t st = (hipStream_t)stp;
+  CHK(ready(e));
+  ARG_CHECK(lc, "null loss config");
+  ARG_CHECK(lc->method == 0 || lc->method == 1, "unknown method %d", lc->method);
+  CHK(check_batch(e, b));
+  ARG_CHECK(b->latents && b->noise && b->sigma_or_t, "batch is missing latents/noise/sigma");
+  CHK(upload_cond(e, b, st));
+  LossP L;
+  fill_loss(e, lc, b, 1.f, L);
+  CHK(launch_loss_prepare(L, st));
+  CHK(run_forward_ops(e, st));
+  CHK(launch_loss_fwd(L, st));
+  h->step.lc = *lc; h->step.b = *b; h->step.valid = true;
+  return 0;
+}
+
+int sdxl_num_segments(sdxl_handle* h) { return h ? h->e.nseg : -1; }
+
+int sdxl_segment_range(sdxl_handle* h, int k, size_t* off, size_t* n) {
+  H_CHECK(h);
+  ARG_CHECK(k >= 0 && k < h->e.nseg, "segment %d out of range", k);
+  int s = h->e.nseg - 1 - k;
+  if (off) *off = h->e.seg_begin[s];
+  if (n) *n = h->e.seg_end[s] - h->e.seg_begin[s];
+  return 0;
+}
+
+static int run_backward_segment(Engine& e, int k, bool first, hipStream_t st) {
+  Plan& p = *e.cur;
+  int s = e.nseg - 1 - k;
+  for (int i = p.seg_last_op[s]; i >= p.seg_first_op[s] && i >= 0; --i) CHK(p.ops[i]->bwd(p, st, first));
+  return 0;
+}
+
+int sdxl_backward_segment(sdxl_handle* h, int k, float grad_scale, int first_micro, void* stp) {
+  H_CHECK(h);
+  Engine& e = h->e;
+  hipStream_t st = (hipStream_t)stp;
+  CHK(ready(e));
+  ARG_CHECK(k >= 0 && k < e.nseg, "segment %d out of range", k);
+  if (k == 0) {
+    ARG_CHECK(h->step.valid, "sdxl_backward_segment(0) needs a preceding sdxl_forward_loss");
+    LossP L;
+    fill_loss(e, &h->step.lc, &h->step.b, grad_scale, L);
+    CHK(launch_loss_bwd(L, st));
+  }
+  return run_backward_segment(e, k, first_micro != 0, st);
+}
+
+int sdxl_loss_fwd_bwd(sdxl_handle* h, const sdxl_loss_config* lc, const sdxl_batch* b, float grad_scale,
+                      int first_micro, void* st) {
+  CHK(sdxl_forward_loss(h, lc, b, st));
+  for (int k = 0; k < h->e.nseg; ++k) CHK(sdxl_backward_segment(h, k, grad_scale, first_micro, st));
+  return 0;
+}
+
+int sdxl_read_loss(sdxl_handle* h, float out[8], void* stp) {
+  H_CHECK(h);
+  CHK(ready(h->e));
+  hipStream_t st = (hipStream_t)stp;
+  HIP_CHECK_RET(hipMemcpyAsync(out, h->e.cur->F(h->e.cur->loss_off), 8 * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_CHECK_RET(hipStreamSynchronize(st));
+  return 0;
+}
+
+int sdxl_unet_forward(sdxl_handle* h, const void* sample, const sdxl_batch* cond, void* pred, void* stp) {
+  H_CHECK(h);
+  Engine& e = h->e;
+  hipStream_t st = (hipStream_t)stp;
+  CHK(ready(e));
+  CHK(check_batch(e, cond));
+  Plan& p = *e.cur;
+  CHK(upload_cond(e, cond, st));
+  size_t bytes = (size_t)p.B * p.H * p.W * 8 * sizeof(bf16);
+  HIP_CHECK_RET(hipMemcpyAsync(p.P(p.x_in), sample, bytes, hipMemcpyDeviceToDevice, st));
+  CHK(run_forward_ops(e, st));
+  if (pred) HIP_CHECK_RET(hipMemcpyAsync(pred, p.P(p.pred), bytes, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+int sdxl_unet_backward(sdxl_handle* h, const void* dpred, int first_micro, void* stp) {
+  H_CHECK(h);
+  Engine& e = h->e;
+  hipStream_t st = (hipStream_t)stp;
+  CHK(ready(e));
+  Plan& p = *e.cur;
+  size_t bytes = (size_t)p.B * p.H * p.W * 8 * sizeof(bf16);
+  HIP_CHECK_RET(hipMemcpyAsync(p.G(p.pred), dpred, bytes, hipMemcpyDeviceToDevice, st));
+  for (int k = 0; k < e.nseg; ++k) CHK(run_backward_segment(e, k, first_micro != 0, st));
+  return 0;
+}
+
+int sdxl_grads_to_bf16(sdxl_handle* h, size_t off, size_t n, void* dst, float scale, void* st) {
+  H_CHECK(h);
+  ARG_CHECK(h->e.grads && off + n <= h->e.param_elems, "range out of bounds");
+  return launch_f32_to_bf16(h->e.grads + off, (bf16*)dst, (long)n, scale, (hipStream_t)st);
+}
+
+int sdxl_grad_sumsq(sdxl_handle* h, float* out, void* st) {
+  H_CHECK(h);
+  ARG_CHECK(h->e.grads, "grads are not bound");
+  HIP_CHECK_RET(hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)st));
+  return launch_sumsq_f32(h->e.grads, (long)h->e.param_elems, out, (hipStream_t)st);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// single-kernel entry points
+// ------------------------------------------------------------------------------------------------------------
+int sdxl_op_gemm(int form, const void* A, const void* B, void* C, int M, int N, int K, const void* bias,
+                 const void* resid, int accumulate, int splitk, void* st) {
+  GemmP g;
+  gemm_defaults(&g);
+  g.form = form;
+  g.A = (const bf16*)A; g.B = (const bf16*)B; g.C = C;
+  g.M = M; g.N = N; g.K = K;
+  if (form == GEMM_NT) { g.lda = K; g.ldb = K; }
+  else if (form == GEMM_NN) { g.lda = K; g.ldb = N; }
+  else { g.lda = M; g.ldb = N; g.out_f32 = 1; g.splitk = splitk; }
+  g.ldc = N;
+  g.bias = (const bf16*)bias;
+  if (resid) { g.resid = (const bf16*)resid; g.ldr = N; }
+  g.accumulate = accumulate;
+  return launch_gemm(g, (hipStream_t)st);
+}
+
+int sdxl_op_conv3x3_fwd(const void* x, const void* w, const void* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                        int stride, void* st) {
+  int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  GemmP g;
+  gemm_defaults(&g);
+  g.form = GEMM_NT;
+  g.A = (const bf16*)x; g.B = (const bf16*)w; g.C = y;
+  g.M = B * Ho * Wo; g.N = Cout; g.K = Cin;
+  g.lda = Cin; g.ldb = 9L * Cin; g.ldc = Cout;
+  g.taps = 9; g.Hm = Ho; g.Wm = Wo; g.Hs = H; g.Ws = W; g.sm = stride; g.sd = 1;
+  g.b_tap_stride = Cin;
+  g.bias = (const bf16*)bias;
+  return launch_gemm(g, (hipStream_t)st);
+}
+int sdxl_op_conv3x3_dgrad(const void* dy, const void* w, void* dx, int B, int H, int W, int Cin, int Cout, int stride,
+                          void* st) {
+  int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  GemmP g;
+  gemm_defaults(&g);
+  g.form = GEMM_NN;
+  g.A = (const bf16*)dy; g.B = (const bf16*)w; g.C = dx;
+  g.M = B * H * W; g.N = Cin; g.K = Cout;
+  g.lda = Cout; g.ldb = 9L * Cin; g.ldc = Cin;
+  g.taps = 9; g.Hm = H; g.Wm = W; g.Hs = Ho; g.Ws = Wo; g.sm = 1; g.sd = stride;
+  g.flip = 1; g.b_tap_stride = Cin;
+  return launch_gemm(g, (hipStream_t)st);
+}
+int sdxl_op_conv3x3_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, int stride,
+                          int splitk, void* st) {
+  int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  GemmP g;
+  gemm_defaults(&g);
+  g.form = GEMM_TN;
+  g.A = (const bf16*)dy; g.B = (const bf16*)x; g.C = dw;
+  g.M = Cout; g.N = Cin; g.K = B * Ho * Wo;
+  g.lda = Cout; g.ldb = Cin; g.ldc = 9L * Cin;
+  g.taps = 9; g.Hm = Ho; g.Wm = Wo; g.Hs = H; g.Ws = W; g.sm = stride; g.sd = 1;
+  g.c_tap_stride = Cin;
+  g.out_f32 = 1; g.splitk = splitk; g.accumulate = 1;
+  return launch_gemm(g, (hipStream_t)st);
+}
+
+int sdxl_op_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int heads, int Nq,
+                          int Nk, long ldq, long ldk, long ldv, long ldo, void* st) {
+  AttnP a;
+  memset(&a, 0, sizeof(a));
+  a.Q = (const bf16*)q; a.K = (const bf16*)k; a.V = (const bf16*)v; a.O = (bf16*)o; a.LSE = lse;
+  a.B = B; a.H = heads; a.Nq = Nq; a.Nk = Nk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+  return launch_attn_fwd(a, (hipStream_t)st);
+}
+int sdxl_op_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                          float* delta, void* dq, void* dk, void* dv, int B, int heads, int Nq, int Nk, long ldq,
+                          long ldk, long ldv, long ldo, void* st) {
+  AttnP a;
+  memset(&a, 0, sizeof(a));
+  a.Q = (const bf16*)q; a.K = (const bf16*)k; a.V = (const bf16*)v; a.O = (bf16*)o; a.LSE = (float*)lse;
+  a.B = B; a.H = heads; a.Nq = Nq; a.Nk = Nk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+  a.dO = (const bf16*)d_o; a.lddo = ldo; a.Delta = delta;
+  a.dQ = (bf16*)dq; a.dK = (bf16*)dk; a.dV = (bf16*)dv; a.lddq = ldq; a.lddk = ldk; a.lddv = ldv;
+  return launch_attn_bwd(a, (hipStream_t)st);
+}
+
+int sdxl_op_groupnorm_fwd(const void* x, void* y, const void* gamma, const void* beta, float* stats, float* ws, int B,
+                          int HW, int C, int G, float eps, int silu, void* st) {
+  return launch_groupnorm_fwd((const bf16*)x, (bf16*)y, (const bf16*)gamma, (const bf16*)beta, stats, ws, B, HW, C, G, eps,
+                              silu, (hipStream_t)st);
+}
+int sdxl_op_groupnorm_bwd(const void* x, const void* dy, const void* gamma, const void* beta, const float* stats, void* dx,
+                          float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int G, int silu, int accumulate,
+                          void* st) {
+  return launch_groupnorm_bwd((const bf16*)x, (const bf16*)dy, (const bf16*)gamma, (const bf16*)beta, stats, (bf16*)dx,
+                              dgamma, dbeta, ws, B, HW, C, G, silu, accumulate, (hipStream_t)st);
+}
+int sdxl_op_layernorm_fwd(const void* x, void* y, const void* gamma, const void* beta, float* stats, int M, int C,
+                          float eps, void* st) {
+  return launch_layernorm_fwd((const bf16*)x, (bf16*)y, (const bf16*)gamma, (const bf16*)beta, stats, M, C, eps,
+                              (hipStream_t)st);
+}
+int sdxl_op_layernorm_bwd(const void* x, const void* dy, const void* gamma, const float* stats, void* dx, float* dgamma,
+                          float* dbeta, int M, int C, int accumulate, void* st) {
+  return launch_layernorm_bwd((const bf16*)x, (const bf16*)dy, (const bf16*)gamma, stats, (bf16*)dx, dgamma, dbeta, M, C,
+                              accumulate, (hipStream_t)st);
+}
+int sdxl_op_geglu_fwd(const void* u, void* g, int M, int C4, void* st) {
+  return launch_geglu_fwd((const bf16*)u, (bf16*)g, M, C4, (hipStream_t)st);
+}
+int sdxl_op_geglu_bwd(const void* u, const void* dg, void* du, int M, int C4, void* st) {
+  return launch_geglu_bwd((const bf16*)u, (const bf16*)dg, (bf16*)du, M, C4, (hipStream_t)st);
+}
+
+int sdxl_op_loss(const sdxl_loss_config* lc, const sdxl_batch* b, void* unet_in, const void* pred, void* dpred,
+                 float grad_scale, float* out8, int phase, void* st) {
+  ARG_CHECK(lc && b, "null argument");
+  LossP L;
+  memset(&L, 0, sizeof(L));
+  L.method = lc->method; L.prediction_type = lc->prediction_type; L.use_min_snr = lc->use_min_snr;
+  L.min_snr_gamma = lc->min_snr_gamma; L.use_ztsnr = lc->use_ztsnr;
+  L.B = b->B; L.HW = b->H * b->W; L.C = 4;
+  L.latents = b->latents; L.noise = b->noise; L.sigma = b->sigma_or_t; L.tag_w = b->tag_weights;
+  L.unet_in = (bf16*)unet_in; L.pred = (const bf16*)pred; L.dpred = (bf16*)dpred;
+  L.grad_scale = grad_scale; L.out = out8;
+  if (phase == 0) return launch_loss_prepare(L, (hipStream_t)st);
+  if (phase == 1) return launch_loss_fwd(L, (hipStream_t)st);
+  if (phase == 2) return launch_loss_bwd(L, (hipStream_t)st);
+  ARG_CHECK(false, "phase %d", phase);
+}
+
+int sdxl_probe_layout(void* out, void* st) { return probe_layout(out, (hipStream_t)st); }
+
+}  // extern "C"

@@ -1,0 +1,285 @@
+// Elementwise / data-movement kernels (HBM-bound): 16-byte vectors, grid-stride, fp32 math.
+#include "kernels.h"
+
+#define EW_BLOCK 256
+static inline int ew_grid(long nvec) {
+  long g = (nvec + EW_BLOCK - 1) / EW_BLOCK;
+  if (g > 4096) g = 4096;  // 16 blocks per CU, grid-stride the rest
+  if (g < 1) g = 1;
+  return (int)g;
+}
+#define VEC_LOOP(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+
+// ------------------------------------------------------------------ GEGLU
+__global__ void geglu_fwd_kernel(const bf16* __restrict__ u, bf16* __restrict__ g, long M, int C4) {
+  const int vpr = C4 / 8;
+  VEC_LOOP(i, M * vpr) {
+    long r = i / vpr;
+    int c = (int)(i - r * vpr) * 8;
+    bf16x8 a = *(const bf16x8*)(u + r * 2 * C4 + c);
+    bf16x8 t = *(const bf16x8*)(u + r * 2 * C4 + C4 + c);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)a[e] * gelu_f((float)t[e]));
+    *(bf16x8*)(g + r * C4 + c) = o;
+  }
+}
+__global__ void geglu_bwd_kernel(const bf16* __restrict__ u, const bf16* __restrict__ dg, bf16* __restrict__ du,
+                                 long M, int C4) {
+  const int vpr = C4 / 8;
+  VEC_LOOP(i, M * vpr) {
+    long r = i / vpr;
+    int c = (int)(i - r * vpr) * 8;
+    bf16x8 a = *(const bf16x8*)(u + r * 2 * C4 + c);
+    bf16x8 t = *(const bf16x8*)(u + r * 2 * C4 + C4 + c);
+    bf16x8 d = *(const bf16x8*)(dg + r * C4 + c);
+    bf16x8 oa, ot;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float tv = (float)t[e], dv = (float)d[e];
+      oa[e] = (bf16)(dv * gelu_f(tv));
+      ot[e] = (bf16)(dv * (float)a[e] * gelu_grad_f(tv));
+    }
+    *(bf16x8*)(du + r * 2 * C4 + c) = oa;
+    *(bf16x8*)(du + r * 2 * C4 + C4 + c) = ot;
+  }
+}
+int launch_geglu_fwd(const bf16* u, bf16* g, int M, int C4, hipStream_t st) {
+  ARG_CHECK(C4 % 8 == 0, "geglu: C4=%d", C4);
+  long nv = (long)M * (C4 / 8);
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, u, g, (long)M, C4);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int launch_geglu_bwd(const bf16* u, const bf16* dg, bf16* du, int M, int C4, hipStream_t st) {
+  ARG_CHECK(C4 % 8 == 0, "geglu: C4=%d", C4);
+  long nv = (long)M * (C4 / 8);
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, u, dg, du, (long)M, C4);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ SiLU / add (flat, n % 8 == 0)
+__global__ void silu_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, long nvec) {
+  VEC_LOOP(i, nvec) {
+    bf16x8 v = *(const bf16x8*)(x + i * 8), o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16)silu_f((float)v[e]);
+    *(bf16x8*)(y + i * 8) = o;
+  }
+}
+template <bool ACC>
+__global__ void silu_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, bf16* __restrict__ dx,
+                                long nvec) {
+  VEC_LOOP(i, nvec) {
+    bf16x8 v = *(const bf16x8*)(x + i * 8), d = *(const bf16x8*)(dy + i * 8), o;
+    if (ACC) o = *(const bf16x8*)(dx + i * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float g = (float)d[e] * silu_grad_f((float)v[e]);
+      if (ACC) g += (float)o[e];
+      o[e] = (bf16)g;
+    }
+    *(bf16x8*)(dx + i * 8) = o;
+  }
+}
+__global__ void add_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ o, long nvec) {
+  VEC_LOOP(i, nvec) {
+    bf16x8 x = *(const bf16x8*)(a + i * 8), y = *(const bf16x8*)(b + i * 8), r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (bf16)((float)x[e] + (float)y[e]);
+    *(bf16x8*)(o + i * 8) = r;
+  }
+}
+int launch_silu_fwd(const bf16* x, bf16* y, long n, hipStream_t st) {
+  ARG_CHECK(n % 8 == 0, "silu: n=%ld", n);
+  hipLaunchKernelGGL(silu_fwd_kernel, dim3(ew_grid(n / 8)), dim3(EW_BLOCK), 0, st, x, y, n / 8);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int launch_silu_bwd(const bf16* x, const bf16* dy, bf16* dx, long n, int accumulate, hipStream_t st) {
+  ARG_CHECK(n % 8 == 0, "silu: n=%ld", n);
+  if (accumulate) hipLaunchKernelGGL(silu_bwd_kernel<true>, dim3(ew_grid(n / 8)), dim3(EW_BLOCK), 0, st, x, dy, dx, n / 8);
+  else hipLaunchKernelGGL(silu_bwd_kernel<false>, dim3(ew_grid(n / 8)), dim3(EW_BLOCK), 0, st, x, dy, dx, n / 8);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int launch_add(const bf16* a, const bf16* b, bf16* o, long n, hipStream_t st) {
+  ARG_CHECK(n % 8 == 0, "add: n=%ld", n);
+  hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n / 8)), dim3(EW_BLOCK), 0, st, a, b, o, n / 8);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ concat / split along channels
+__global__ void concat_kernel(const bf16* __restrict__ a, int Ca, const bf16* __restrict__ b, int Cb,
+                              bf16* __restrict__ o, long rows) {
+  const int va = Ca / 8, vt = (Ca + Cb) / 8;
+  VEC_LOOP(i, rows * vt) {
+    long r = i / vt;
+    int v = (int)(i - r * vt);
+    bf16x8 x = v < va ? *(const bf16x8*)(a + r * Ca + v * 8) : *(const bf16x8*)(b + r * Cb + (v - va) * 8);
+    *(bf16x8*)(o + i * 8) = x;
+  }
+}
+__global__ void split_add_kernel(const bf16* __restrict__ g, bf16* __restrict__ ga, int Ca, int acc_a,
+                                 bf16* __restrict__ gb, int Cb, int acc_b, long rows) {
+  const int va = Ca / 8, vt = (Ca + Cb) / 8;
+  VEC_LOOP(i, rows * vt) {
+    long r = i / vt;
+    int v = (int)(i - r * vt);
+    bf16x8 x = *(const bf16x8*)(g + i * 8);
+    bf16* dst = v < va ? ga + r * Ca + v * 8 : gb + r * Cb + (v - va) * 8;
+    if (v < va ? acc_a : acc_b) {
+      bf16x8 y = *(const bf16x8*)dst;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = (bf16)((float)x[e] + (float)y[e]);
+    }
+    *(bf16x8*)dst = x;
+  }
+}
+int launch_concat(const bf16* a, int Ca, const bf16* b, int Cb, bf16* o, long rows, hipStream_t st) {
+  ARG_CHECK(Ca % 8 == 0 && Cb % 8 == 0, "concat: Ca=%d Cb=%d", Ca, Cb);
+  long nv = rows * ((Ca + Cb) / 8);
+  hipLaunchKernelGGL(concat_kernel, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, a, Ca, b, Cb, o, rows);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int launch_split_add(const bf16* g, bf16* ga, int Ca, int acc_a, bf16* gb, int Cb, int acc_b, long rows,
+                     hipStream_t st) {
+  ARG_CHECK(Ca % 8 == 0 && Cb % 8 == 0, "split: Ca=%d Cb=%d", Ca, Cb);
+  long nv = rows * ((Ca + Cb) / 8);
+  hipLaunchKernelGGL(split_add_kernel, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, g, ga, Ca, acc_a, gb, Cb, acc_b, rows);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ nearest 2x upsample (token-major)
+__global__ void upsample2x_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int B, int H, int W, int C) {
+  const int vpr = C / 8;
+  const long n = (long)B * (2 * H) * (2 * W) * vpr;
+  VEC_LOOP(i, n) {
+    long pix = i / vpr;
+    int v = (int)(i - pix * vpr);
+    int xo = (int)(pix % (2 * W));
+    long t = pix / (2 * W);
+    int yo = (int)(t % (2 * H));
+    int b = (int)(t / (2 * H));
+    long src = ((long)b * H + (yo >> 1)) * W + (xo >> 1);
+    *(bf16x8*)(y + i * 8) = *(const bf16x8*)(x + src * C + v * 8);
+  }
+}
+template <bool ACC>
+__global__ void upsample2x_bwd_kernel(const bf16* __restrict__ dy, bf16* __restrict__ dx, int B, int H, int W, int C) {
+  const int vpr = C / 8;
+  const long n = (long)B * H * W * vpr;
+  VEC_LOOP(i, n) {
+    long pix = i / vpr;
+    int v = (int)(i - pix * vpr);
+    int xi = (int)(pix % W);
+    long t = pix / W;
+    int yi = (int)(t % H);
+    int b = (int)(t / H);
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int dyy = 0; dyy < 2; ++dyy)
+#pragma unroll
+      for (int dxx = 0; dxx < 2; ++dxx) {
+        long src = ((long)b * 2 * H + 2 * yi + dyy) * 2 * W + 2 * xi + dxx;
+        bf16x8 g = *(const bf16x8*)(dy + src * C + v * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += (float)g[e];
+      }
+    bf16x8 o;
+    if (ACC) o = *(const bf16x8*)(dx + i * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16)(ACC ? s[e] + (float)o[e] : s[e]);
+    *(bf16x8*)(dx + i * 8) = o;
+  }
+}
+int launch_upsample2x(const bf16* x, bf16* y, int B, int H, int W, int C, hipStream_t st) {
+  ARG_CHECK(C % 8 == 0, "upsample: C=%d", C);
+  long nv = (long)B * 4 * H * W * (C / 8);
+  hipLaunchKernelGGL(upsample2x_kernel, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, x, y, B, H, W, C);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int launch_upsample2x_bwd(const bf16* dy, bf16* dx, int B, int H, int W, int C, int accumulate, hipStream_t st) {
+  ARG_CHECK(C % 8 == 0, "upsample: C=%d", C);
+  long nv = (long)B * H * W * (C / 8);
+  if (accumulate) hipLaunchKernelGGL(upsample2x_bwd_kernel<true>, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, dy, dx, B, H, W, C);
+  else hipLaunchKernelGGL(upsample2x_bwd_kernel<false>, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, dy, dx, B, H, W, C);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ sinusoidal embedding (cos first)
+__global__ void sincos_kernel(const float* __restrict__ t, bf16* __restrict__ out, int rows, int dim, long ldo) {
+  const int half = dim / 2;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * half) return;
+  int r = i / half, k = i - r * half;
+  float f = expf(-9.210340371976184f * (float)k / (float)half);  // ln(10000)
+  float a = t[r] * f;
+  out[(long)r * ldo + k] = (bf16)cosf(a);
+  out[(long)r * ldo + half + k] = (bf16)sinf(a);
+}
+int launch_sincos(const float* t, bf16* out, int rows, int dim, long ldo, hipStream_t st) {
+  ARG_CHECK(dim % 2 == 0, "sincos: dim=%d", dim);
+  int n = rows * (dim / 2);
+  hipLaunchKernelGGL(sincos_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, t, out, rows, dim, ldo);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ small utilities
+__global__ void copy_cols_kernel(const bf16* __restrict__ src, long lds_, bf16* __restrict__ dst, long ldd, int rows,
+                                 int cols) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  int r = i / cols, c = i - r * cols;
+  dst[(long)r * ldd + c] = src[(long)r * lds_ + c];
+}
+int launch_copy_cols(const bf16* src, long lds_, bf16* dst, long ldd, int rows, int cols, hipStream_t st) {
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(cdiv((long)rows * cols, 256)), dim3(256), 0, st, src, lds_, dst, ldd, rows, cols);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, long n, float scale) {
+  VEC_LOOP(i, n) y[i] = (bf16)(x[i] * scale);
+}
+__global__ void bf16_to_f32_kernel(const bf16* __restrict__ x, float* __restrict__ y, long n) {
+  VEC_LOOP(i, n) y[i] = (float)x[i];
+}
+int launch_f32_to_bf16(const float* x, bf16* y, long n, float scale, hipStream_t st) {
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, y, n, scale);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int launch_bf16_to_f32(const bf16* x, float* y, long n, hipStream_t st) {
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, st, x, y, n);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+__global__ void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+  float s = 0.f;
+  VEC_LOOP(i, n) s += x[i] * x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+int launch_sumsq_f32(const float* x, long n, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(sumsq_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_BLOCK), 0, st, x, n, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+__global__ void scale_kernel(float* __restrict__ x, long n, const float* __restrict__ scale) {
+  const float s = *scale;
+  VEC_LOOP(i, n) x[i] *= s;
+}
+int launch_scale_f32(float* x, long n, const float* scale_dev, hipStream_t st) {
+  hipLaunchKernelGGL(scale_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_BLOCK), 0, st, x, n, scale_dev);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,124 @@
+// Static execution plan ("tape") of the SDXL UNet training step.
+//
+// Engine  = configuration + packed parameters (bf16 weight arena, fp32 gradient arena) shared by all plans.
+// Plan    = one bucket shape (B, H, W): every activation, gradient, statistic and scratch buffer has a fixed
+//           offset in one workspace arena, every op holds resolved offsets, and forward / backward are plain
+//           in-order / reverse-order walks that only launch kernels (no allocation, no host sync, no autograd).
+// Gradient buffers are assigned while walking the tape in reverse: the first writer of a tensor's gradient
+// overwrites, later writers accumulate, and a residual connection's gradient is an alias of its output's.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/sdxlstep.h"
+#include "kernels.h"
+
+static const size_t NONE = (size_t)-1;
+
+struct Act {           // bf16 activation [rows][cols] in the workspace
+  size_t off = NONE;   // byte offset of data
+  size_t goff = NONE;  // byte offset of gradient (assigned in reverse planning)
+  long rows = 0;
+  int cols = 0;
+  bool need_grad = true;
+};
+
+struct PRef {  // native parameter: element offset into the bf16 weight arena and the fp32 grad arena
+  size_t off = NONE;
+  size_t numel = 0;
+};
+
+struct SrcParam {  // one diffusers state-dict tensor and where it lives in the native arena
+  std::string name;
+  int ndim;
+  long shape[4];
+  PRef native;
+  int kind;  // 0: rows copied at elem_off ; 1: conv3x3 [co][ci][3][3] -> [co][9][ci_pad]
+  size_t elem_off;
+  int ci_pad;
+};
+
+struct Engine;
+struct Plan;
+
+struct Op {
+  int seg = 0;
+  virtual ~Op() {}
+  virtual int fwd(Plan& p, hipStream_t st) = 0;
+  virtual void plan_bwd(Plan& p) = 0;
+  virtual int bwd(Plan& p, hipStream_t st, bool first_micro) = 0;
+};
+
+struct Plan {
+  Engine* eng = nullptr;
+  int B = 0, H = 0, W = 0, ctx = 0;
+  size_t ws_bytes = 0;   // bytes needed
+  size_t cursor = 0;
+  std::vector<std::unique_ptr<Act>> acts;
+  std::vector<std::unique_ptr<Op>> ops;
+  std::vector<int> seg_first_op, seg_last_op;  // op index ranges per segment (forward order)
+  // well-known buffers
+  Act *x_in = nullptr, *pred = nullptr, *ehs = nullptr, *aug_in = nullptr, *te_sin = nullptr, *tid_emb = nullptr;
+  size_t t_off = NONE, tid_off = NONE, loss_off = NONE;
+
+  Act* new_act(long rows, int cols, bool need_grad = true);
+  size_t alloc(size_t bytes);
+  int grad_write(Act* a);           // reverse planning: returns accumulate flag; allocates on first write
+  bool grad_alias(Act* x, Act* y);  // x.g := y.g when x has none yet
+  template <class T, class... A>
+  T* add(A&&... a);
+  // pointers (valid once a workspace is bound)
+  bf16* P(const Act* a) const;
+  bf16* G(const Act* a) const;
+  float* F(size_t off) const;
+};
+
+struct Engine {
+  sdxl_unet_config cfg;
+  int device = 0;
+  // parameters
+  std::vector<PRef> natives;  // in creation (= forward) order
+  std::vector<SrcParam> src;
+  std::map<std::string, int> src_index;
+  size_t param_elems = 0;
+  bf16* weights = nullptr;
+  float* grads = nullptr;
+  bool own_weights = false, own_grads = false;
+  // segments: contiguous native-parameter ranges (forward order)
+  int nseg = 1;
+  std::vector<size_t> seg_begin, seg_end;
+  // plans
+  std::map<std::tuple<int, int, int, int>, std::unique_ptr<Plan>> plans;
+  Plan* cur = nullptr;
+  char* ws = nullptr;
+  size_t ws_cap = 0;
+  bool own_ws = false;
+  // builder state
+  bool registering = true;
+  size_t native_cursor = 0;
+  Plan* bp = nullptr;  // plan being built (nullptr while registering parameters)
+
+  PRef param(size_t numel);
+  void map_src(const std::string& name, std::vector<long> shape, PRef p, int kind, size_t elem_off, int ci_pad);
+  int seg_of(size_t elem_off) const;
+  void build(Plan* plan);  // registers parameters (plan == nullptr) or builds a plan
+  bf16* Wp(PRef p) const { return weights + p.off; }
+  float* Gp(PRef p) const { return grads + p.off; }
+};
+
+inline bf16* Plan::P(const Act* a) const { return (bf16*)(eng->ws + a->off); }
+inline bf16* Plan::G(const Act* a) const { return a->goff == NONE ? nullptr : (bf16*)(eng->ws + a->goff); }
+inline float* Plan::F(size_t off) const { return (float*)(eng->ws + off); }
+template <class T, class... A>
+T* Plan::add(A&&... a) {
+  T* o = new T(std::forward<A>(a)...);
+  ops.emplace_back(o);
+  return o;
+}
+
+int engine_load_weight(Engine& e, const char* name, const void* src, int dtype, hipStream_t st);
+int engine_export(Engine& e, const char* name, void* dst, int dtype, bool grad, hipStream_t st);
+int probe_layout(void* out, hipStream_t st);

@@ -1,0 +1,747 @@
+// UNet plan builder, op implementations (forward + backward), parameter import/export.
+// Architecture = public SDXL-base UNet2DConditionModel semantics; the reference
+// reaches it through diffusers at ddpm_trainer.py:320-325 and flow_matching_trainer.py:400-405.
+#include "engine.h"
+
+#include <stdarg.h>
+
+static thread_local char g_err[1024] = "";
+void sdxl_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* sdxl_get_error() { return g_err; }
+
+#define CHK(x)            \
+  do {                    \
+    int _r = (x);         \
+    if (_r) return _r;    \
+  } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ================================================================================================
+// Plan memory
+// ================================================================================================
+size_t Plan::alloc(size_t bytes) {
+  size_t off = cursor;
+  cursor = align_up(cursor + bytes, 256);
+  ws_bytes = cursor;
+  return off;
+}
+Act* Plan::new_act(long rows, int cols, bool need_grad) {
+  Act* a = new Act();
+  a->rows = rows;
+  a->cols = cols;
+  a->need_grad = need_grad;
+  a->off = alloc((size_t)rows * cols * sizeof(bf16));
+  acts.emplace_back(a);
+  return a;
+}
+int Plan::grad_write(Act* a) {
+  if (a->goff == NONE) {
+    a->goff = alloc((size_t)a->rows * a->cols * sizeof(bf16));
+    return 0;
+  }
+  return 1;
+}
+bool Plan::grad_alias(Act* x, Act* y) {
+  if (x->goff == NONE) {
+    x->goff = y->goff;
+    return true;
+  }
+  return false;
+}
+
+// ================================================================================================
+// Ops
+// ================================================================================================
+static int pick_splitk(long out_rows, long out_cols, int taps, long red) {
+  long tiles = (long)cdiv(out_rows, 128) * cdiv(out_cols, 128) * taps;
+  long ktiles = cdiv(red, 64);
+  long s = 640 / tiles;
+  if (s < 1) s = 1;
+  long maxs = ktiles / 4;
+  if (maxs < 1) maxs = 1;
+  if (s > maxs) s = maxs;
+  if (s > 64) s = 64;
+  return (int)s;
+}
+
+struct LinearOp : Op {
+  Act *x, *y, *resid;
+  PRef w, b;
+  int K, N;
+  int acc_x = 0, resid_alias = 0, splitk = 1;
+  LinearOp(Act* x_, Act* y_, PRef w_, PRef b_, int K_, int N_, Act* resid_) : x(x_), y(y_), resid(resid_), w(w_), b(b_), K(K_), N(N_) {}
+  int fwd(Plan& p, hipStream_t st) override {
+    GemmP g;
+    gemm_defaults(&g);
+    g.form = GEMM_NT;
+    g.A = p.P(x); g.B = p.eng->Wp(w); g.C = p.P(y);
+    g.M = (int)x->rows; g.N = N; g.K = K;
+    g.lda = K; g.ldb = K; g.ldc = N;
+    g.bias = b.off == NONE ? nullptr : p.eng->Wp(b);
+    if (resid) { g.resid = p.P(resid); g.ldr = N; }
+    return launch_gemm(g, st);
+  }
+  void plan_bwd(Plan& p) override {
+    if (resid) resid_alias = p.grad_alias(resid, y) ? 1 : 0;
+    if (x->need_grad) acc_x = p.grad_write(x);
+    splitk = pick_splitk(N, K, 1, x->rows);
+  }
+  int bwd(Plan& p, hipStream_t st, bool first) override {
+    const bf16* dy = p.G(y);
+    const int M = (int)x->rows;
+    if (resid && !resid_alias) CHK(launch_add(p.G(resid), dy, p.G(resid), (long)M * N, st));
+    if (x->need_grad) {
+      GemmP g;
+      gemm_defaults(&g);
+      g.form = GEMM_NN;
+      g.A = dy; g.B = p.eng->Wp(w); g.C = p.G(x);
+      g.M = M; g.N = K; g.K = N;
+      g.lda = N; g.ldb = K; g.ldc = K;
+      g.accumulate = acc_x;
+      CHK(launch_gemm(g, st));
+    }
+    {
+      GemmP g;
+      gemm_defaults(&g);
+      g.form = GEMM_TN;
+      g.A = dy; g.B = p.P(x); g.C = p.eng->Gp(w);
+      g.M = N; g.N = K; g.K = M;
+      g.lda = N; g.ldb = K; g.ldc = K;
+      g.out_f32 = 1;
+      g.splitk = splitk;
+      g.accumulate = (splitk > 1 || !first) ? 1 : 0;
+      CHK(launch_gemm(g, st));
+    }
+    if (b.off != NONE) CHK(launch_colsum_f32(dy, p.eng->Gp(b), M, N, N, st));
+    return 0;
+  }
+};
+
+struct ConvOp : Op {
+  Act *x, *y, *resid, *rowvec;
+  PRef w, b;
+  int Bn, H, W, Cin, Cout, stride, Ho, Wo;
+  int acc_x = 0, resid_alias = 0, acc_rv = 0, splitk = 1;
+  size_t tmp_off = NONE;  // fp32 [B][Cout] for the rowvec gradient
+  ConvOp(Act* x_, Act* y_, PRef w_, PRef b_, int B_, int H_, int W_, int Cin_, int Cout_, int stride_, Act* resid_,
+         Act* rowvec_)
+      : x(x_), y(y_), resid(resid_), rowvec(rowvec_), w(w_), b(b_), Bn(B_), H(H_), W(W_), Cin(Cin_), Cout(Cout_),
+        stride(stride_) {
+    Ho = (H - 1) / stride + 1;
+    Wo = (W - 1) / stride + 1;
+  }
+  int fwd(Plan& p, hipStream_t st) override {
+    GemmP g;
+    gemm_defaults(&g);
+    g.form = GEMM_NT;
+    g.A = p.P(x); g.B = p.eng->Wp(w); g.C = p.P(y);
+    g.M = Bn * Ho * Wo; g.N = Cout; g.K = Cin;
+    g.lda = Cin; g.ldb = 9L * Cin; g.ldc = Cout;
+    g.taps = 9; g.Hm = Ho; g.Wm = Wo; g.Hs = H; g.Ws = W; g.sm = stride; g.sd = 1;
+    g.b_tap_stride = Cin;
+    g.bias = p.eng->Wp(b);
+    if (resid) { g.resid = p.P(resid); g.ldr = Cout; }
+    if (rowvec) { g.rowvec = p.P(rowvec); g.ldv = Cout; g.rows_per_batch = Ho * Wo; }
+    return launch_gemm(g, st);
+  }
+  void plan_bwd(Plan& p) override {
+    if (resid) resid_alias = p.grad_alias(resid, y) ? 1 : 0;
+    if (rowvec) { acc_rv = p.grad_write(rowvec); tmp_off = p.alloc(sizeof(float) * Bn * Cout); }
+    if (x->need_grad) acc_x = p.grad_write(x);
+    splitk = pick_splitk(Cout, Cin, 9, (long)Bn * Ho * Wo);
+  }
+  int bwd(Plan& p, hipStream_t st, bool first) override {
+    const bf16* dy = p.G(y);
+    const long Mo = (long)Bn * Ho * Wo;
+    if (resid && !resid_alias) CHK(launch_add(p.G(resid), dy, p.G(resid), Mo * Cout, st));
+    if (rowvec) {
+      float* tmp = p.F(tmp_off);
+      HIP_CHECK_RET(hipMemsetAsync(tmp, 0, sizeof(float) * Bn * Cout, st));
+      for (int bi = 0; bi < Bn; ++bi)
+        CHK(launch_colsum_f32(dy + (long)bi * Ho * Wo * Cout, tmp + (long)bi * Cout, Ho * Wo, Cout, Cout, st));
+      if (acc_rv) {
+        sdxl_set_error("conv: accumulating rowvec gradient is not supported");
+        return 3;
+      }
+      CHK(launch_f32_to_bf16(tmp, p.G(rowvec), (long)Bn * Cout, 1.f, st));
+    }
+    if (x->need_grad) {
+      GemmP g;
+      gemm_defaults(&g);
+      g.form = GEMM_NN;
+      g.A = dy; g.B = p.eng->Wp(w); g.C = p.G(x);
+      g.M = Bn * H * W; g.N = Cin; g.K = Cout;
+      g.lda = Cout; g.ldb = 9L * Cin; g.ldc = Cin;
+      g.taps = 9; g.Hm = H; g.Wm = W; g.Hs = Ho; g.Ws = Wo; g.sm = 1; g.sd = stride;
+      g.flip = 1; g.b_tap_stride = Cin;
+      g.accumulate = acc_x;
+      CHK(launch_gemm(g, st));
+    }
+    {
+      GemmP g;
+      gemm_defaults(&g);
+      g.form = GEMM_TN;
+      g.A = dy; g.B = p.P(x); g.C = p.eng->Gp(w);
+      g.M = Cout; g.N = Cin; g.K = (int)Mo;
+      g.lda = Cout; g.ldb = Cin; g.ldc = 9L * Cin;
+      g.taps = 9; g.Hm = Ho; g.Wm = Wo; g.Hs = H; g.Ws = W; g.sm = stride; g.sd = 1;
+      g.c_tap_stride = Cin;
+      g.out_f32 = 1;
+      g.splitk = splitk;
+      g.accumulate = (splitk > 1 || !first) ? 1 : 0;
+      CHK(launch_gemm(g, st));
+    }
+    CHK(launch_colsum_f32(dy, p.eng->Gp(b), (int)Mo, Cout, Cout, st));
+    return 0;
+  }
+};
+
+struct GroupNormOp : Op {
+  Act *x, *y;
+  PRef gm, bt;
+  int Bn, HW, C, G, silu;
+  float eps;
+  size_t stats_off, ws_off;
+  int acc_x = 0;
+  GroupNormOp(Plan& p, Act* x_, Act* y_, PRef g_, PRef b_, int B_, int HW_, int C_, int G_, float eps_, int silu_)
+      : x(x_), y(y_), gm(g_), bt(b_), Bn(B_), HW(HW_), C(C_), G(G_), silu(silu_), eps(eps_) {
+    stats_off = p.alloc(sizeof(float) * Bn * G * 2);
+    ws_off = p.alloc(sizeof(float) * ((size_t)Bn * G * 2 + (size_t)Bn * C * 6));
+  }
+  int fwd(Plan& p, hipStream_t st) override {
+    return launch_groupnorm_fwd(p.P(x), p.P(y), p.eng->Wp(gm), p.eng->Wp(bt), p.F(stats_off), p.F(ws_off), Bn, HW, C, G,
+                                eps, silu, st);
+  }
+  void plan_bwd(Plan& p) override { acc_x = p.grad_write(x); }
+  int bwd(Plan& p, hipStream_t st, bool) override {
+    return launch_groupnorm_bwd(p.P(x), p.G(y), p.eng->Wp(gm), p.eng->Wp(bt), p.F(stats_off), p.G(x), p.eng->Gp(gm),
+                                p.eng->Gp(bt), p.F(ws_off), Bn, HW, C, G, silu, acc_x, st);
+  }
+};
+
+struct LayerNormOp : Op {
+  Act *x, *y;
+  PRef gm, bt;
+  int C;
+  float eps;
+  size_t stats_off;
+  int acc_x = 0;
+  LayerNormOp(Plan& p, Act* x_, Act* y_, PRef g_, PRef b_, int C_, float eps_) : x(x_), y(y_), gm(g_), bt(b_), C(C_), eps(eps_) {
+    stats_off = p.alloc(sizeof(float) * x->rows * 2);
+  }
+  int fwd(Plan& p, hipStream_t st) override {
+    return launch_layernorm_fwd(p.P(x), p.P(y), p.eng->Wp(gm), p.eng->Wp(bt), p.F(stats_off), (int)x->rows, C, eps, st);
+  }
+  void plan_bwd(Plan& p) override { acc_x = p.grad_write(x); }
+  int bwd(Plan& p, hipStream_t st, bool) override {
+    return launch_layernorm_bwd(p.P(x), p.G(y), p.eng->Wp(gm), p.F(stats_off), p.G(x), p.eng->Gp(gm), p.eng->Gp(bt),
+                                (int)x->rows, C, acc_x, st);
+  }
+};
+
+// self attention: qkv [B*N][3C]; cross attention: q [B*N][C], kv [B*ctx][2C]
+struct AttnOp : Op {
+  Act *q, *kv, *o;  // self: q == kv == qkv tensor
+  int Bn, heads, Nq, Nk, C;
+  bool self;
+  size_t lse_off, delta_off;
+  AttnOp(Plan& p, Act* q_, Act* kv_, Act* o_, int B_, int heads_, int Nq_, int Nk_, int C_, bool self_)
+      : q(q_), kv(kv_), o(o_), Bn(B_), heads(heads_), Nq(Nq_), Nk(Nk_), C(C_), self(self_) {
+    lse_off = p.alloc(sizeof(float) * (size_t)Bn * heads * Nq);
+    delta_off = p.alloc(sizeof(float) * (size_t)Bn * heads * Nq);
+  }
+  void fill(Plan& p, AttnP& a, bool grads) {
+    memset(&a, 0, sizeof(a));
+    a.B = Bn; a.H = heads; a.Nq = Nq; a.Nk = Nk;
+    if (self) {
+      a.Q = p.P(q); a.K = p.P(q) + C; a.V = p.P(q) + 2 * C;
+      a.ldq = a.ldk = a.ldv = 3L * C;
+    } else {
+      a.Q = p.P(q); a.ldq = C;
+      a.K = p.P(kv); a.V = p.P(kv) + C; a.ldk = a.ldv = 2L * C;
+    }
+    a.O = p.P(o); a.ldo = C;
+    a.LSE = p.F(lse_off);
+    if (grads) {
+      a.dO = p.G(o); a.lddo = C;
+      a.Delta = p.F(delta_off);
+      if (self) {
+        a.dQ = p.G(q); a.dK = p.G(q) + C; a.dV = p.G(q) + 2 * C;
+        a.lddq = a.lddk = a.lddv = 3L * C;
+      } else {
+        a.dQ = p.G(q); a.lddq = C;
+        a.dK = p.G(kv); a.dV = p.G(kv) + C; a.lddk = a.lddv = 2L * C;
+      }
+    }
+  }
+  int fwd(Plan& p, hipStream_t st) override {
+    AttnP a;
+    fill(p, a, false);
+    return launch_attn_fwd(a, st);
+  }
+  bool bad = false;
+  void plan_bwd(Plan& p) override {
+    if (p.grad_write(q)) bad = true;
+    if (!self && p.grad_write(kv)) bad = true;
+  }
+  int bwd(Plan& p, hipStream_t st, bool) override {
+    if (bad) { sdxl_set_error("attention: operand gradient has another writer"); return 3; }
+    AttnP a;
+    fill(p, a, true);
+    return launch_attn_bwd(a, st);
+  }
+};
+
+struct GegluOp : Op {
+  Act *u, *g;
+  int C4;
+  bool bad = false;
+  GegluOp(Act* u_, Act* g_, int C4_) : u(u_), g(g_), C4(C4_) {}
+  int fwd(Plan& p, hipStream_t st) override { return launch_geglu_fwd(p.P(u), p.P(g), (int)u->rows, C4, st); }
+  void plan_bwd(Plan& p) override { if (p.grad_write(u)) bad = true; }
+  int bwd(Plan& p, hipStream_t st, bool) override {
+    if (bad) { sdxl_set_error("geglu: operand gradient has another writer"); return 3; }
+    return launch_geglu_bwd(p.P(u), p.G(g), p.G(u), (int)u->rows, C4, st);
+  }
+};
+
+struct SiluOp : Op {
+  Act *x, *y;
+  int acc = 0;
+  SiluOp(Act* x_, Act* y_) : x(x_), y(y_) {}
+  int fwd(Plan& p, hipStream_t st) override { return launch_silu_fwd(p.P(x), p.P(y), x->rows * x->cols, st); }
+  void plan_bwd(Plan& p) override { acc = p.grad_write(x); }
+  int bwd(Plan& p, hipStream_t st, bool) override {
+    return launch_silu_bwd(p.P(x), p.G(y), p.G(x), x->rows * x->cols, acc, st);
+  }
+};
+
+struct ConcatOp : Op {
+  Act *a, *b, *o;
+  int acc_a = 0, acc_b = 0;
+  ConcatOp(Act* a_, Act* b_, Act* o_) : a(a_), b(b_), o(o_) {}
+  int fwd(Plan& p, hipStream_t st) override { return launch_concat(p.P(a), a->cols, p.P(b), b->cols, p.P(o), a->rows, st); }
+  void plan_bwd(Plan& p) override { acc_a = p.grad_write(a); acc_b = p.grad_write(b); }
+  int bwd(Plan& p, hipStream_t st, bool) override {
+    return launch_split_add(p.G(o), p.G(a), a->cols, acc_a, p.G(b), b->cols, acc_b, a->rows, st);
+  }
+};
+
+struct UpsampleOp : Op {
+  Act *x, *y;
+  int Bn, H, W, C, acc = 0;
+  UpsampleOp(Act* x_, Act* y_, int B_, int H_, int W_, int C_) : x(x_), y(y_), Bn(B_), H(H_), W(W_), C(C_) {}
+  int fwd(Plan& p, hipStream_t st) override { return launch_upsample2x(p.P(x), p.P(y), Bn, H, W, C, st); }
+  void plan_bwd(Plan& p) override { acc = p.grad_write(x); }
+  int bwd(Plan& p, hipStream_t st, bool) override { return launch_upsample2x_bwd(p.G(y), p.G(x), Bn, H, W, C, acc, st); }
+};
+
+// conditioning embeddings (inputs only: no gradient).  t -> sincos(320); time_ids -> sincos(256) x 6;
+// aug_in = [pooled | time-id embedding]
+struct EmbedInOp : Op {
+  int fwd(Plan& p, hipStream_t st) override {
+    const sdxl_unet_config& c = p.eng->cfg;
+    const int B = p.B, ch0 = c.block_out_channels[0], ad = c.addition_time_embed_dim;
+    CHK(launch_sincos(p.F(p.t_off), p.P(p.te_sin), B, ch0, ch0, st));
+    CHK(launch_sincos(p.F(p.tid_off), p.P(p.tid_emb), B * 6, ad, ad, st));
+    CHK(launch_copy_cols(p.P(p.tid_emb), 6L * ad, p.P(p.aug_in) + c.pooled_dim, c.pooled_dim + 6L * ad, B, 6 * ad, st));
+    return 0;
+  }
+  void plan_bwd(Plan&) override {}
+  int bwd(Plan&, hipStream_t, bool) override { return 0; }
+};
+
+// ================================================================================================
+// Parameters
+// ================================================================================================
+PRef Engine::param(size_t numel) {
+  if (registering) {
+    PRef p;
+    p.off = param_elems;
+    p.numel = numel;
+    param_elems = align_up(param_elems + numel, 64);
+    natives.push_back(p);
+    return p;
+  }
+  PRef p = natives.at(native_cursor++);
+  if (p.numel != numel) {
+    fprintf(stderr, "sdxlstep: internal error: parameter walk mismatch (%zu vs %zu)\n", p.numel, numel);
+    abort();
+  }
+  return p;
+}
+
+void Engine::map_src(const std::string& name, std::vector<long> shape, PRef p, int kind, size_t elem_off, int ci_pad) {
+  if (!registering) return;
+  SrcParam s;
+  s.name = name;
+  s.ndim = (int)shape.size();
+  for (int i = 0; i < 4; ++i) s.shape[i] = i < s.ndim ? shape[i] : 1;
+  s.native = p;
+  s.kind = kind;
+  s.elem_off = elem_off;
+  s.ci_pad = ci_pad;
+  src_index[name] = (int)src.size();
+  src.push_back(s);
+}
+
+int Engine::seg_of(size_t elem_off) const {
+  for (int s = 0; s < nseg; ++s)
+    if (elem_off >= seg_begin[s] && elem_off < seg_end[s]) return s;
+  return nseg - 1;
+}
+
+// ================================================================================================
+// Builder: one walk that either registers parameters (bp == nullptr) or emits the plan's ops
+// ================================================================================================
+namespace {
+struct Builder {
+  Engine& e;
+  Plan* pl;
+  int B, H, W, ctx;
+  int last_seg = 0;
+  Act* emb_act = nullptr;
+  explicit Builder(Engine& e_, Plan* p_) : e(e_), pl(p_) {
+    if (pl) { B = pl->B; H = pl->H; W = pl->W; ctx = pl->ctx; } else { B = H = W = ctx = 0; }
+  }
+  template <class T>
+  T* tagseg(T* op, PRef first) {
+    if (first.off != NONE) last_seg = e.seg_of(first.off);
+    op->seg = last_seg;
+    return op;
+  }
+  // ---- layers ----
+  Act* linear(const std::string& name, Act* x, int K, int N, bool bias, Act* resid) {
+    PRef w = e.param((size_t)N * K);
+    e.map_src(name + ".weight", {N, K}, w, 0, 0, 0);
+    PRef b;
+    if (bias) { b = e.param(N); e.map_src(name + ".bias", {N}, b, 0, 0, 0); }
+    if (!pl) return nullptr;
+    Act* y = pl->new_act(x->rows, N);
+    tagseg(pl->add<LinearOp>(x, y, w, b, K, N, resid), w);
+    return y;
+  }
+  // fused projection of several [Ni, K] source matrices into one [sum Ni, K] native matrix (no bias)
+  Act* linear_fused(const std::vector<std::string>& names, Act* x, int K, int Neach) {
+    const int n = (int)names.size();
+    PRef w = e.param((size_t)n * Neach * K);
+    for (int i = 0; i < n; ++i) e.map_src(names[i] + ".weight", {Neach, K}, w, 0, (size_t)i * Neach * K, 0);
+    if (!pl) return nullptr;
+    Act* y = pl->new_act(x->rows, n * Neach);
+    tagseg(pl->add<LinearOp>(x, y, w, PRef(), K, n * Neach, nullptr), w);
+    return y;
+  }
+  Act* conv(const std::string& name, Act* x, int h, int w_, int cin, int cout, int stride, Act* resid, Act* rowvec,
+            int cin_src = -1, int cout_src = -1) {
+    if (cin_src < 0) cin_src = cin;
+    if (cout_src < 0) cout_src = cout;
+    PRef w = e.param((size_t)cout * 9 * cin);
+    e.map_src(name + ".weight", {cout_src, cin_src, 3, 3}, w, 1, 0, cin);
+    PRef b = e.param(cout);
+    e.map_src(name + ".bias", {cout_src}, b, 0, 0, 0);
+    if (!pl) return nullptr;
+    int ho = (h - 1) / stride + 1, wo = (w_ - 1) / stride + 1;
+    Act* y = pl->new_act((long)B * ho * wo, cout);
+    tagseg(pl->add<ConvOp>(x, y, w, b, B, h, w_, cin, cout, stride, resid, rowvec), w);
+    return y;
+  }
+  Act* groupnorm(const std::string& name, Act* x, int hw, int C, float eps, int silu) {
+    PRef g = e.param(C);
+    e.map_src(name + ".weight", {C}, g, 0, 0, 0);
+    PRef b = e.param(C);
+    e.map_src(name + ".bias", {C}, b, 0, 0, 0);
+    if (!pl) return nullptr;
+    Act* y = pl->new_act(x->rows, C);
+    tagseg(pl->add<GroupNormOp>(*pl, x, y, g, b, B, hw, C, e.cfg.norm_num_groups, eps, silu), g);
+    return y;
+  }
+  Act* layernorm(const std::string& name, Act* x, int C) {
+    PRef g = e.param(C);
+    e.map_src(name + ".weight", {C}, g, 0, 0, 0);
+    PRef b = e.param(C);
+    e.map_src(name + ".bias", {C}, b, 0, 0, 0);
+    if (!pl) return nullptr;
+    Act* y = pl->new_act(x->rows, C);
+    tagseg(pl->add<LayerNormOp>(*pl, x, y, g, b, C, e.cfg.ln_eps), g);
+    return y;
+  }
+  Act* silu(Act* x) {
+    if (!pl) return nullptr;
+    Act* y = pl->new_act(x->rows, x->cols);
+    tagseg(pl->add<SiluOp>(x, y), PRef());
+    return y;
+  }
+  Act* resnet(const std::string& p, Act* x, int h, int w_, int cin, int cout) {
+    Act* n1 = groupnorm(p + ".norm1", x, h * w_, cin, e.cfg.resnet_eps, 1);
+    // diffusers key order: norm1, conv1, time_emb_proj, norm2, conv2, conv_shortcut.  The time projection must
+    // run before conv1 consumes it, so parameters are registered in execution order instead.
+    Act* tp = linear(p + ".time_emb_proj", emb_act, e.cfg.block_out_channels[0] * 4, cout, true, nullptr);
+    Act* c1 = conv(p + ".conv1", n1, h, w_, cin, cout, 1, nullptr, tp);
+    Act* n2 = groupnorm(p + ".norm2", c1, h * w_, cout, e.cfg.resnet_eps, 1);
+    Act* sc = x;
+    if (cin != cout) sc = linear(p + ".conv_shortcut", x, cin, cout, true, nullptr);
+    return conv(p + ".conv2", n2, h, w_, cout, cout, 1, sc, nullptr);
+  }
+  Act* tf_block(const std::string& b, Act* x, Act* ehs, int C, int N) {
+    const int heads = C / e.cfg.head_dim, cross = e.cfg.cross_attention_dim;
+    Act* l1 = layernorm(b + ".norm1", x, C);
+    Act* qkv = linear_fused({b + ".attn1.to_q", b + ".attn1.to_k", b + ".attn1.to_v"}, l1, C, C);
+    Act* a1 = nullptr;
+    if (pl) {
+      a1 = pl->new_act(x->rows, C);
+      tagseg(pl->add<AttnOp>(*pl, qkv, qkv, a1, B, heads, N, N, C, true), PRef());
+    }
+    Act* x1 = linear(b + ".attn1.to_out.0", a1, C, C, true, x);
+    Act* l2 = layernorm(b + ".norm2", x1, C);
+    Act* q = linear(b + ".attn2.to_q", l2, C, C, false, nullptr);
+    Act* kv = linear_fused({b + ".attn2.to_k", b + ".attn2.to_v"}, ehs, cross, C);
+    Act* a2 = nullptr;
+    if (pl) {
+      a2 = pl->new_act(x->rows, C);
+      tagseg(pl->add<AttnOp>(*pl, q, kv, a2, B, heads, N, ctx, C, false), PRef());
+    }
+    Act* x2 = linear(b + ".attn2.to_out.0", a2, C, C, true, x1);
+    Act* l3 = layernorm(b + ".norm3", x2, C);
+    Act* u = linear(b + ".ff.net.0.proj", l3, C, 8 * C, true, nullptr);
+    Act* g = nullptr;
+    if (pl) {
+      g = pl->new_act(x->rows, 4 * C);
+      tagseg(pl->add<GegluOp>(u, g, 4 * C), PRef());
+    }
+    return linear(b + ".ff.net.2", g, 4 * C, C, true, x2);
+  }
+  Act* transformer(const std::string& p, Act* x, Act* ehs, int h, int w_, int C, int depth) {
+    Act* n = groupnorm(p + ".norm", x, h * w_, C, e.cfg.tf_gn_eps, 0);
+    Act* t = linear(p + ".proj_in", n, C, C, true, nullptr);
+    for (int k = 0; k < depth; ++k) t = tf_block(p + ".transformer_blocks." + std::to_string(k), t, ehs, C, h * w_);
+    return linear(p + ".proj_out", t, C, C, true, x);
+  }
+  void run() {
+    const sdxl_unet_config& c = e.cfg;
+    const int* ch = c.block_out_channels;
+    const int temb = ch[0] * 4;
+    const int add_in = c.pooled_dim + 6 * c.addition_time_embed_dim;
+    Act *x_in = nullptr, *ehs = nullptr, *te_sin = nullptr, *aug_in = nullptr;
+    if (pl) {
+      pl->x_in = x_in = pl->new_act((long)B * H * W, 8, false);
+      pl->ehs = ehs = pl->new_act((long)B * ctx, c.cross_attention_dim, false);
+      pl->te_sin = te_sin = pl->new_act(B, ch[0], false);
+      pl->tid_emb = pl->new_act((long)B * 6, c.addition_time_embed_dim, false);
+      pl->aug_in = aug_in = pl->new_act(B, add_in, false);
+      pl->t_off = pl->alloc(sizeof(float) * B);
+      pl->tid_off = pl->alloc(sizeof(float) * B * 6);
+      pl->loss_off = pl->alloc(sizeof(float) * 8);
+      tagseg(pl->add<EmbedInOp>(), PRef());
+    }
+    Act* t1 = linear("time_embedding.linear_1", te_sin, ch[0], temb, true, nullptr);
+    Act* t1s = silu(t1);
+    Act* t2 = linear("time_embedding.linear_2", t1s, temb, temb, true, nullptr);
+    Act* a1 = linear("add_embedding.linear_1", aug_in, add_in, temb, true, nullptr);
+    Act* a1s = silu(a1);
+    Act* emb = linear("add_embedding.linear_2", a1s, temb, temb, true, t2);
+    emb_act = silu(emb);
+
+    Act* x = conv("conv_in", x_in, H, W, 8, ch[0], 1, nullptr, nullptr, c.in_channels, ch[0]);
+    struct Skip { Act* a; int c; };
+    std::vector<Skip> skips;
+    skips.push_back({x, ch[0]});
+    int h = H, w = W, prev = ch[0];
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < c.layers_per_block; ++j) {
+        std::string p = "down_blocks." + std::to_string(i);
+        x = resnet(p + ".resnets." + std::to_string(j), x, h, w, prev, ch[i]);
+        prev = ch[i];
+        if (c.transformer_layers[i] > 0)
+          x = transformer(p + ".attentions." + std::to_string(j), x, ehs, h, w, ch[i], c.transformer_layers[i]);
+        skips.push_back({x, prev});
+      }
+      if (i < 2) {
+        x = conv("down_blocks." + std::to_string(i) + ".downsamplers.0.conv", x, h, w, prev, prev, 2, nullptr, nullptr);
+        h = (h - 1) / 2 + 1;
+        w = (w - 1) / 2 + 1;
+        skips.push_back({x, prev});
+      }
+    }
+    x = resnet("mid_block.resnets.0", x, h, w, prev, prev);
+    x = transformer("mid_block.attentions.0", x, ehs, h, w, prev, c.transformer_layers[2]);
+    x = resnet("mid_block.resnets.1", x, h, w, prev, prev);
+    for (int ui = 0; ui < 3; ++ui) {
+      const int lvl = 2 - ui;
+      std::string p = "up_blocks." + std::to_string(ui);
+      for (int j = 0; j < c.layers_per_block + 1; ++j) {
+        Skip s = skips.back();
+        skips.pop_back();
+        Act* cat = nullptr;
+        if (pl) {
+          cat = pl->new_act(x->rows, prev + s.c);
+          tagseg(pl->add<ConcatOp>(x, s.a, cat), PRef());
+        }
+        x = resnet(p + ".resnets." + std::to_string(j), cat, h, w, prev + s.c, ch[lvl]);
+        prev = ch[lvl];
+        if (c.transformer_layers[lvl] > 0)
+          x = transformer(p + ".attentions." + std::to_string(j), x, ehs, h, w, prev, c.transformer_layers[lvl]);
+      }
+      if (ui < 2) {
+        Act* up = nullptr;
+        if (pl) {
+          up = pl->new_act((long)B * 4 * h * w, prev);
+          tagseg(pl->add<UpsampleOp>(x, up, B, h, w, prev), PRef());
+        }
+        h *= 2;
+        w *= 2;
+        x = conv(p + ".upsamplers.0.conv", up, h, w, prev, prev, 1, nullptr, nullptr);
+      }
+    }
+    Act* no = groupnorm("conv_norm_out", x, h * w, prev, c.resnet_eps, 1);
+    Act* out = conv("conv_out", no, h, w, prev, 8, 1, nullptr, nullptr, prev, c.out_channels);
+    if (pl) pl->pred = out;
+  }
+};
+}  // namespace
+
+void Engine::build(Plan* plan) {
+  registering = plan == nullptr;
+  native_cursor = 0;
+  Builder b(*this, plan);
+  b.run();
+  if (registering) {
+    // segments: contiguous parameter ranges of ~96M elements (forward order)
+    const size_t target = 96u << 20;
+    seg_begin.clear();
+    seg_end.clear();
+    size_t start = 0;
+    for (size_t i = 0; i < natives.size(); ++i) {
+      size_t end = i + 1 < natives.size() ? natives[i + 1].off : param_elems;
+      if (end - start >= target || i + 1 == natives.size()) {
+        seg_begin.push_back(start);
+        seg_end.push_back(end);
+        start = end;
+      }
+    }
+    nseg = (int)seg_begin.size();
+    registering = false;
+  } else {
+    // reverse planning: the loss writes d(pred)
+    plan->grad_write(plan->pred);
+    for (int i = (int)plan->ops.size() - 1; i >= 0; --i) plan->ops[i]->plan_bwd(*plan);
+    plan->seg_first_op.assign(nseg, -1);
+    plan->seg_last_op.assign(nseg, -2);
+    for (int i = 0; i < (int)plan->ops.size(); ++i) {
+      int s = plan->ops[i]->seg;
+      if (plan->seg_first_op[s] < 0) plan->seg_first_op[s] = i;
+      plan->seg_last_op[s] = i;
+    }
+  }
+}
+
+// ================================================================================================
+// Parameter import / export (PyTorch layout <-> packed native layout)
+// ================================================================================================
+template <typename TS, typename TD>
+__global__ void repack_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long n, int kind, int co, int ci,
+                              int ci_pad, int to_native) {
+  // kind 0: flat copy.  kind 1: src [co][ci][3][3] <-> native [co][9][ci_pad]
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long s = i, d = i;
+    if (kind == 1) {
+      long o = i / ((long)ci * 9);
+      long rem = i - o * (long)ci * 9;
+      int c = (int)(rem / 9), tap = (int)(rem - (long)c * 9);
+      long nat = (o * 9 + tap) * ci_pad + c;
+      if (to_native) { s = i; d = nat; } else { s = nat; d = i; }
+    }
+    dst[d] = (TD)(float)src[s];
+  }
+}
+
+template <typename TS, typename TD>
+static int repack_launch(const TS* src, TD* dst, long n, const SrcParam& sp, int to_native, hipStream_t st) {
+  long g = (n + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL((repack_kernel<TS, TD>), dim3((int)g), dim3(256), 0, st, src, dst, n, sp.kind, (int)sp.shape[0],
+                     (int)sp.shape[1], sp.ci_pad, to_native);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+static const SrcParam* find_src(Engine& e, const char* name) {
+  auto it = e.src_index.find(name);
+  if (it == e.src_index.end()) {
+    sdxl_set_error("unknown parameter '%s'", name);
+    return nullptr;
+  }
+  return &e.src[it->second];
+}
+
+int engine_load_weight(Engine& e, const char* name, const void* srcp, int dtype, hipStream_t st) {
+  const SrcParam* sp = find_src(e, name);
+  if (!sp) return 1;
+  ARG_CHECK(e.weights, "weights are not bound");
+  long n = 1;
+  for (int i = 0; i < sp->ndim; ++i) n *= sp->shape[i];
+  bf16* dst = e.weights + sp->native.off + sp->elem_off;
+  if (dtype == 0) return repack_launch((const float*)srcp, dst, n, *sp, 1, st);
+  if (dtype == 1) return repack_launch((const bf16*)srcp, dst, n, *sp, 1, st);
+  ARG_CHECK(false, "dtype %d not supported (0 = fp32, 1 = bf16)", dtype);
+}
+
+int engine_export(Engine& e, const char* name, void* dstp, int dtype, bool grad, hipStream_t st) {
+  const SrcParam* sp = find_src(e, name);
+  if (!sp) return 1;
+  long n = 1;
+  for (int i = 0; i < sp->ndim; ++i) n *= sp->shape[i];
+  size_t off = sp->native.off + sp->elem_off;
+  if (grad) {
+    ARG_CHECK(e.grads, "grads are not bound");
+    const float* s = e.grads + off;
+    if (dtype == 0) return repack_launch(s, (float*)dstp, n, *sp, 0, st);
+    if (dtype == 1) return repack_launch(s, (bf16*)dstp, n, *sp, 0, st);
+  } else {
+    ARG_CHECK(e.weights, "weights are not bound");
+    const bf16* s = e.weights + off;
+    if (dtype == 0) return repack_launch(s, (float*)dstp, n, *sp, 0, st);
+    if (dtype == 1) return repack_launch(s, (bf16*)dstp, n, *sp, 0, st);
+  }
+  ARG_CHECK(false, "dtype %d not supported (0 = fp32, 1 = bf16)", dtype);
+}
+
+// ================================================================================================
+// Hardware layout probe: what ds_read_b64_tr_b16 and the 16x16x32 MFMA really do on this chip.
+// out[0..1023]   : transpose-read result, lane l element j (as float) from an LDS image holding value = index
+// out[1024..1279]: C[16][16] of A.B with A[i][k] = (i==k), B[k][j] = k*16+j  (k < 16), via the slot convention
+// ================================================================================================
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+__global__ void probe_kernel(float* out) {
+  __shared__ __attribute__((aligned(16))) bf16 t[64 * 16];
+  const int l = threadIdx.x;
+  for (int i = l; i < 64 * 16; i += 64) t[i] = (bf16)(float)(i & 255);
+  __syncthreads();
+  // four 16-lane groups; group g reads the [4][16] block starting at row 4g of a 16-column image
+  const int l16 = l & 15, g = l >> 4;
+  const bf16* p0 = t + (g * 4 + (l16 >> 2)) * 16 + (l16 & 3) * 4;
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)p0);
+  union { s16x4 s; bf16x4 b; } u;
+  u.s = v;
+  for (int j = 0; j < 4; ++j) out[l * 4 + j] = (float)u.b[j];
+  // MFMA probe
+  bf16x8 a, b;
+  for (int j = 0; j < 8; ++j) {
+    int k = g * 8 + j;
+    a[j] = (bf16)((k == l16) ? 1.f : 0.f);                 // A[i=l16][k]
+    b[j] = (bf16)((k < 16) ? (float)(k * 16 + l16) : 0.f);  // B[k][j=l16]
+  }
+  f32x4 c = {0.f, 0.f, 0.f, 0.f};
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) out[1024 + l * 4 + r] = c[r];
+}
+int probe_layout(void* out, hipStream_t st) {
+  hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, st, (float*)out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}

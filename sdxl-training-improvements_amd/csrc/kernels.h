@@ -1,0 +1,129 @@
+// Launcher declarations for every hand-written gfx950 kernel family of the SDXL training step.
+// All tensors are bf16, token-major ("NHWC"): an activation is a row-major [rows = B*H*W, C] matrix.
+// All launchers are stream-ordered and return 0 on success (non-zero + sdxl_last_error() otherwise).
+#pragma once
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// bf16 MFMA GEMM family (gemm.hip).  C[M,N] = sum_k A(m,k) * B(k,n), fp32 accumulate.
+//   NT: A [M][K] K-contiguous (optionally rows gathered from an image = implicit-GEMM conv),
+//       B [N][K] K-contiguous                     -> Linear forward, conv3x3 forward
+//   NN: A as NT, B [K][N] N-contiguous            -> Linear dgrad, conv3x3 dgrad
+//   TN: A [K][M] M-contiguous, B [K][N] N-contiguous (optionally rows gathered) -> wgrad
+// ------------------------------------------------------------------------------------------------
+enum { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
+
+struct GemmP {
+  int form;
+  const bf16* A;
+  const bf16* B;
+  void* C;
+  int M, N, K;      // K = reduction length per tap (channels for conv forms, pixels for TN)
+  long lda, ldb, ldc;
+  // implicit-GEMM 3x3 gather (taps == 9).  The gathered operand's rows are pixels (b,y,x) of an
+  // Hm x Wm image; tap (dy,dx) reads source pixel ((y*sm+dy-1)/sd, (x*sm+dx-1)/sd) of an Hs x Ws
+  // image when divisible and in range, else zero.
+  int taps;
+  int Hm, Wm, Hs, Ws, sm, sd;
+  int flip;            // NT/NN: weight tap index = flip ? 8-tap : tap
+  long b_tap_stride;   // NT/NN: elements added to B per weight tap
+  long c_tap_stride;   // TN: elements added to C per tap
+  // epilogue, bf16 output:  C = acc + bias[n] + rowvec[m / rows_per_batch][n] + resid[m][n]
+  const bf16* bias;
+  const bf16* resid;
+  long ldr;
+  const bf16* rowvec;
+  long ldv;
+  int rows_per_batch;
+  // fp32 output (wgrad): C_f32 (+)= acc ; atomic when splitk > 1
+  int out_f32;
+  int accumulate;
+  int splitk;
+};
+void gemm_defaults(GemmP* p);
+int launch_gemm(const GemmP& p, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------------
+// flash attention, head_dim 64 (attention.hip).  Q rows [B*Nq], K/V rows [B*Nk]; head h lives in
+// columns [h*64, h*64+64) of each; row strides ldq/ldk/ldv/ldo in elements.  softmax scale 1/8.
+// ------------------------------------------------------------------------------------------------
+struct AttnP {
+  const bf16 *Q, *K, *V;
+  bf16* O;
+  float* LSE;          // [B*H][Nq]  log-sum-exp of the scaled scores (natural log)
+  int B, H, Nq, Nk;
+  long ldq, ldk, ldv, ldo;
+  // backward
+  const bf16* dO;
+  long lddo;
+  bf16 *dQ, *dK, *dV;
+  long lddq, lddk, lddv;
+  float* Delta;        // [B*H][Nq]  rowsum(dO * O)
+  int accumulate;      // dQ/dK/dV += (else =)
+};
+int launch_attn_fwd(const AttnP& p, hipStream_t st);
+int launch_attn_bwd(const AttnP& p, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------------
+// normalisation (norm.hip)
+// ------------------------------------------------------------------------------------------------
+// GroupNorm over [B][HW][C] with G groups (+ optional SiLU).  stats: [B][G][2] = mean, rstd.
+int launch_groupnorm_fwd(const bf16* x, bf16* y, const bf16* gamma, const bf16* beta, float* stats,
+                         float* ws /* B*C*2 floats */, int B, int HW, int C, int G, float eps, int silu,
+                         hipStream_t st);
+// dx (+)= ; dgamma/dbeta fp32 += .  ws: B*C*2 floats
+int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const bf16* beta,
+                         const float* stats, bf16* dx, float* dgamma, float* dbeta, float* ws, int B, int HW,
+                         int C, int G, int silu, int accumulate, hipStream_t st);
+// LayerNorm over rows of [M][C]; stats [M][2] = mean, rstd
+int launch_layernorm_fwd(const bf16* x, bf16* y, const bf16* gamma, const bf16* beta, float* stats, int M,
+                         int C, float eps, hipStream_t st);
+int launch_layernorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const float* stats, bf16* dx,
+                         float* dgamma, float* dbeta, int M, int C, int accumulate, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------------
+// elementwise / small (elementwise.hip)
+// ------------------------------------------------------------------------------------------------
+int launch_geglu_fwd(const bf16* u, bf16* g, int M, int C4, hipStream_t st);            // u [M][2*C4]
+int launch_geglu_bwd(const bf16* u, const bf16* dg, bf16* du, int M, int C4, hipStream_t st);
+int launch_silu_fwd(const bf16* x, bf16* y, long n, hipStream_t st);
+int launch_silu_bwd(const bf16* x, const bf16* dy, bf16* dx, long n, int accumulate, hipStream_t st);
+int launch_add(const bf16* a, const bf16* b, bf16* o, long n, hipStream_t st);           // o = a + b
+int launch_colsum_f32(const bf16* x, float* out, int M, int N, long ldx, hipStream_t st);  // out[n] += sum_m
+int launch_concat(const bf16* a, int Ca, const bf16* b, int Cb, bf16* o, long rows, hipStream_t st);
+int launch_split_add(const bf16* g, bf16* ga, int Ca, int acc_a, bf16* gb, int Cb, int acc_b, long rows,
+                     hipStream_t st);                                                  // concat backward
+int launch_upsample2x(const bf16* x, bf16* y, int B, int H, int W, int C, hipStream_t st);
+int launch_upsample2x_bwd(const bf16* dy, bf16* dx, int B, int H, int W, int C, int accumulate, hipStream_t st);
+// sinusoidal embedding, cos first: out[r][0:half]=cos(t*f_i), out[r][half:]=sin ; out row stride ldo
+int launch_sincos(const float* t, bf16* out, int rows, int dim, long ldo, hipStream_t st);
+int launch_copy_cols(const bf16* src, long lds, bf16* dst, long ldd, int rows, int cols, hipStream_t st);
+int launch_f32_to_bf16(const float* x, bf16* y, long n, float scale, hipStream_t st);
+int launch_bf16_to_f32(const bf16* x, float* y, long n, hipStream_t st);
+int launch_sumsq_f32(const float* x, long n, float* out /* += */, hipStream_t st);
+int launch_scale_f32(float* x, long n, const float* scale_dev, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------------
+// loss side (loss.hip) -- restates reference compute_loss arithmetic on device
+// ------------------------------------------------------------------------------------------------
+struct LossP {
+  int method;             // 0 = ddpm, 1 = flow matching
+  int prediction_type;    // ddpm: 0 = epsilon, 1 = v_prediction
+  int use_min_snr;        // ddpm
+  float min_snr_gamma;
+  int use_ztsnr;          // clamp noisy latents to +-20000
+  int B, HW, C;           // latents [B][C][HW] (NCHW, fp32), C = 4
+  const float* latents;   // x (ddpm) / x1 (flow)
+  const float* noise;     // noise (ddpm) / x0 (flow)
+  const float* sigma;     // ddpm: [B] sigma ; flow: [B] t
+  const float* tag_w;     // optional [B]
+  bf16* unet_in;          // [B*HW][8] (channels 4..7 zero)
+  const bf16* pred;       // [B*HW][8]
+  bf16* dpred;            // [B*HW][8]
+  float grad_scale;       // multiplies d(loss)/d(pred) (1/grad_accum, 1/world)
+  float* out;             // device: [0]=loss [1]=raw loss [2]=sum|pred| [3]=sum pred^2 [4]=sum|noise|
+                          //         [5]=sum x0^2 [6]=sum x1^2 [7]=gate
+};
+int launch_loss_prepare(const LossP& p, hipStream_t st);
+int launch_loss_fwd(const LossP& p, hipStream_t st);
+int launch_loss_bwd(const LossP& p, hipStream_t st);

@@ -1,0 +1,489 @@
+// GroupNorm(+SiLU) and LayerNorm, forward and backward, for token-major bf16 activations on gfx950.
+// HBM-bound kernels: 16-byte (8 x bf16) loads, every thread owns a fixed 8-channel vector so the
+// per-channel coefficients stay in registers; fp32 statistics with a per-group shift (first element
+// of the group) so E[(x-K)^2]-E[x-K]^2 does not cancel when |mean| >> std (sigma up to 2e4 inputs).
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm
+// ------------------------------------------------------------------------------------------------
+// launch geometry shared by the row-streaming kernels: blockDim = vpr * rpi threads
+struct GnGeom {
+  int vpr;   // 8-channel vectors per row = C/8
+  int rpi;   // rows per iteration in a block
+  int threads;
+  int chunks;  // grid.x : row chunks per sample
+  int rows_per_chunk;
+};
+static GnGeom gn_geom(int HW, int C) {
+  GnGeom g;
+  g.vpr = C / 8;
+  g.rpi = g.vpr >= 256 ? 1 : 256 / g.vpr;
+  g.threads = g.vpr * g.rpi;
+  int target_chunks = 2048;  // ~8 blocks per CU over the whole launch is plenty for an HBM stream
+  int rows = HW;
+  int chunks = rows / (g.rpi * 8);
+  if (chunks < 1) chunks = 1;
+  if (chunks > target_chunks) chunks = target_chunks;
+  g.chunks = chunks;
+  g.rows_per_chunk = (rows + chunks - 1) / chunks;
+  return g;
+}
+
+// partial sums of (x-K), (x-K)^2 per (b, group) -> ws[b][G][2] (atomic)
+__global__ void gn_stats_kernel(const bf16* __restrict__ x, float* __restrict__ ws, int HW, int C, int G,
+                                int vpr, int rpi, int rows_per_chunk) {
+  extern __shared__ float sred[];  // [G][2]
+  const int b = blockIdx.y;
+  const int vec = threadIdx.x % vpr, rsub = threadIdx.x / vpr;
+  const int cpg = C / G;
+  const bf16* xb = x + (long)b * HW * C;
+  for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) sred[i] = 0.f;
+  __syncthreads();
+  int gid[8];
+  float K[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    gid[e] = (vec * 8 + e) / cpg;
+    K[e] = (float)xb[gid[e] * cpg];
+  }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  const int r0 = blockIdx.x * rows_per_chunk;
+  const int r1 = min(HW, r0 + rows_per_chunk);
+  for (int r = r0 + rsub; r < r1; r += rpi) {
+    bf16x8 v = *(const bf16x8*)(xb + (long)r * C + vec * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float d = (float)v[e] - K[e];
+      s1[e] += d;
+      s2[e] += d * d;
+    }
+  }
+  // merge elements of the same group inside the vector before touching LDS
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (e + 1 < 8 && gid[e + 1] == gid[e]) {
+      s1[e + 1] += s1[e];
+      s2[e + 1] += s2[e];
+    } else {
+      atomicAdd(&sred[gid[e] * 2], s1[e]);
+      atomicAdd(&sred[gid[e] * 2 + 1], s2[e]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) atomicAdd(&ws[(long)b * G * 2 + i], sred[i]);
+}
+
+// stats[b][g] = (mean, rstd);  coef[b][c] = (a, s) with y = act(a*x + s)
+__global__ void gn_finalize_kernel(const bf16* __restrict__ x, const float* __restrict__ ws,
+                                   const bf16* __restrict__ gamma, const bf16* __restrict__ beta,
+                                   float* __restrict__ stats, float* __restrict__ coef, int HW, int C, int G,
+                                   float eps) {
+  const int b = blockIdx.x;
+  const int cpg = C / G;
+  const float n = (float)HW * (float)cpg;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    int g = c / cpg;
+    float K = (float)x[(long)b * HW * C + g * cpg];
+    float m1 = ws[((long)b * G + g) * 2] / n;
+    float m2 = ws[((long)b * G + g) * 2 + 1] / n;
+    float var = fmaxf(m2 - m1 * m1, 0.f);
+    float mean = K + m1;
+    float rstd = rsqrtf(var + eps);
+    if (c == g * cpg) {
+      stats[((long)b * G + g) * 2] = mean;
+      stats[((long)b * G + g) * 2 + 1] = rstd;
+    }
+    float a = rstd * (float)gamma[c];
+    coef[((long)b * C + c) * 2] = a;
+    coef[((long)b * C + c) * 2 + 1] = (float)beta[c] - mean * a;
+  }
+}
+
+template <bool SILU>
+__global__ void gn_apply_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, const float* __restrict__ coef,
+                                int HW, int C, int vpr, int rpi, int rows_per_chunk) {
+  const int b = blockIdx.y;
+  const int vec = threadIdx.x % vpr, rsub = threadIdx.x / vpr;
+  float a[8], s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    a[e] = coef[((long)b * C + vec * 8 + e) * 2];
+    s[e] = coef[((long)b * C + vec * 8 + e) * 2 + 1];
+  }
+  const bf16* xb = x + (long)b * HW * C;
+  bf16* yb = y + (long)b * HW * C;
+  const int r0 = blockIdx.x * rows_per_chunk;
+  const int r1 = min(HW, r0 + rows_per_chunk);
+  for (int r = r0 + rsub; r < r1; r += rpi) {
+    bf16x8 v = *(const bf16x8*)(xb + (long)r * C + vec * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float n = (float)v[e] * a[e] + s[e];
+      o[e] = (bf16)(SILU ? silu_f(n) : n);
+    }
+    *(bf16x8*)(yb + (long)r * C + vec * 8) = o;
+  }
+}
+
+int launch_groupnorm_fwd(const bf16* x, bf16* y, const bf16* gamma, const bf16* beta, float* stats, float* ws,
+                         int B, int HW, int C, int G, float eps, int silu, hipStream_t st) {
+  ARG_CHECK(C % 8 == 0 && C % G == 0 && G <= 64, "groupnorm: C=%d G=%d unsupported", C, G);
+  ARG_CHECK(C / 8 <= 512, "groupnorm: C=%d too wide", C);
+  GnGeom g = gn_geom(HW, C);
+  float* part = ws;                 // [B][G][2]
+  float* coef = ws + (long)B * G * 2;  // [B][C][2]
+  HIP_CHECK_RET(hipMemsetAsync(part, 0, sizeof(float) * B * G * 2, st));
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(g.chunks, B), dim3(g.threads), 2 * G * sizeof(float), st, x, part, HW, C,
+                     G, g.vpr, g.rpi, g.rows_per_chunk);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, x, part, gamma, beta, stats, coef, HW, C, G, eps);
+  if (silu)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(g.chunks, B), dim3(g.threads), 0, st, x, y, coef, HW, C, g.vpr,
+                       g.rpi, g.rows_per_chunk);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(g.chunks, B), dim3(g.threads), 0, st, x, y, coef, HW, C, g.vpr,
+                       g.rpi, g.rows_per_chunk);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+// backward pass 1: per (b,c)  A = sum dn, Bs = sum dn*xhat  -> ws[b][c][2] (atomic)
+template <bool SILU>
+__global__ void gn_bwd_reduce_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                     const bf16* __restrict__ gamma, const bf16* __restrict__ beta,
+                                     const float* __restrict__ stats, float* __restrict__ ws, int HW, int C, int G,
+                                     int vpr, int rpi, int rows_per_chunk) {
+  extern __shared__ float sred[];  // [C][2]
+  const int b = blockIdx.y;
+  const int vec = threadIdx.x % vpr, rsub = threadIdx.x / vpr;
+  const int cpg = C / G;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sred[i] = 0.f;
+  __syncthreads();
+  float mean[8], rstd[8], ga[8], be[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    int c = vec * 8 + e, g = c / cpg;
+    mean[e] = stats[((long)b * G + g) * 2];
+    rstd[e] = stats[((long)b * G + g) * 2 + 1];
+    ga[e] = (float)gamma[c];
+    be[e] = (float)beta[c];
+  }
+  float sa[8], sb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sa[e] = 0.f; sb[e] = 0.f; }
+  const bf16* xb = x + (long)b * HW * C;
+  const bf16* db = dy + (long)b * HW * C;
+  const int r0 = blockIdx.x * rows_per_chunk;
+  const int r1 = min(HW, r0 + rows_per_chunk);
+  for (int r = r0 + rsub; r < r1; r += rpi) {
+    bf16x8 v = *(const bf16x8*)(xb + (long)r * C + vec * 8);
+    bf16x8 d = *(const bf16x8*)(db + (long)r * C + vec * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float xh = ((float)v[e] - mean[e]) * rstd[e];
+      float dn = (float)d[e];
+      if (SILU) dn *= silu_grad_f(xh * ga[e] + be[e]);
+      sa[e] += dn;
+      sb[e] += dn * xh;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    atomicAdd(&sred[(vec * 8 + e) * 2], sa[e]);
+    atomicAdd(&sred[(vec * 8 + e) * 2 + 1], sb[e]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&ws[(long)b * C * 2 + i], sred[i]);
+}
+
+// per sample: dgamma/dbeta atomics, group sums, per-(b,c) coefficients c1,c2,c3 : dx = c1*dn + c3*x + c2
+__global__ void gn_bwd_finalize_kernel(const float* __restrict__ ws, const bf16* __restrict__ gamma,
+                                       const float* __restrict__ stats, float* __restrict__ coef,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int HW, int C, int G) {
+  __shared__ float gs[64 * 2];
+  const int b = blockIdx.x;
+  const int cpg = C / G;
+  const float n = (float)HW * (float)cpg;
+  for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) gs[i] = 0.f;
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float A = ws[((long)b * C + c) * 2], Bs = ws[((long)b * C + c) * 2 + 1];
+    atomicAdd(&dbeta[c], A);
+    atomicAdd(&dgamma[c], Bs);
+    float ga = (float)gamma[c];
+    atomicAdd(&gs[(c / cpg) * 2], ga * A);
+    atomicAdd(&gs[(c / cpg) * 2 + 1], ga * Bs);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    int g = c / cpg;
+    float mean = stats[((long)b * G + g) * 2], rstd = stats[((long)b * G + g) * 2 + 1];
+    float S1 = gs[g * 2] / n, S2 = gs[g * 2 + 1] / n;
+    float c1 = rstd * (float)gamma[c];
+    float c3 = -rstd * rstd * S2;
+    float c2 = -rstd * S1 - mean * c3;
+    coef[((long)b * C + c) * 3] = c1;
+    coef[((long)b * C + c) * 3 + 1] = c2;
+    coef[((long)b * C + c) * 3 + 2] = c3;
+  }
+}
+
+template <bool SILU, bool ACC>
+__global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                    const bf16* __restrict__ gamma, const bf16* __restrict__ beta,
+                                    const float* __restrict__ stats, const float* __restrict__ coef,
+                                    bf16* __restrict__ dx, int HW, int C, int G, int vpr, int rpi,
+                                    int rows_per_chunk) {
+  const int b = blockIdx.y;
+  const int vec = threadIdx.x % vpr, rsub = threadIdx.x / vpr;
+  const int cpg = C / G;
+  float a[8], s[8], c1[8], c2[8], c3[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    int c = vec * 8 + e, g = c / cpg;
+    float mean = stats[((long)b * G + g) * 2], rstd = stats[((long)b * G + g) * 2 + 1];
+    a[e] = rstd * (float)gamma[c];
+    s[e] = (float)beta[c] - mean * a[e];
+    c1[e] = coef[((long)b * C + c) * 3];
+    c2[e] = coef[((long)b * C + c) * 3 + 1];
+    c3[e] = coef[((long)b * C + c) * 3 + 2];
+  }
+  const bf16* xb = x + (long)b * HW * C;
+  const bf16* db = dy + (long)b * HW * C;
+  bf16* ob = dx + (long)b * HW * C;
+  const int r0 = blockIdx.x * rows_per_chunk;
+  const int r1 = min(HW, r0 + rows_per_chunk);
+  for (int r = r0 + rsub; r < r1; r += rpi) {
+    bf16x8 v = *(const bf16x8*)(xb + (long)r * C + vec * 8);
+    bf16x8 d = *(const bf16x8*)(db + (long)r * C + vec * 8);
+    bf16x8 o;
+    if (ACC) o = *(const bf16x8*)(ob + (long)r * C + vec * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float xv = (float)v[e];
+      float dn = (float)d[e];
+      if (SILU) dn *= silu_grad_f(xv * a[e] + s[e]);
+      float g = c1[e] * dn + c3[e] * xv + c2[e];
+      if (ACC) g += (float)o[e];
+      o[e] = (bf16)g;
+    }
+    *(bf16x8*)(ob + (long)r * C + vec * 8) = o;
+  }
+}
+
+int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const bf16* beta, const float* stats,
+                         bf16* dx, float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int G, int silu,
+                         int accumulate, hipStream_t st) {
+  ARG_CHECK(C % 8 == 0 && C % G == 0 && G <= 64, "groupnorm bwd: C=%d G=%d unsupported", C, G);
+  GnGeom g = gn_geom(HW, C);
+  float* part = ws;                    // [B][C][2]
+  float* coef = ws + (long)B * C * 2;  // [B][C][3]
+  HIP_CHECK_RET(hipMemsetAsync(part, 0, sizeof(float) * B * C * 2, st));
+  size_t sh = 2 * C * sizeof(float);
+  if (silu)
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<true>, dim3(g.chunks, B), dim3(g.threads), sh, st, x, dy, gamma, beta,
+                       stats, part, HW, C, G, g.vpr, g.rpi, g.rows_per_chunk);
+  else
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<false>, dim3(g.chunks, B), dim3(g.threads), sh, st, x, dy, gamma, beta,
+                       stats, part, HW, C, G, g.vpr, g.rpi, g.rows_per_chunk);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, st, part, gamma, stats, coef, dgamma, dbeta, HW, C,
+                     G);
+#define GN_BWD_APPLY(S, A)                                                                                          \
+  hipLaunchKernelGGL((gn_bwd_apply_kernel<S, A>), dim3(g.chunks, B), dim3(g.threads), 0, st, x, dy, gamma, beta, stats, \
+                     coef, dx, HW, C, G, g.vpr, g.rpi, g.rows_per_chunk)
+  if (silu) { if (accumulate) GN_BWD_APPLY(true, true); else GN_BWD_APPLY(true, false); }
+  else      { if (accumulate) GN_BWD_APPLY(false, true); else GN_BWD_APPLY(false, false); }
+#undef GN_BWD_APPLY
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: 16 lanes per row, NV 16-byte vectors per lane (C = 128*NV), whole row in registers,
+// exact two-pass mean/variance.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float group16_sum(float v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, const bf16* __restrict__ gamma,
+                              const bf16* __restrict__ beta, float* __restrict__ stats, int M, float eps) {
+  constexpr int C = NV * 128;
+  const int sub = threadIdx.x & 15;
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (row >= M) return;  // whole 16-lane group exits together
+  bf16x8 v[NV];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = *(const bf16x8*)(x + (long)row * C + (i * 16 + sub) * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += (float)v[i][e];
+  }
+  const float mean = group16_sum(sum) * (1.f / C);
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { float d = (float)v[i][e] - mean; sq += d * d; }
+  const float rstd = rsqrtf(group16_sum(sq) * (1.f / C) + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    bf16x8 gv = *(const bf16x8*)(gamma + (i * 16 + sub) * 8);
+    bf16x8 bv = *(const bf16x8*)(beta + (i * 16 + sub) * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16)(((float)v[i][e] - mean) * rstd * (float)gv[e] + (float)bv[e]);
+    *(bf16x8*)(y + (long)row * C + (i * 16 + sub) * 8) = o;
+  }
+  if (sub == 0) { stats[(long)row * 2] = mean; stats[(long)row * 2 + 1] = rstd; }
+}
+
+int launch_layernorm_fwd(const bf16* x, bf16* y, const bf16* gamma, const bf16* beta, float* stats, int M, int C,
+                         float eps, hipStream_t st) {
+  ARG_CHECK(C % 128 == 0, "layernorm: C=%d must be a multiple of 128", C);
+  dim3 grid(cdiv(M, 16)), blk(256);
+  switch (C / 128) {
+#define LN_CASE(NV) case NV: hipLaunchKernelGGL(ln_fwd_kernel<NV>, grid, blk, 0, st, x, y, gamma, beta, stats, M, eps); break;
+    LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(8) LN_CASE(10)
+#undef LN_CASE
+    default: ARG_CHECK(false, "layernorm: C=%d not instantiated", C);
+  }
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+// backward, dx: same geometry as forward (16 lanes per row), nothing carried between rows
+template <int NV, bool ACC>
+__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                 const bf16* __restrict__ gamma, const float* __restrict__ stats,
+                                 bf16* __restrict__ dx, int M) {
+  constexpr int C = NV * 128;
+  const int sub = threadIdx.x & 15;
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (row >= M) return;
+  const float mean = stats[(long)row * 2], rstd = stats[(long)row * 2 + 1];
+  bf16x8 v[NV], d[NV];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = *(const bf16x8*)(x + (long)row * C + (i * 16 + sub) * 8);
+    d[i] = *(const bf16x8*)(dy + (long)row * C + (i * 16 + sub) * 8);
+    bf16x8 gv = *(const bf16x8*)(gamma + (i * 16 + sub) * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float h = ((float)v[i][e] - mean) * rstd;
+      float t = (float)d[i][e] * (float)gv[e];
+      s1 += t;
+      s2 += t * h;
+    }
+  }
+  s1 = group16_sum(s1) * (1.f / C);
+  s2 = group16_sum(s2) * (1.f / C);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    bf16x8 gv = *(const bf16x8*)(gamma + (i * 16 + sub) * 8);
+    bf16x8 o;
+    if (ACC) o = *(const bf16x8*)(dx + (long)row * C + (i * 16 + sub) * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float h = ((float)v[i][e] - mean) * rstd;
+      float t = (float)d[i][e] * (float)gv[e];
+      float g = rstd * (t - s1 - h * s2);
+      if (ACC) g += (float)o[e];
+      o[e] = (bf16)g;
+    }
+    *(bf16x8*)(dx + (long)row * C + (i * 16 + sub) * 8) = o;
+  }
+}
+
+// backward, dgamma/dbeta: column-oriented (thread = fixed 8-column vector, 8 row lanes per block,
+// 256 columns per block); the re-read of x/dy right after the dx kernel is served by L2/MALL.
+// With x == nullptr this is a plain column sum (bias gradients): out_b[n] += sum_m dy[m][n].
+__global__ __launch_bounds__(256) void col_reduce_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, long ld,
+                                  const float* __restrict__ stats, float* __restrict__ out_g,
+                                  float* __restrict__ out_b, int M, int C, int rows_per_chunk) {
+  __shared__ float sred[2][8][256 + 8];
+  const int cv = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 256 + cv * 8;
+  const bool cok = c0 < C;
+  float sg[8], sb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sg[e] = 0.f; sb[e] = 0.f; }
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+  if (cok) {
+    for (int r = r0 + rl; r < r1; r += 8) {
+      bf16x8 d = *(const bf16x8*)(dy + (long)r * ld + c0);
+      if (x) {
+        bf16x8 v = *(const bf16x8*)(x + (long)r * ld + c0);
+        const float mean = stats[(long)r * 2], rstd = stats[(long)r * 2 + 1];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float dv = (float)d[e];
+          sg[e] += dv * ((float)v[e] - mean) * rstd;
+          sb[e] += dv;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sb[e] += (float)d[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sred[0][rl][cv * 8 + e] = sg[e]; sred[1][rl][cv * 8 + e] = sb[e]; }
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) {
+    float g = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { g += sred[0][k][threadIdx.x]; b += sred[1][k][threadIdx.x]; }
+    if (x) atomicAdd(&out_g[c], g);
+    atomicAdd(&out_b[c], b);
+  }
+}
+
+static void col_reduce_geom(int M, int C, dim3* grid, int* rows_per_chunk) {
+  int colblocks = cdiv(C, 256);
+  int chunks = 1024 / colblocks;
+  if (chunks < 1) chunks = 1;
+  int maxchunks = cdiv(M, 32);
+  if (chunks > maxchunks) chunks = maxchunks;
+  *rows_per_chunk = cdiv(M, chunks);
+  *grid = dim3(colblocks, cdiv(M, *rows_per_chunk));
+}
+
+int launch_layernorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const float* stats, bf16* dx,
+                         float* dgamma, float* dbeta, int M, int C, int accumulate, hipStream_t st) {
+  ARG_CHECK(C % 128 == 0, "layernorm bwd: C=%d must be a multiple of 128", C);
+  dim3 grid(cdiv(M, 16)), blk(256);
+  switch (C / 128) {
+#define LN_CASE(NV)                                                                                            \
+  case NV:                                                                                                     \
+    if (accumulate) hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, true>), grid, blk, 0, st, x, dy, gamma, stats, dx, M); \
+    else hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, false>), grid, blk, 0, st, x, dy, gamma, stats, dx, M);         \
+    break;
+    LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(8) LN_CASE(10)
+#undef LN_CASE
+    default: ARG_CHECK(false, "layernorm bwd: C=%d not instantiated", C);
+  }
+  dim3 g2; int rpc;
+  col_reduce_geom(M, C, &g2, &rpc);
+  hipLaunchKernelGGL(col_reduce_kernel, g2, dim3(256), 0, st, x, dy, (long)C, stats, dgamma, dbeta, M, C, rpc);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_colsum_f32(const bf16* x, float* out, int M, int N, long ldx, hipStream_t st) {
+  ARG_CHECK(N % 8 == 0 && ldx % 8 == 0, "colsum: N=%d ld=%ld must be multiples of 8", N, ldx);
+  dim3 g2; int rpc;
+  col_reduce_geom(M, N, &g2, &rpc);
+  hipLaunchKernelGGL(col_reduce_kernel, g2, dim3(256), 0, st, (const bf16*)nullptr, x, ldx, (const float*)nullptr,
+                     (float*)nullptr, out, M, N, rpc);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
