@@ -4,5 +4,6 @@ The directory name is not a valid Python identifier; import it with
     importlib.import_module("sdxl-training-improvements_amd")      or      import sdxl_amd   (alias at repo root)
 """
 from . import lib  # noqa: F401
+from . import unet  # noqa: F401
 
-__all__ = ["lib"]
+__all__ = ["lib", "unet"]

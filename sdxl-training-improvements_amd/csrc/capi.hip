@@ -456,4 +456,35 @@ int sdxl_op_loss(const sdxl_loss_config* lc, const sdxl_batch* b, void* unet_in,
 
 int sdxl_probe_layout(void* out, void* st) { return probe_layout(out, (hipStream_t)st); }
 
+// debug: order-independent checksum (sum of raw 16-bit patterns) of every activation of the current plan, in
+// creation order.  Synchronises.  Used to localise run-to-run differences.
+__global__ void checksum_kernel(const unsigned short* __restrict__ x, long n, unsigned long long* out) {
+  unsigned long long s = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    s += (unsigned long long)x[i] * (unsigned long long)((i % 251) + 1);
+  atomicAdd(out, s);
+}
+int sdxl_debug_act_checksums(sdxl_handle* h, unsigned long long* out_host, int cap, int* n_out, int grads) {
+  H_CHECK(h);
+  CHK(ready(h->e));
+  Plan& p = *h->e.cur;
+  int n = (int)p.acts.size();
+  if (n_out) *n_out = n;
+  if (n > cap) n = cap;
+  unsigned long long* d = nullptr;
+  HIP_CHECK_RET(hipMalloc((void**)&d, sizeof(unsigned long long) * (n > 0 ? n : 1)));
+  HIP_CHECK_RET(hipMemset(d, 0, sizeof(unsigned long long) * (n > 0 ? n : 1)));
+  for (int i = 0; i < n; ++i) {
+    Act* a = p.acts[i].get();
+    const bf16* src = grads ? p.G(a) : p.P(a);
+    if (!src) continue;
+    long cnt = a->rows * a->cols;
+    hipLaunchKernelGGL(checksum_kernel, dim3(64), dim3(256), 0, 0, (const unsigned short*)src, cnt, d + i);
+  }
+  HIP_CHECK_RET(hipDeviceSynchronize());
+  HIP_CHECK_RET(hipMemcpy(out_host, d, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  return 0;
+}
+
 }  // extern "C"

@@ -207,21 +207,22 @@ struct GroupNormOp : Op {
   PRef gm, bt;
   int Bn, HW, C, G, silu;
   float eps;
-  size_t stats_off, ws_off;
+  size_t stats_off;
   int acc_x = 0;
   GroupNormOp(Plan& p, Act* x_, Act* y_, PRef g_, PRef b_, int B_, int HW_, int C_, int G_, float eps_, int silu_)
       : x(x_), y(y_), gm(g_), bt(b_), Bn(B_), HW(HW_), C(C_), G(G_), silu(silu_), eps(eps_) {
     stats_off = p.alloc(sizeof(float) * Bn * G * 2);
-    ws_off = p.alloc(sizeof(float) * ((size_t)Bn * G * 2 + (size_t)Bn * C * 6));
+    size_t need = groupnorm_ws_floats(Bn, C, G);
+    if (need > p.gn_ws_floats) p.gn_ws_floats = need;  // one scratch, sized for the widest norm, allocated in build()
   }
   int fwd(Plan& p, hipStream_t st) override {
-    return launch_groupnorm_fwd(p.P(x), p.P(y), p.eng->Wp(gm), p.eng->Wp(bt), p.F(stats_off), p.F(ws_off), Bn, HW, C, G,
+    return launch_groupnorm_fwd(p.P(x), p.P(y), p.eng->Wp(gm), p.eng->Wp(bt), p.F(stats_off), p.F(p.gn_ws_off), Bn, HW, C, G,
                                 eps, silu, st);
   }
   void plan_bwd(Plan& p) override { acc_x = p.grad_write(x); }
   int bwd(Plan& p, hipStream_t st, bool) override {
     return launch_groupnorm_bwd(p.P(x), p.G(y), p.eng->Wp(gm), p.eng->Wp(bt), p.F(stats_off), p.G(x), p.eng->Gp(gm),
-                                p.eng->Gp(bt), p.F(ws_off), Bn, HW, C, G, silu, acc_x, st);
+                                p.eng->Gp(bt), p.F(p.gn_ws_off), Bn, HW, C, G, silu, acc_x, st);
   }
 };
 
@@ -417,9 +418,10 @@ struct Builder {
     return op;
   }
   // ---- layers ----
-  Act* linear(const std::string& name, Act* x, int K, int N, bool bias, Act* resid) {
+  Act* linear(const std::string& name, Act* x, int K, int N, bool bias, Act* resid, bool conv1x1 = false) {
     PRef w = e.param((size_t)N * K);
-    e.map_src(name + ".weight", {N, K}, w, 0, 0, 0);
+    if (conv1x1) e.map_src(name + ".weight", {N, K, 1, 1}, w, 0, 0, 0);
+    else e.map_src(name + ".weight", {N, K}, w, 0, 0, 0);
     PRef b;
     if (bias) { b = e.param(N); e.map_src(name + ".bias", {N}, b, 0, 0, 0); }
     if (!pl) return nullptr;
@@ -485,7 +487,7 @@ struct Builder {
     Act* c1 = conv(p + ".conv1", n1, h, w_, cin, cout, 1, nullptr, tp);
     Act* n2 = groupnorm(p + ".norm2", c1, h * w_, cout, e.cfg.resnet_eps, 1);
     Act* sc = x;
-    if (cin != cout) sc = linear(p + ".conv_shortcut", x, cin, cout, true, nullptr);
+    if (cin != cout) sc = linear(p + ".conv_shortcut", x, cin, cout, true, nullptr, true);
     return conv(p + ".conv2", n2, h, w_, cout, cout, 1, sc, nullptr);
   }
   Act* tf_block(const std::string& b, Act* x, Act* ehs, int C, int N) {
@@ -627,6 +629,7 @@ void Engine::build(Plan* plan) {
     nseg = (int)seg_begin.size();
     registering = false;
   } else {
+    plan->gn_ws_off = plan->alloc(sizeof(float) * plan->gn_ws_floats);
     // reverse planning: the loss writes d(pred)
     plan->grad_write(plan->pred);
     for (int i = (int)plan->ops.size() - 1; i >= 0; --i) plan->ops[i]->plan_bwd(*plan);

@@ -68,10 +68,12 @@ int launch_attn_bwd(const AttnP& p, hipStream_t st);
 // normalisation (norm.hip)
 // ------------------------------------------------------------------------------------------------
 // GroupNorm over [B][HW][C] with G groups (+ optional SiLU).  stats: [B][G][2] = mean, rstd.
+// ws: groupnorm_ws_floats(B, C, G) floats of scratch (may be shared by stream-ordered calls)
+size_t groupnorm_ws_floats(int B, int C, int G);
 int launch_groupnorm_fwd(const bf16* x, bf16* y, const bf16* gamma, const bf16* beta, float* stats,
-                         float* ws /* B*C*2 floats */, int B, int HW, int C, int G, float eps, int silu,
+                         float* ws, int B, int HW, int C, int G, float eps, int silu,
                          hipStream_t st);
-// dx (+)= ; dgamma/dbeta fp32 += .  ws: B*C*2 floats
+// dx (+)= ; dgamma/dbeta fp32 += .  ws: same scratch
 int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const bf16* beta,
                          const float* stats, bf16* dx, float* dgamma, float* dbeta, float* ws, int B, int HW,
                          int C, int G, int silu, int accumulate, hipStream_t st);

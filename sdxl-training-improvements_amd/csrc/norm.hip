@@ -15,38 +15,40 @@ struct GnGeom {
   int chunks;  // grid.x : row chunks per sample
   int rows_per_chunk;
 };
+#define GN_MAX_CHUNKS 256
 static GnGeom gn_geom(int HW, int C) {
   GnGeom g;
   g.vpr = C / 8;
   g.rpi = g.vpr >= 256 ? 1 : 256 / g.vpr;
   g.threads = g.vpr * g.rpi;
-  int target_chunks = 2048;  // ~8 blocks per CU over the whole launch is plenty for an HBM stream
-  int rows = HW;
-  int chunks = rows / (g.rpi * 8);
+  int chunks = HW / (g.rpi * 8);
   if (chunks < 1) chunks = 1;
-  if (chunks > target_chunks) chunks = target_chunks;
-  g.chunks = chunks;
-  g.rows_per_chunk = (rows + chunks - 1) / chunks;
+  if (chunks > GN_MAX_CHUNKS) chunks = GN_MAX_CHUNKS;
+  g.rows_per_chunk = (HW + chunks - 1) / chunks;
+  g.chunks = (HW + g.rows_per_chunk - 1) / g.rows_per_chunk;
   return g;
 }
+size_t groupnorm_ws_floats(int B, int C, int G) {
+  size_t fwd = (size_t)GN_MAX_CHUNKS * B * G * 2 + (size_t)B * C * 2;
+  size_t bwd = (size_t)GN_MAX_CHUNKS * B * C * 2 + (size_t)B * C * 3;
+  return fwd > bwd ? fwd : bwd;
+}
 
-// partial sums of (x-K), (x-K)^2 per (b, group) -> ws[b][G][2] (atomic)
-__global__ void gn_stats_kernel(const bf16* __restrict__ x, float* __restrict__ ws, int HW, int C, int G,
+// All reductions below are order-deterministic (no atomics on the activation path): a block reduces its rows
+// through LDS in a fixed order and writes one partial per chunk; the finalize kernel sums chunks in order.
+// Bitwise-reproducible statistics keep the bf16 activations (and so the loss) reproducible run to run.
+
+// partial sums of (x-K), (x-K)^2 per (chunk, b, group) -> part[chunk][b][G][2]
+__global__ void gn_stats_kernel(const bf16* __restrict__ x, float* __restrict__ part, int HW, int C, int G,
                                 int vpr, int rpi, int rows_per_chunk) {
-  extern __shared__ float sred[];  // [G][2]
-  const int b = blockIdx.y;
+  extern __shared__ float sred[];  // [2][rpi][C]
+  const int b = blockIdx.y, B = gridDim.y;
   const int vec = threadIdx.x % vpr, rsub = threadIdx.x / vpr;
   const int cpg = C / G;
   const bf16* xb = x + (long)b * HW * C;
-  for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) sred[i] = 0.f;
-  __syncthreads();
-  int gid[8];
   float K[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    gid[e] = (vec * 8 + e) / cpg;
-    K[e] = (float)xb[gid[e] * cpg];
-  }
+  for (int e = 0; e < 8; ++e) K[e] = (float)xb[((vec * 8 + e) / cpg) * cpg];
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
@@ -61,44 +63,53 @@ __global__ void gn_stats_kernel(const bf16* __restrict__ x, float* __restrict__ 
       s2[e] += d * d;
     }
   }
-  // merge elements of the same group inside the vector before touching LDS
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    if (e + 1 < 8 && gid[e + 1] == gid[e]) {
-      s1[e + 1] += s1[e];
-      s2[e + 1] += s2[e];
-    } else {
-      atomicAdd(&sred[gid[e] * 2], s1[e]);
-      atomicAdd(&sred[gid[e] * 2 + 1], s2[e]);
-    }
+    sred[(long)rsub * C + vec * 8 + e] = s1[e];
+    sred[(long)(rpi + rsub) * C + vec * 8 + e] = s2[e];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) atomicAdd(&ws[(long)b * G * 2 + i], sred[i]);
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float a = 0.f, q = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c)
+      for (int r = 0; r < rpi; ++r) { a += sred[(long)r * C + c]; q += sred[(long)(rpi + r) * C + c]; }
+    float* o = part + (((long)blockIdx.x * B + b) * G + g) * 2;
+    o[0] = a;
+    o[1] = q;
+  }
 }
 
 // stats[b][g] = (mean, rstd);  coef[b][c] = (a, s) with y = act(a*x + s)
-__global__ void gn_finalize_kernel(const bf16* __restrict__ x, const float* __restrict__ ws,
+__global__ void gn_finalize_kernel(const bf16* __restrict__ x, const float* __restrict__ part, int chunks,
                                    const bf16* __restrict__ gamma, const bf16* __restrict__ beta,
                                    float* __restrict__ stats, float* __restrict__ coef, int HW, int C, int G,
                                    float eps) {
-  const int b = blockIdx.x;
+  __shared__ float gm[64], gr[64];
+  const int b = blockIdx.x, B = gridDim.x;
   const int cpg = C / G;
   const float n = (float)HW * (float)cpg;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float a = 0.f, q = 0.f;
+    for (int k = 0; k < chunks; ++k) {
+      const float* pp = part + (((long)k * B + b) * G + g) * 2;
+      a += pp[0];
+      q += pp[1];
+    }
+    float K = (float)x[(long)b * HW * C + g * cpg];
+    float m1 = a / n, m2 = q / n;
+    float var = fmaxf(m2 - m1 * m1, 0.f);
+    float mean = K + m1, rstd = rsqrtf(var + eps);
+    gm[g] = mean;
+    gr[g] = rstd;
+    stats[((long)b * G + g) * 2] = mean;
+    stats[((long)b * G + g) * 2 + 1] = rstd;
+  }
+  __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     int g = c / cpg;
-    float K = (float)x[(long)b * HW * C + g * cpg];
-    float m1 = ws[((long)b * G + g) * 2] / n;
-    float m2 = ws[((long)b * G + g) * 2 + 1] / n;
-    float var = fmaxf(m2 - m1 * m1, 0.f);
-    float mean = K + m1;
-    float rstd = rsqrtf(var + eps);
-    if (c == g * cpg) {
-      stats[((long)b * G + g) * 2] = mean;
-      stats[((long)b * G + g) * 2 + 1] = rstd;
-    }
-    float a = rstd * (float)gamma[c];
+    float a = gr[g] * (float)gamma[c];
     coef[((long)b * C + c) * 2] = a;
-    coef[((long)b * C + c) * 2 + 1] = (float)beta[c] - mean * a;
+    coef[((long)b * C + c) * 2 + 1] = (float)beta[c] - gm[g] * a;
   }
 }
 
@@ -134,12 +145,13 @@ int launch_groupnorm_fwd(const bf16* x, bf16* y, const bf16* gamma, const bf16* 
   ARG_CHECK(C % 8 == 0 && C % G == 0 && G <= 64, "groupnorm: C=%d G=%d unsupported", C, G);
   ARG_CHECK(C / 8 <= 512, "groupnorm: C=%d too wide", C);
   GnGeom g = gn_geom(HW, C);
-  float* part = ws;                 // [B][G][2]
-  float* coef = ws + (long)B * G * 2;  // [B][C][2]
-  HIP_CHECK_RET(hipMemsetAsync(part, 0, sizeof(float) * B * G * 2, st));
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(g.chunks, B), dim3(g.threads), 2 * G * sizeof(float), st, x, part, HW, C,
-                     G, g.vpr, g.rpi, g.rows_per_chunk);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, x, part, gamma, beta, stats, coef, HW, C, G, eps);
+  float* part = ws;                                      // [chunks][B][G][2]
+  float* coef = ws + (size_t)GN_MAX_CHUNKS * B * G * 2;  // [B][C][2]
+  size_t sh = sizeof(float) * 2 * g.rpi * C;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(g.chunks, B), dim3(g.threads), sh, st, x, part, HW, C, G, g.vpr, g.rpi,
+                     g.rows_per_chunk);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, x, part, g.chunks, gamma, beta, stats, coef, HW, C,
+                     G, eps);
   if (silu)
     hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(g.chunks, B), dim3(g.threads), 0, st, x, y, coef, HW, C, g.vpr,
                        g.rpi, g.rows_per_chunk);
@@ -150,18 +162,16 @@ int launch_groupnorm_fwd(const bf16* x, bf16* y, const bf16* gamma, const bf16* 
   return 0;
 }
 
-// backward pass 1: per (b,c)  A = sum dn, Bs = sum dn*xhat  -> ws[b][c][2] (atomic)
+// backward pass 1: per (chunk,b,c)  A = sum dn, Bs = sum dn*xhat  -> part[chunk][b][C][2]
 template <bool SILU>
 __global__ void gn_bwd_reduce_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                      const bf16* __restrict__ gamma, const bf16* __restrict__ beta,
-                                     const float* __restrict__ stats, float* __restrict__ ws, int HW, int C, int G,
+                                     const float* __restrict__ stats, float* __restrict__ part, int HW, int C, int G,
                                      int vpr, int rpi, int rows_per_chunk) {
-  extern __shared__ float sred[];  // [C][2]
-  const int b = blockIdx.y;
+  extern __shared__ float sred[];  // [2][rpi][C]
+  const int b = blockIdx.y, B = gridDim.y;
   const int vec = threadIdx.x % vpr, rsub = threadIdx.x / vpr;
   const int cpg = C / G;
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sred[i] = 0.f;
-  __syncthreads();
   float mean[8], rstd[8], ga[8], be[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -192,36 +202,55 @@ __global__ void gn_bwd_reduce_kernel(const bf16* __restrict__ x, const bf16* __r
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    atomicAdd(&sred[(vec * 8 + e) * 2], sa[e]);
-    atomicAdd(&sred[(vec * 8 + e) * 2 + 1], sb[e]);
+    sred[(long)rsub * C + vec * 8 + e] = sa[e];
+    sred[(long)(rpi + rsub) * C + vec * 8 + e] = sb[e];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&ws[(long)b * C * 2 + i], sred[i]);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a = 0.f, q = 0.f;
+    for (int r = 0; r < rpi; ++r) { a += sred[(long)r * C + c]; q += sred[(long)(rpi + r) * C + c]; }
+    float* o = part + (((long)blockIdx.x * B + b) * C + c) * 2;
+    o[0] = a;
+    o[1] = q;
+  }
 }
 
-// per sample: dgamma/dbeta atomics, group sums, per-(b,c) coefficients c1,c2,c3 : dx = c1*dn + c3*x + c2
-__global__ void gn_bwd_finalize_kernel(const float* __restrict__ ws, const bf16* __restrict__ gamma,
+// per sample: chunk sums (fixed order), dgamma/dbeta, group sums, per-(b,c) coefficients: dx = c1*dn + c3*x + c2
+__global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, const bf16* __restrict__ gamma,
                                        const float* __restrict__ stats, float* __restrict__ coef,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int HW, int C, int G) {
-  __shared__ float gs[64 * 2];
-  const int b = blockIdx.x;
+  extern __shared__ float sh[];  // [2][C] gamma-weighted sums, then [2][G] group sums
+  float* wa = sh;
+  float* wb = sh + C;
+  float* gs = sh + 2 * C;
+  const int b = blockIdx.x, B = gridDim.x;
   const int cpg = C / G;
   const float n = (float)HW * (float)cpg;
-  for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) gs[i] = 0.f;
-  __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float A = ws[((long)b * C + c) * 2], Bs = ws[((long)b * C + c) * 2 + 1];
-    atomicAdd(&dbeta[c], A);
+    float A = 0.f, Bs = 0.f;
+    for (int k = 0; k < chunks; ++k) {
+      const float* pp = part + (((long)k * B + b) * C + c) * 2;
+      A += pp[0];
+      Bs += pp[1];
+    }
+    atomicAdd(&dbeta[c], A);     // parameter gradients: fp32 sum over the batch (order-insensitive to ~1e-7)
     atomicAdd(&dgamma[c], Bs);
     float ga = (float)gamma[c];
-    atomicAdd(&gs[(c / cpg) * 2], ga * A);
-    atomicAdd(&gs[(c / cpg) * 2 + 1], ga * Bs);
+    wa[c] = ga * A;
+    wb[c] = ga * Bs;
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float a = 0.f, q = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += wa[c]; q += wb[c]; }
+    gs[g * 2] = a / n;
+    gs[g * 2 + 1] = q / n;
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     int g = c / cpg;
     float mean = stats[((long)b * G + g) * 2], rstd = stats[((long)b * G + g) * 2 + 1];
-    float S1 = gs[g * 2] / n, S2 = gs[g * 2 + 1] / n;
+    float S1 = gs[g * 2], S2 = gs[g * 2 + 1];
     float c1 = rstd * (float)gamma[c];
     float c3 = -rstd * rstd * S2;
     float c2 = -rstd * S1 - mean * c3;
@@ -279,18 +308,17 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const
                          int accumulate, hipStream_t st) {
   ARG_CHECK(C % 8 == 0 && C % G == 0 && G <= 64, "groupnorm bwd: C=%d G=%d unsupported", C, G);
   GnGeom g = gn_geom(HW, C);
-  float* part = ws;                    // [B][C][2]
-  float* coef = ws + (long)B * C * 2;  // [B][C][3]
-  HIP_CHECK_RET(hipMemsetAsync(part, 0, sizeof(float) * B * C * 2, st));
-  size_t sh = 2 * C * sizeof(float);
+  float* part = ws;                                      // [chunks][B][C][2]
+  float* coef = ws + (size_t)GN_MAX_CHUNKS * B * C * 2;  // [B][C][3]
+  size_t sh = sizeof(float) * 2 * g.rpi * C;
   if (silu)
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<true>, dim3(g.chunks, B), dim3(g.threads), sh, st, x, dy, gamma, beta,
                        stats, part, HW, C, G, g.vpr, g.rpi, g.rows_per_chunk);
   else
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<false>, dim3(g.chunks, B), dim3(g.threads), sh, st, x, dy, gamma, beta,
                        stats, part, HW, C, G, g.vpr, g.rpi, g.rows_per_chunk);
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, st, part, gamma, stats, coef, dgamma, dbeta, HW, C,
-                     G);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), sizeof(float) * (2 * C + 2 * G), st, part, g.chunks,
+                     gamma, stats, coef, dgamma, dbeta, HW, C, G);
 #define GN_BWD_APPLY(S, A)                                                                                          \
   hipLaunchKernelGGL((gn_bwd_apply_kernel<S, A>), dim3(g.chunks, B), dim3(g.threads), 0, st, x, dy, gamma, beta, stats, \
                      coef, dx, HW, C, G, g.vpr, g.rpi, g.rows_per_chunk)

@@ -76,6 +76,7 @@ SIGNATURES = {
     "sdxl_op_geglu_bwd": [_vp, _vp, _vp, _i, _i, _vp],
     "sdxl_op_loss": [_P(LossConfig), _P(Batch), _vp, _vp, _vp, _f, _vp, _i, _vp],
     "sdxl_probe_layout": [_vp, _vp],
+    "sdxl_debug_act_checksums": [_vp, _P(C.c_ulonglong), _i, _P(_i), _i],
 }
 
 _lib = None
