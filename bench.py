@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of one SDXL-base training step (loss prep + UNet forward + loss + UNet backward,
+gradients zeroed each step; optimizer excluded) on synthetic data, batch 4 per GPU at 1024^2 (latent 128x128), bf16.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU; data parallel = each rank runs the same step on its own batch and the UNet gradients are
+all-reduced (bf16, pre-scaled by 1/N) over RCCL/xGMI in ~190 MB buckets overlapped with the rest of backward.
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel family (the bf16 MFMA GEMM behind every Linear and
+3x3 conv: forward, dgrad, wgrad), measured with HIP events around each of its launches in a separate profiled step;
+`cpu_baseline` is the fp32 CPU oracle (the restatement of the reference's arithmetic) timed on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+FLOP_PER_IMAGE_1024 = 20.28e12      # fwd+bwd, BASELINE.md section 2 (2*M*N*K of every matmul, bwd = 2x fwd)
+FLOP_PER_IMAGE_512 = 4.77e12
+PEAK_BF16_TFLOPS = 2516.6           # 256 CU x 2.4 GHz x 4096 FLOP/clk/CU (MI355X dense bf16 MFMA)
+
+WORKLOADS = {
+    "ddpm_b4_1024": dict(method="ddpm", B=4, H=128, W=128, flop_per_image=FLOP_PER_IMAGE_1024,
+                         desc="method=ddpm v_prediction + zero_terminal_snr + MinSNR(5), SDXL-base UNet fwd+bwd, "
+                              "batch 4/GPU, 1024^2 (latent 128x128)"),
+    "flow_b4_1024": dict(method="flow_matching", B=4, H=128, W=128, flop_per_image=FLOP_PER_IMAGE_1024,
+                         desc="method=flow_matching (logit-normal t), SDXL-base UNet fwd+bwd, batch 4/GPU, 1024^2"),
+    "ddpm_b1_512": dict(method="ddpm", B=1, H=64, W=64, flop_per_image=FLOP_PER_IMAGE_512,
+                        desc="method=ddpm, SDXL-base UNet fwd+bwd, batch 1, 512^2 (latent 64x64)"),
+}
+
+
+def karras_table(n=1000, smin=0.002, smax=20000.0, rho=7.0):
+    ramp = torch.linspace(0, 1, n)
+    return (smax ** (1 / rho) + ramp * (smin ** (1 / rho) - smax ** (1 / rho))) ** rho
+
+
+def make_batch(wl, rank, device, cross=2048, pooled=1280):
+    g = torch.Generator().manual_seed(1234 + rank)
+    B, H, W = wl["B"], wl["H"], wl["W"]
+    r = lambda *s: torch.randn(*s, generator=g)
+    b = dict(lat=r(B, 4, H, W), noise=r(B, 4, H, W), ehs=r(B, 77, cross), pooled=r(B, pooled),
+             tid=torch.tensor([[8.0 * W, 8.0 * H, 0, 0, 8.0 * W, 8.0 * H]] * B))
+    u = torch.rand(B, generator=g)
+    if wl["method"] == "ddpm":
+        ts = (u * 1000).long()
+        b["timestep"] = ts.float()
+        b["sigma_or_t"] = karras_table()[ts]
+    else:
+        t = torch.sigmoid(r(B))
+        b["timestep"] = t
+        b["sigma_or_t"] = t
+    return {k: v.to(device) for k, v in b.items()}
+
+
+def cpu_baseline(threads: int | None = None):
+    """fp32 CPU oracle, cfg 1 (B=1, 512^2, single process): one forward+backward of the SDXL-base UNet + DDPM loss."""
+    from oracle import loss_ref as R
+    from oracle import unet_ref as U
+    if threads:
+        torch.set_num_threads(threads)
+    cores = torch.get_num_threads()
+    cfg = U.SDXL_BASE
+    t0 = time.time()
+    w = {}
+    g = torch.Generator().manual_seed(0)
+    pool = torch.rand(1 << 22, generator=g) - 0.5        # cheap init (tiled random pool): timing is value-independent
+    for name, shape in U.param_shapes(cfg).items():
+        std, mean = U.synth_std(name, shape)
+        n = math.prod(shape)
+        t = pool.repeat((n + pool.numel() - 1) // pool.numel())[:n].reshape(shape) * (3.4641 * std) + mean
+        w[name] = t.requires_grad_(True)
+    t_init = time.time() - t0
+    B, H, W = 1, 64, 64
+    lat, noise = torch.randn(B, 4, H, W, generator=g), torch.randn(B, 4, H, W, generator=g)
+    batch = {"vae_latents": lat, "prompt_embeds": torch.randn(B, 77, 2048, generator=g),
+             "pooled_prompt_embeds": torch.randn(B, 1280, generator=g),
+             "time_ids": torch.tensor([[512.0, 512, 0, 0, 512, 512]])}
+    ts = torch.tensor([500])
+    unet_fn = lambda s, t, e, p, ti: U.unet_forward(w, s, t, e, p, ti, cfg)
+    t0 = time.time()
+    out = R.compute_loss_ddpm(unet_fn, batch, noise, ts)
+    out["loss"].backward()
+    dt = time.time() - t0
+    img_s_512 = B / dt
+    return {"value": img_s_512 * FLOP_PER_IMAGE_512 / FLOP_PER_IMAGE_1024, "unit": "images/sec", "cores": cores,
+            "kind": "port",
+            "sample": f"oracle (fp32 torch CPU restatement), cfg1: ddpm B=1 512^2, 1 fwd+bwd step = {dt:.2f} s "
+                      f"({img_s_512:.4f} img/s at 512^2, {FLOP_PER_IMAGE_512 / dt / 1e12:.3f} TFLOP/s); value is scaled "
+                      f"to 1024^2-equivalent images by the FLOP ratio 4.77/20.28; weight init {t_init:.1f} s untimed"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="ddpm_b4_1024", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--profile-steps", type=int, default=1, help="extra steps with per-launch GEMM event timing")
+    args = ap.parse_args()
+
+    import sdxl_amd  # noqa: F401
+    from sdxl_amd import distributed as D
+    from sdxl_amd import lib, synth
+    from sdxl_amd import unet as NU
+
+    rank, local_rank, world = D.env_rank_world()
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
+    D.init_process_group("nccl" if world > 1 else None)
+    wl = WORKLOADS[args.workload]
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    net = NU.NativeUNet(NU.make_config(), device=local_rank)
+    synth.load_synthetic(net, seed=0)                      # same weights on every rank
+    net.plan(wl["B"], wl["H"], wl["W"], 77)
+    b = make_batch(wl, rank, dev)
+    L = net.L
+
+    def cast(off, n, dst):
+        lib.check(L.sdxl_grads_to_bf16(net.h, off, n, C.c_void_p(dst.data_ptr()), 1.0,
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    sync = D.GradSync(net.param_elems, cast, torch.bfloat16, dev)
+    scale = 1.0 / world
+
+    def step():
+        net.zero_grads()
+        net.forward_loss(wl["method"], b["lat"], b["noise"], b["sigma_or_t"], b["timestep"], b["ehs"], b["pooled"], b["tid"])
+        net.backward(scale, True, on_segment=sync.on_segment if world > 1 else None)
+        sync.finish()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    loss = net.read_loss()[0]
+    images = world * wl["B"] * args.steps
+    value = images / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    # dominant-kernel roofline: per-launch HIP events around every GEMM-family launch (same stream), profiled steps
+    roof = None
+    if args.profile_steps > 0:
+        lib.check(L.sdxl_profile_gemm_begin())
+        for _ in range(args.profile_steps):
+            step()
+        fl, ms, n = C.c_double(), C.c_double(), C.c_int()
+        lib.check(L.sdxl_profile_gemm_end(C.byref(fl), C.byref(ms), C.byref(n)))
+        achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        roof = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "kernel": "gemm_kernel<NT|NN|TN, conv|linear> (bf16 MFMA 16x16x32, 128x128x64 tile)",
+                "launches_per_step": n.value // args.profile_steps,
+                "gemm_ms_per_step": round(ms.value / args.profile_steps, 2),
+                "gemm_tflop_per_step": round(fl.value / args.profile_steps / 1e12, 2)}
+
+    if rank == 0:
+        step_tflops = value / world * wl["flop_per_image"] / 1e12
+        out = {"metric": "images/sec/node SDXL-base 1024^2 bf16 fwd+bwd", "value": round(value, 3), "unit": "images/sec",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": wl["desc"], "global_batch": wl["B"] * world, "parallelism": f"dp{world}",
+                          "weights": "synthetic (counter-hash init of the 2,567,463,684-parameter SDXL-base UNet)"},
+               "step_tflops_per_gpu": round(step_tflops, 1),
+               "step_mfma_frac": round(step_tflops / PEAK_BF16_TFLOPS, 4),
+               "loss": loss, "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            del net, sync
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(args.cpu_threads or None)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

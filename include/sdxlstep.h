@@ -143,6 +143,11 @@ int sdxl_op_loss(const sdxl_loss_config* lc, const sdxl_batch* b, void* unet_in,
                  float grad_scale, float* out8_dev, int phase /*0 prepare,1 loss,2 dpred*/, void* stream);
 /* debug: run ds_read_b64_tr_b16 / MFMA layout probes (used by tests/test_gpu_layout.py) */
 int sdxl_probe_layout(void* out_dev, void* stream);
+/* measurement: between begin and end every launch of the bf16 MFMA GEMM family (Linear / conv fwd, dgrad, wgrad) is
+ * bracketed by HIP events on its launch stream; end synchronises and returns the summed algorithmic FLOPs
+ * (2*M*N*K*taps), the summed event time and the number of launches. */
+int sdxl_profile_gemm_begin(void);
+int sdxl_profile_gemm_end(double* flops, double* ms, int* launches);
 /* debug: checksum of every activation (grads != 0: of every activation gradient) of the current plan, in creation
  * order; synchronises the device.  n_out receives the number of activations. */
 int sdxl_debug_act_checksums(sdxl_handle* h, unsigned long long* out_host, int cap, int* n_out, int grads);

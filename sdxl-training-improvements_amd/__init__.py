@@ -5,5 +5,7 @@ The directory name is not a valid Python identifier; import it with
 """
 from . import lib  # noqa: F401
 from . import unet  # noqa: F401
+from . import synth  # noqa: F401
+from . import distributed  # noqa: F401
 
-__all__ = ["lib", "unet"]
+__all__ = ["lib", "unet", "synth", "distributed"]

@@ -455,6 +455,8 @@ int sdxl_op_loss(const sdxl_loss_config* lc, const sdxl_batch* b, void* unet_in,
 }
 
 int sdxl_probe_layout(void* out, void* st) { return probe_layout(out, (hipStream_t)st); }
+int sdxl_profile_gemm_begin(void) { return gemm_profile_begin(); }
+int sdxl_profile_gemm_end(double* flops, double* ms, int* launches) { return gemm_profile_end(flops, ms, launches); }
 
 // debug: order-independent checksum (sum of raw 16-bit patterns) of every activation of the current plan, in
 // creation order.  Synchronises.  Used to localise run-to-run differences.

@@ -345,7 +345,53 @@ static int launch_one(const GemmP& p, dim3 grid, hipStream_t st) {
   return 0;
 }
 
-int launch_gemm(const GemmP& pin, hipStream_t st) {
+// ---- optional per-launch timing (bench.py roofline): HIP events on the launch stream around every GEMM launch ----
+#include <vector>
+struct GemmProf {
+  bool on = false;
+  std::vector<hipEvent_t> ev;
+  size_t used = 0;
+  std::vector<double> flops;
+};
+static GemmProf g_prof;
+int gemm_profile_begin() {
+  g_prof.on = true;
+  g_prof.used = 0;
+  g_prof.flops.clear();
+  return 0;
+}
+int gemm_profile_end(double* flops, double* ms, int* launches) {
+  g_prof.on = false;
+  double f = 0, t = 0;
+  HIP_CHECK_RET(hipDeviceSynchronize());
+  for (size_t i = 0; i < g_prof.flops.size(); ++i) {
+    float e = 0.f;
+    HIP_CHECK_RET(hipEventElapsedTime(&e, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+    t += e;
+    f += g_prof.flops[i];
+  }
+  if (flops) *flops = f;
+  if (ms) *ms = t;
+  if (launches) *launches = (int)g_prof.flops.size();
+  return 0;
+}
+static int launch_gemm_impl(const GemmP& pin, hipStream_t st);
+int launch_gemm(const GemmP& p, hipStream_t st) {
+  if (!g_prof.on) return launch_gemm_impl(p, st);
+  while (g_prof.ev.size() < g_prof.used + 2) {
+    hipEvent_t e;
+    HIP_CHECK_RET(hipEventCreate(&e));
+    g_prof.ev.push_back(e);
+  }
+  HIP_CHECK_RET(hipEventRecord(g_prof.ev[g_prof.used], st));
+  int rc = launch_gemm_impl(p, st);
+  HIP_CHECK_RET(hipEventRecord(g_prof.ev[g_prof.used + 1], st));
+  g_prof.used += 2;
+  g_prof.flops.push_back(2.0 * (double)p.M * (double)p.N * (double)p.K * (double)p.taps);
+  return rc;
+}
+
+static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
   GemmP p = pin;
   ARG_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
   ARG_CHECK(p.N % 8 == 0, "gemm: N=%d must be a multiple of 8", p.N);

@@ -42,6 +42,9 @@ struct GemmP {
 };
 void gemm_defaults(GemmP* p);
 int launch_gemm(const GemmP& p, hipStream_t st);
+// per-launch HIP-event timing of every GEMM launch between begin and end (end synchronises the device)
+int gemm_profile_begin();
+int gemm_profile_end(double* flops, double* ms, int* launches);
 
 // ------------------------------------------------------------------------------------------------
 // flash attention, head_dim 64 (attention.hip).  Q rows [B*Nq], K/V rows [B*Nk]; head h lives in

@@ -30,7 +30,7 @@ static GnGeom gn_geom(int HW, int C) {
 }
 size_t groupnorm_ws_floats(int B, int C, int G) {
   size_t fwd = (size_t)GN_MAX_CHUNKS * B * G * 2 + (size_t)B * C * 2;
-  size_t bwd = (size_t)GN_MAX_CHUNKS * B * C * 2 + (size_t)B * C * 3;
+  size_t bwd = (size_t)GN_MAX_CHUNKS * B * C * 2 + (size_t)B * C * 5;
   return fwd > bwd ? fwd : bwd;
 }
 
@@ -85,16 +85,26 @@ __global__ void gn_finalize_kernel(const bf16* __restrict__ x, const float* __re
                                    float* __restrict__ stats, float* __restrict__ coef, int HW, int C, int G,
                                    float eps) {
   __shared__ float gm[64], gr[64];
+  __shared__ float ps[4][64][2];
   const int b = blockIdx.x, B = gridDim.x;
   const int cpg = C / G;
   const float n = (float)HW * (float)cpg;
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+  {  // fixed-order chunk sum: thread (slice = t/64, g = t%64) adds chunks slice, slice+4, ...
+    const int g = threadIdx.x & 63, sl = threadIdx.x >> 6;
     float a = 0.f, q = 0.f;
-    for (int k = 0; k < chunks; ++k) {
-      const float* pp = part + (((long)k * B + b) * G + g) * 2;
-      a += pp[0];
-      q += pp[1];
-    }
+    if (g < G)
+      for (int k = sl; k < chunks; k += 4) {
+        const float* pp = part + (((long)k * B + b) * G + g) * 2;
+        a += pp[0];
+        q += pp[1];
+      }
+    ps[sl][g][0] = a;
+    ps[sl][g][1] = q;
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float a = (ps[0][g][0] + ps[1][g][0]) + (ps[2][g][0] + ps[3][g][0]);
+    float q = (ps[0][g][1] + ps[1][g][1]) + (ps[2][g][1] + ps[3][g][1]);
     float K = (float)x[(long)b * HW * C + g * cpg];
     float m1 = a / n, m2 = q / n;
     float var = fmaxf(m2 - m1 * m1, 0.f);
@@ -215,7 +225,29 @@ __global__ void gn_bwd_reduce_kernel(const bf16* __restrict__ x, const bf16* __r
   }
 }
 
-// per sample: chunk sums (fixed order), dgamma/dbeta, group sums, per-(b,c) coefficients: dx = c1*dn + c3*x + c2
+// fixed-order sum over chunks: block = 64 channels x 4 chunk slices -> sums[b][c][2]
+__global__ void gn_bwd_chunksum_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ sums) {
+  __shared__ float ps[4][64][2];
+  const int b = blockIdx.y, B = gridDim.y;
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float a = 0.f, q = 0.f;
+  if (c < C)
+    for (int k = sl; k < chunks; k += 4) {
+      const float* pp = part + (((long)k * B + b) * C + c) * 2;
+      a += pp[0];
+      q += pp[1];
+    }
+  ps[sl][cl][0] = a;
+  ps[sl][cl][1] = q;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    sums[((long)b * C + c) * 2] = (ps[0][cl][0] + ps[1][cl][0]) + (ps[2][cl][0] + ps[3][cl][0]);
+    sums[((long)b * C + c) * 2 + 1] = (ps[0][cl][1] + ps[1][cl][1]) + (ps[2][cl][1] + ps[3][cl][1]);
+  }
+}
+
+// per sample: dgamma/dbeta, group sums, per-(b,c) coefficients: dx = c1*dn + c3*x + c2
 __global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, const bf16* __restrict__ gamma,
                                        const float* __restrict__ stats, float* __restrict__ coef,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int HW, int C, int G) {
@@ -223,16 +255,11 @@ __global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, int chunk
   float* wa = sh;
   float* wb = sh + C;
   float* gs = sh + 2 * C;
-  const int b = blockIdx.x, B = gridDim.x;
+  const int b = blockIdx.x;
   const int cpg = C / G;
   const float n = (float)HW * (float)cpg;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float A = 0.f, Bs = 0.f;
-    for (int k = 0; k < chunks; ++k) {
-      const float* pp = part + (((long)k * B + b) * C + c) * 2;
-      A += pp[0];
-      Bs += pp[1];
-    }
+    float A = part[((long)b * C + c) * 2], Bs = part[((long)b * C + c) * 2 + 1];   // chunk-summed
     atomicAdd(&dbeta[c], A);     // parameter gradients: fp32 sum over the batch (order-insensitive to ~1e-7)
     atomicAdd(&dgamma[c], Bs);
     float ga = (float)gamma[c];
@@ -310,6 +337,7 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const
   GnGeom g = gn_geom(HW, C);
   float* part = ws;                                      // [chunks][B][C][2]
   float* coef = ws + (size_t)GN_MAX_CHUNKS * B * C * 2;  // [B][C][3]
+  float* sums = coef + (size_t)B * C * 3;                // [B][C][2]
   size_t sh = sizeof(float) * 2 * g.rpi * C;
   if (silu)
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<true>, dim3(g.chunks, B), dim3(g.threads), sh, st, x, dy, gamma, beta,
@@ -317,7 +345,8 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const
   else
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<false>, dim3(g.chunks, B), dim3(g.threads), sh, st, x, dy, gamma, beta,
                        stats, part, HW, C, G, g.vpr, g.rpi, g.rows_per_chunk);
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), sizeof(float) * (2 * C + 2 * G), st, part, g.chunks,
+  hipLaunchKernelGGL(gn_bwd_chunksum_kernel, dim3(cdiv(C, 64), B), dim3(256), 0, st, part, g.chunks, C, sums);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), sizeof(float) * (2 * C + 2 * G), st, sums, g.chunks,
                      gamma, stats, coef, dgamma, dbeta, HW, C, G);
 #define GN_BWD_APPLY(S, A)                                                                                          \
   hipLaunchKernelGGL((gn_bwd_apply_kernel<S, A>), dim3(g.chunks, B), dim3(g.threads), 0, st, x, dy, gamma, beta, stats, \
