@@ -1,0 +1,249 @@
+"""Trainer-plugin surface of the native path -- the drop-in for the reference's method trainers.
+
+Reference contract mirrored here:
+  * constructed like every trainer: (model, optimizer, train_dataloader, device, wandb_logger=None, config=None, **kw)
+    (training/trainers/base_router.py:14-31, sdxl_trainer.py:18-41);
+  * `compute_loss(batch) -> {"loss": 0-d tensor with .backward(), "metrics": dict}` (methods/example_method.py:108-122;
+    flow matching signature `(model, batch, generator=None)` is accepted too, flow_matching_trainer.py:261);
+  * `training_step(batch)` = the DDPM name of the same thing (ddpm_trainer.py:280);
+  * `_execute_training_step(batch, accumulate, is_last_accumulation_step) -> (loss, metrics)`
+    (ddpm_trainer.py:256-278 / flow_matching_trainer.py:237-259), with the D10 repair: gradients are zeroed at the
+    START of an accumulation cycle, not before its last micro-step;
+  * `train(num_epochs)`: the template loop (methods/example_method.py:150-230): every N micro-steps clip -> step -> zero;
+  * batch dict keys {"vae_latents","prompt_embeds","pooled_prompt_embeds","time_ids","metadata"} else ValueError
+    (ddpm_trainer.py:284-290); optional "tag_weights" [B];
+  * metric keys: DDPM loss, lr, timestep_mean, timestep_std, noise_scale, pred_scale, batch_size (ddpm_trainer.py:386-396);
+    flow matching loss, x0_norm, x1_norm, time_mean, time_std, velocity_norm, batch_size, lr
+    (flow_matching_trainer.py:338-347).
+Selected by `training.method` in config.yaml exactly like the reference (sdxl_trainer.py:128-152): "ddpm" or
+"flow_matching"; anything else raises ValueError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import time
+from collections import defaultdict
+from typing import Any, Dict, Optional
+
+import torch
+
+from . import distributed as D
+from . import lib
+from .config import Config
+from .scheduler import NoiseScheduler
+from .unet import NativeUNet
+
+REQUIRED_KEYS = {"vae_latents", "prompt_embeds", "pooled_prompt_embeds", "time_ids", "metadata"}
+
+
+class _NativeLoss(torch.autograd.Function):
+    """0-d loss whose backward runs the HIP backward with the incoming scale (so `(loss / N).backward()` works)."""
+
+    @staticmethod
+    def forward(ctx, anchor, trainer, value):
+        ctx.trainer = trainer
+        return anchor.new_tensor(value)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.trainer._native_backward(float(grad_out))
+        return None, None, None
+
+
+class FlatAdamW:
+    """Plain AdamW over the packed arenas (bf16 weights, fp32 grads, fp32 moments), torch elementwise ops.
+    Functional stand-in so the loop is usable; NOT the reference's AdamWBF16 arithmetic (row f1 of SURVEY 8(f):
+    stochastic-rounded bf16 moments + error feedback, to be a fused HIP kernel)."""
+
+    def __init__(self, net: NativeUNet, lr=1e-6, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        self.net = net
+        self.param_groups = [{"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay}]
+        self.m = torch.zeros_like(net.grads)
+        self.v = torch.zeros_like(net.grads)
+        self.t = 0
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.net.zero_grads()
+
+    @torch.no_grad()
+    def step(self, grads: Optional[torch.Tensor] = None):
+        g = self.net.grads if grads is None else grads.float()
+        p = self.param_groups[0]
+        b1, b2 = p["betas"]
+        self.t += 1
+        self.m.mul_(b1).add_(g, alpha=1 - b1)
+        self.v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (self.v / (1 - b2 ** self.t)).sqrt_().add_(p["eps"])
+        w = self.net.weights.float()
+        w.mul_(1 - p["lr"] * p["weight_decay"]).addcdiv_(self.m, denom, value=-p["lr"] / (1 - b1 ** self.t))
+        self.net.weights.copy_(w)
+
+
+class NativeSDXLTrainer:
+    """SDXL trainer whose compute_loss / backward run in libsdxlstep (HIP, gfx950)."""
+
+    name = "native_mi355x"
+
+    def __init__(self, model, optimizer=None, train_dataloader=None, device=None, wandb_logger=None,
+                 config: Optional[Config] = None, **kwargs):
+        self.model = model
+        self.train_dataloader = train_dataloader
+        self.device = device if device is not None else torch.device("cuda", 0)
+        self.wandb_logger = wandb_logger
+        self.config = config if config is not None else Config()
+        method = str(self.config.training.method).lower()
+        if method not in ("ddpm", "flow_matching"):
+            raise ValueError(f"Unsupported training method: {self.config.training.method}")   # sdxl_trainer.py:151
+        self.method = method
+        self.gradient_accumulation_steps = int(self.config.training.gradient_accumulation_steps)
+        self.net: NativeUNet = model.unet if hasattr(model, "unet") else model
+        for attr in ("forward_loss", "backward", "read_loss", "zero_grads", "param_elems"):
+            if not hasattr(self.net, attr):
+                raise TypeError("model.unet must be a NativeUNet (use NativeUNet.load_state_dict to import a torch "
+                                f"UNet); missing `{attr}`")
+        self.noise_scheduler = NoiseScheduler(self.config, "cpu")
+        self.optimizer = optimizer if optimizer is not None else FlatAdamW(
+            self.net, self.config.optimizer.learning_rate, (self.config.optimizer.beta1, self.config.optimizer.beta2),
+            self.config.optimizer.epsilon, self.config.optimizer.weight_decay)
+        self.sync = D.GradSync(self.net.param_elems, self._cast, torch.bfloat16, getattr(self.net, "device", "cpu"))
+        self._micro = 0                      # micro-step index inside the accumulation cycle
+        self._anchor = torch.zeros((), requires_grad=True)
+        self._exchange = True
+
+    # -------------------------------------------------------------------------------- loss
+    def _cast(self, off, n, dst):
+        lib.check(self.net.L.sdxl_grads_to_bf16(self.net.h, off, n, C.c_void_p(dst.data_ptr()), 1.0,
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def compute_loss(self, *args, generator: Optional[torch.Generator] = None, timesteps=None, noise=None) -> Dict[str, Any]:
+        """compute_loss(batch) or compute_loss(model, batch[, generator]).  `timesteps` (ddpm: int64 indices, flow
+        matching: t in (0,1)) and `noise` (ddpm noise / flow-matching x0) may be injected for reproducible fixtures;
+        otherwise they are drawn as the reference draws them."""
+        batch = args[-1] if not isinstance(args[-1], torch.Generator) else args[-2]
+        if isinstance(args[-1], torch.Generator):
+            generator = args[-1]
+        if not all(k in batch for k in REQUIRED_KEYS):
+            raise ValueError(f"Batch missing required keys: {REQUIRED_KEYS - set(batch.keys())}")
+        lat = batch["vae_latents"].float()
+        B = lat.shape[0]
+        cm = self.config.model
+        if noise is None:
+            noise = torch.randn(lat.shape, generator=generator)
+        tag = batch.get("tag_weights")
+        if self.method == "ddpm":
+            ts = timesteps if timesteps is not None else self.noise_scheduler.sample_timesteps(B, generator)
+            sig = self.noise_scheduler.timestep_to_sigma(ts)
+            self.net.forward_loss("ddpm", lat, noise, sig, ts.float(), batch["prompt_embeds"],
+                                  batch["pooled_prompt_embeds"], batch["time_ids"], tag,
+                                  prediction_type=self.config.training.prediction_type,
+                                  min_snr_gamma=cm.min_snr_gamma, use_ztsnr=cm.use_ztsnr)
+        else:
+            if timesteps is None:                                      # sample_logit_normal, :373-385
+                timesteps = torch.sigmoid(torch.randn(B, generator=generator))
+            t = timesteps.float()
+            if str(self.config.training.mixed_precision) == "bf16":     # D6: t is handed to the UNet in model dtype
+                t_unet = t.to(torch.bfloat16).float()
+            else:
+                t_unet = t
+            self.net.forward_loss("flow_matching", lat, noise, t, t_unet, batch["prompt_embeds"],
+                                  batch["pooled_prompt_embeds"], batch["time_ids"], tag)
+            ts = t
+        o = self.net.read_loss()                                        # the single host sync of the step
+        numel = lat.numel()
+        lr = self.optimizer.param_groups[0]["lr"] if self.optimizer is not None else 0.0
+        if self.method == "ddpm":
+            metrics = {"loss": o[0], "lr": lr, "timestep_mean": float(ts.float().mean()),
+                       "noise_scale": o[4] / numel, "pred_scale": o[2] / numel, "batch_size": B}
+            if B > 1:
+                metrics["timestep_std"] = float(ts.float().std())
+        else:
+            metrics = {"loss": o[0], "x0_norm": math.sqrt(o[5]), "x1_norm": math.sqrt(o[6]),
+                       "time_mean": float(ts.mean()), "time_std": float(ts.std()) if B > 1 else float("nan"),
+                       "velocity_norm": math.sqrt(o[3]), "batch_size": B, "lr": lr}
+        loss = _NativeLoss.apply(self._anchor, self, o[0])
+        return {"loss": loss, "metrics": metrics}
+
+    training_step = compute_loss                                        # DDPM trainer's name for it
+
+    def _native_backward(self, grad_scale: float) -> None:
+        first = self._micro == 0
+        world = self.sync.world
+        self.sync.enabled = self._exchange
+        self.net.backward(grad_scale / world, first, on_segment=self.sync.on_segment if world > 1 else None)
+
+    # -------------------------------------------------------------------------------- loop pieces
+    def _execute_training_step(self, batch, accumulate: bool = False, is_last_accumulation_step: bool = True, **kw):
+        N = self.gradient_accumulation_steps if accumulate else 1
+        if self._micro == 0:
+            self.net.zero_grads()                                      # start of the cycle (D10 repair)
+        self._exchange = (not accumulate) or is_last_accumulation_step
+        out = self.compute_loss(batch, **kw)
+        loss = out["loss"] / N if accumulate else out["loss"]
+        loss.backward()
+        self._micro = 0 if self._exchange else self._micro + 1
+        if self._exchange:
+            self.sync.finish()
+        return loss.detach() * N, out["metrics"]
+
+    def clip_grad_norm_(self, max_norm: float) -> float:
+        """torch.nn.utils.clip_grad_norm_ over the flat arena (flow_matching_trainer.py:181-186)."""
+        if self.sync.world > 1:
+            g = self.sync.reduced()
+            norm = float(g.float().norm())
+            if norm > max_norm:
+                g.mul_(max_norm / (norm + 1e-6))
+            return norm
+        norm = self.net.grad_norm()
+        if norm > max_norm:
+            self.net.grads.mul_(max_norm / (norm + 1e-6))
+        return norm
+
+    def optimizer_step(self) -> Optional[float]:
+        gn = None
+        if self.config.training.clip_grad_norm and self.config.training.clip_grad_norm > 0:
+            gn = self.clip_grad_norm_(float(self.config.training.clip_grad_norm))
+        if self.optimizer is not None:
+            if isinstance(self.optimizer, FlatAdamW):
+                self.optimizer.step(self.sync.reduced() if self.sync.world > 1 else None)
+            else:
+                self.optimizer.step()
+        return gn
+
+    def train(self, num_epochs: int) -> None:
+        N = self.gradient_accumulation_steps
+        global_step = 0
+        for epoch in range(num_epochs):
+            acc_loss, acc_metrics = 0.0, defaultdict(float)
+            for step, batch in enumerate(self.train_dataloader):
+                t0 = time.time()
+                last = (step + 1) % N == 0
+                loss, metrics = self._execute_training_step(batch, accumulate=True, is_last_accumulation_step=last)
+                acc_loss += float(loss)
+                for k, v in metrics.items():
+                    acc_metrics[k] += v
+                if last:
+                    eff = {k: v / N for k, v in acc_metrics.items()}
+                    gn = self.optimizer_step()
+                    if gn is not None:
+                        eff["grad_norm"] = gn
+                    eff.update(epoch=epoch + 1, step=global_step, loss=acc_loss / N, step_time=time.time() - t0)
+                    if D.is_main_process():
+                        if self.wandb_logger is not None:
+                            self.wandb_logger.log_metrics(eff, step=global_step)
+                        else:
+                            print({k: (round(v, 6) if isinstance(v, float) else v) for k, v in eff.items()}, flush=True)
+                    acc_loss, acc_metrics = 0.0, defaultdict(float)
+                global_step += 1
+
+    def save_checkpoint(self, path, is_final: bool = False) -> None:
+        """UNet weights back as a diffusers-keyed state_dict (row f4); the rest of the pipeline stays PyTorch."""
+        if D.is_main_process():
+            torch.save({k: v.cpu() for k, v in self.net.state_dict().items()}, path)
+
+
+def create_trainer(model, optimizer=None, train_dataloader=None, device=None, wandb_logger=None, config=None, **kw):
+    """BaseRouter.create equivalent for model_type == "sdxl" (base_router.py:48-84)."""
+    if config is not None and str(config.model.model_type).lower() != "sdxl":
+        raise ValueError(f"Unsupported model type: {config.model.model_type}")
+    return NativeSDXLTrainer(model, optimizer, train_dataloader, device, wandb_logger, config, **kw)

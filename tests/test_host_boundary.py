@@ -1,0 +1,150 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/sdxlstep.h declares,
+fails loudly without a GPU (no fallback), and the host-side mirror of the trainer-plugin surface behaves like the
+reference's (config loading rule, batch validation, method dispatch, accumulation semantics, metric keys)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+import sdxl_amd  # noqa: F401
+from sdxl_amd import lib
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_header_symbols_all_exported_and_bound():
+    hdr = (ROOT / "include" / "sdxlstep.h").read_text()
+    declared = set(re.findall(r"\b(sdxl_[a-z0-9_]+)\s*\(", hdr))
+    L = lib.load()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in sdxlstep.h but not exported by libsdxlstep.so"
+    bound = set(lib.SIGNATURES) | {"sdxl_last_error"}
+    assert declared == bound, (declared - bound, bound - declared)
+
+
+def test_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = lib.load()
+    cfg = lib.UNetConfig()
+    assert L.sdxl_default_config(C.byref(cfg)) == 0 and list(cfg.block_out_channels) == [320, 640, 1280]
+    h = C.c_void_p()
+    rc = L.sdxl_create(C.byref(cfg), 0, C.byref(h))
+    assert rc != 0 and b"hip" in L.sdxl_last_error().lower()
+    from sdxl_amd import unet
+    with pytest.raises(lib.SdxlError):
+        unet.NativeUNet()
+
+
+def test_bad_arguments_are_reported_not_crashed():
+    L = lib.load()
+    assert L.sdxl_default_config(None) == 1 and b"null" in L.sdxl_last_error()
+    assert L.sdxl_bind_params(None, None, None) == 1
+    assert L.sdxl_num_params(None) == -1
+
+
+def test_config_yaml_rule(tmp_path):
+    import importlib
+    cfgm = importlib.import_module("sdxl-training-improvements_amd.config")
+    p = tmp_path / "c.yaml"
+    p.write_text("training:\n  method: flow_matching\n  gradient_accumulation_steps: 4\n  bogus_key: 1\n"
+                 "model:\n  min_snr_gamma: null\nunknown_section:\n  a: 1\n")
+    c = cfgm.Config.from_yaml(p)
+    assert c.training.method == "flow_matching" and c.training.gradient_accumulation_steps == 4
+    assert c.model.min_snr_gamma is None and c.model.sigma_max == 20000.0 and not hasattr(c.training, "bogus_key")
+    d = cfgm.Config.from_yaml(tmp_path / "missing.yaml")
+    assert d.training.method == "ddpm" and d.model.min_snr_gamma == 5.0 and d.optimizer.optimizer_type == "adamw_bf16"
+
+
+def test_scheduler_matches_reference_goldens(golden):
+    import importlib
+    import numpy as np
+    cfgm = importlib.import_module("sdxl-training-improvements_amd.config")
+    sch = importlib.import_module("sdxl-training-improvements_amd.scheduler")
+    s = sch.NoiseScheduler(cfgm.Config())
+    assert np.array_equal(s.sigmas.numpy(), golden["karras_table"])
+    for c in range(int(golden["n_sched_cases"])):
+        k = f"sch{c}"
+        x, n, t = (torch.from_numpy(golden[f"{k}_{q}"]) for q in ("x", "noise", "t"))
+        assert np.array_equal(s.add_noise(x, n, t).numpy(), golden[f"{k}_noisy"])
+        assert np.array_equal(s.get_velocity(x, n, t).numpy(), golden[f"{k}_vel"])
+        assert np.array_equal(s.get_snr(t).numpy(), golden[f"{k}_snr"])
+    torch.manual_seed(123)
+    assert np.array_equal(s.sample_timesteps(8).numpy(), golden["sample_timesteps_seed123_B8"])
+
+
+class FakeNet:
+    """Records what the trainer asks of the native UNet."""
+    param_elems = 16
+    device = "cpu"
+
+    def __init__(self):
+        self.calls = []
+        self.grads = torch.zeros(16)
+        self.weights = torch.zeros(16, dtype=torch.bfloat16)
+
+    def zero_grads(self):
+        self.calls.append(("zero",))
+
+    def forward_loss(self, method, *a, **k):
+        self.calls.append(("fwd", method, k))
+
+    def backward(self, scale, first, on_segment=None):
+        self.calls.append(("bwd", round(scale, 6), first))
+
+    def read_loss(self):
+        return [0.5, 0, 8.0, 16.0, 4.0, 9.0, 25.0, 1.0]
+
+    def grad_norm(self):
+        return 0.0
+
+
+def _batch(B=2):
+    return {"vae_latents": torch.randn(B, 4, 8, 8), "prompt_embeds": torch.randn(B, 77, 16),
+            "pooled_prompt_embeds": torch.randn(B, 8), "time_ids": torch.zeros(B, 1, 6), "metadata": {}}
+
+
+def _trainer(method, accum=1):
+    import importlib
+    cfgm = importlib.import_module("sdxl-training-improvements_amd.config")
+    T = importlib.import_module("sdxl-training-improvements_amd.trainer")
+    cfg = cfgm.Config()
+    cfg.training.method = method
+    cfg.training.gradient_accumulation_steps = accum
+    net = FakeNet()
+    class M:
+        unet = net
+    return T.NativeSDXLTrainer(M(), optimizer=None, train_dataloader=None, device="cpu", config=cfg), net, T
+
+
+def test_trainer_plugin_contract():
+    tr, net, T = _trainer("ddpm")
+    with pytest.raises(ValueError, match="missing required keys"):
+        tr.compute_loss({"vae_latents": torch.zeros(1, 4, 8, 8)})
+    out = tr.compute_loss(_batch())
+    assert set(out) == {"loss", "metrics"} and out["loss"].dim() == 0 and out["loss"].requires_grad
+    assert set(out["metrics"]) == {"loss", "lr", "timestep_mean", "timestep_std", "noise_scale", "pred_scale", "batch_size"}
+    assert set(tr.compute_loss(_batch(1))["metrics"]) == {"loss", "lr", "timestep_mean", "noise_scale", "pred_scale", "batch_size"}
+    tr2, net2, _ = _trainer("flow_matching")
+    m = tr2.compute_loss(tr2.model, _batch(), torch.Generator().manual_seed(0))["metrics"]   # FM signature (model, batch, generator)
+    assert set(m) == {"loss", "x0_norm", "x1_norm", "time_mean", "time_std", "velocity_norm", "batch_size", "lr"}
+    assert m["x0_norm"] == 3.0 and m["x1_norm"] == 5.0 and m["velocity_norm"] == 4.0
+    with pytest.raises(ValueError, match="Unsupported training method"):
+        _trainer("dreambooth")
+    with pytest.raises(TypeError):
+        T.NativeSDXLTrainer(object(), config=tr.config)
+
+
+def test_accumulation_semantics_d9_d10():
+    """zero_grad at the START of a cycle, backward scale 1/N on every micro-step, first_micro only on the first."""
+    tr, net, _ = _trainer("ddpm", accum=4)
+    for i in range(8):
+        loss, _m = tr._execute_training_step(_batch(), accumulate=True, is_last_accumulation_step=(i + 1) % 4 == 0)
+        assert abs(float(loss) - 0.5) < 1e-6                 # unscaled loss is returned for logging
+    zeros = [i for i, c in enumerate(net.calls) if c[0] == "zero"]
+    bwds = [c for c in net.calls if c[0] == "bwd"]
+    assert len(zeros) == 2 and len(bwds) == 8
+    assert [b[2] for b in bwds] == [True, False, False, False] * 2 and all(b[1] == 0.25 for b in bwds)
+    assert net.calls[0] == ("zero",) and net.calls[zeros[1] - 1][0] == "bwd"
