@@ -330,6 +330,18 @@ int sdxl_grad_sumsq(sdxl_handle* h, float* out, void* st) {
 // ------------------------------------------------------------------------------------------------------------
 // single-kernel entry points
 // ------------------------------------------------------------------------------------------------------------
+static float* g_test_slab = nullptr;
+static size_t g_test_slab_floats = 0;
+static int test_slab(size_t floats, float** out) {   // scratch for the split-K slabs of the test entry points
+  if (floats > g_test_slab_floats) {
+    if (g_test_slab) (void)hipFree(g_test_slab);
+    HIP_CHECK_RET(hipMalloc((void**)&g_test_slab, floats * sizeof(float)));
+    g_test_slab_floats = floats;
+  }
+  *out = g_test_slab;
+  return 0;
+}
+
 int sdxl_op_gemm(int form, const void* A, const void* B, void* C, int M, int N, int K, const void* bias,
                  const void* resid, int accumulate, int splitk, void* st) {
   GemmP g;
@@ -339,7 +351,10 @@ int sdxl_op_gemm(int form, const void* A, const void* B, void* C, int M, int N, 
   g.M = M; g.N = N; g.K = K;
   if (form == GEMM_NT) { g.lda = K; g.ldb = K; }
   else if (form == GEMM_NN) { g.lda = K; g.ldb = N; }
-  else { g.lda = M; g.ldb = N; g.out_f32 = 1; g.splitk = splitk; }
+  else {
+    g.lda = M; g.ldb = N; g.out_f32 = 1; g.splitk = splitk;
+    if (splitk > 1) CHK(test_slab(gemm_slab_floats(M, N, 1, splitk), &g.slab));
+  }
   g.ldc = N;
   g.bias = (const bf16*)bias;
   if (resid) { g.resid = (const bf16*)resid; g.ldr = N; }
@@ -386,6 +401,7 @@ int sdxl_op_conv3x3_wgrad(const void* x, const void* dy, float* dw, int B, int H
   g.taps = 9; g.Hm = Ho; g.Wm = Wo; g.Hs = H; g.Ws = W; g.sm = stride; g.sd = 1;
   g.c_tap_stride = Cin;
   g.out_f32 = 1; g.splitk = splitk; g.accumulate = 1;
+  if (splitk > 1) CHK(test_slab(gemm_slab_floats(Cout, Cin, 9, splitk), &g.slab));
   return launch_gemm(g, (hipStream_t)st);
 }
 

@@ -64,6 +64,7 @@ struct Plan {
   Act *x_in = nullptr, *pred = nullptr, *ehs = nullptr, *aug_in = nullptr, *te_sin = nullptr, *tid_emb = nullptr;
   size_t t_off = NONE, tid_off = NONE, loss_off = NONE;
   size_t gn_ws_off = NONE, gn_ws_floats = 0;  // GroupNorm scratch shared by all (stream-ordered) norm ops
+  size_t slab_off = NONE, slab_floats = 0;    // split-K partial slabs of the wgrad GEMMs (shared, stream-ordered)
 
   Act* new_act(long rows, int cols, bool need_grad = true);
   size_t alloc(size_t bytes);

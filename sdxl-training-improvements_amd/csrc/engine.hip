@@ -58,16 +58,21 @@ bool Plan::grad_alias(Act* x, Act* y) {
 // ================================================================================================
 // Ops
 // ================================================================================================
+// split-K factor of a wgrad GEMM: enough workgroups to fill 256 CUs x 2, at least 8 K-steps per split
 static int pick_splitk(long out_rows, long out_cols, int taps, long red) {
   long tiles = (long)cdiv(out_rows, 128) * cdiv(out_cols, 128) * taps;
   long ktiles = cdiv(red, 64);
-  long s = 640 / tiles;
+  long s = 512 / tiles;
   if (s < 1) s = 1;
-  long maxs = ktiles / 4;
+  long maxs = ktiles / 8;
   if (maxs < 1) maxs = 1;
   if (s > maxs) s = maxs;
-  if (s > 64) s = 64;
+  if (s > 32) s = 32;
   return (int)s;
+}
+static void want_slab(Plan& p, int M, int N, int taps, int splitk) {
+  size_t need = gemm_slab_floats(M, N, taps, splitk);
+  if (need > p.slab_floats) p.slab_floats = need;
 }
 
 struct LinearOp : Op {
@@ -91,6 +96,7 @@ struct LinearOp : Op {
     if (resid) resid_alias = p.grad_alias(resid, y) ? 1 : 0;
     if (x->need_grad) acc_x = p.grad_write(x);
     splitk = pick_splitk(N, K, 1, x->rows);
+    want_slab(p, N, K, 1, splitk);
   }
   int bwd(Plan& p, hipStream_t st, bool first) override {
     const bf16* dy = p.G(y);
@@ -115,7 +121,8 @@ struct LinearOp : Op {
       g.lda = N; g.ldb = K; g.ldc = K;
       g.out_f32 = 1;
       g.splitk = splitk;
-      g.accumulate = (splitk > 1 || !first) ? 1 : 0;
+      g.slab = p.F(p.slab_off);
+      g.accumulate = first ? 0 : 1;
       CHK(launch_gemm(g, st));
     }
     if (b.off != NONE) CHK(launch_colsum_f32(dy, p.eng->Gp(b), M, N, N, st));
@@ -155,6 +162,7 @@ struct ConvOp : Op {
     if (rowvec) { acc_rv = p.grad_write(rowvec); tmp_off = p.alloc(sizeof(float) * Bn * Cout); }
     if (x->need_grad) acc_x = p.grad_write(x);
     splitk = pick_splitk(Cout, Cin, 9, (long)Bn * Ho * Wo);
+    want_slab(p, Cout, Cin, 9, splitk);
   }
   int bwd(Plan& p, hipStream_t st, bool first) override {
     const bf16* dy = p.G(y);
@@ -194,7 +202,8 @@ struct ConvOp : Op {
       g.c_tap_stride = Cin;
       g.out_f32 = 1;
       g.splitk = splitk;
-      g.accumulate = (splitk > 1 || !first) ? 1 : 0;
+      g.slab = p.F(p.slab_off);
+      g.accumulate = first ? 0 : 1;
       CHK(launch_gemm(g, st));
     }
     CHK(launch_colsum_f32(dy, p.eng->Gp(b), (int)Mo, Cout, Cout, st));
@@ -633,6 +642,7 @@ void Engine::build(Plan* plan) {
     // reverse planning: the loss writes d(pred)
     plan->grad_write(plan->pred);
     for (int i = (int)plan->ops.size() - 1; i >= 0; --i) plan->ops[i]->plan_bwd(*plan);
+    plan->slab_off = plan->alloc(sizeof(float) * (plan->slab_floats ? plan->slab_floats : 4));
     plan->seg_first_op.assign(nseg, -1);
     plan->seg_last_op.assign(nseg, -2);
     for (int i = 0; i < (int)plan->ops.size(); ++i) {

@@ -2,8 +2,8 @@
 //
 // One workgroup = 256 threads = 4 waves (2x2), block tile 128x128, K-step 64.
 // Each wave owns a 64x64 sub-tile = 4x4 fragments of v_mfma_f32_16x16x32_bf16.
-// Operand tiles are staged global -> VGPR -> LDS (double-buffered LDS, next tile's global loads in
-// flight under the current tile's MFMAs).  An operand whose reduction dimension is the
+// Operand tiles go global -> LDS directly (global_load_lds_dwordx4, LDS-DMA; two LDS stages, the next tile's DMA
+// in flight under the current tile's MFMAs; XOR-swizzled images, see below).  An operand whose reduction dimension is the
 // contiguous one is read from LDS with ds_read_b128; an operand whose reduction dimension is the
 // strided one (dgrad's weights, both wgrad operands) is read with the gfx950 transpose read
 // ds_read_b64_tr_b16, so no transposed copies of weights or activations are ever materialised.
@@ -19,32 +19,39 @@
 #define BM 128
 #define BN 128
 #define BK 64
-#define LDK 72    // K-contiguous tile:  [128][72] bf16 (144 B rows: 16-B aligned, de-phased banks)
-#define LDN 136   // N-contiguous tile:  [64][136] bf16 (272 B rows)
-#define TILE_BYTES 18432
-#define LDC 132   // fp32 staging of the output tile [128][132]
-#define GEMM_SMEM (4 * TILE_BYTES)
+#define TILE_BYTES 16384  // one operand tile: [128 rows][64 k] or [64 k][128 cols] bf16, XOR-swizzled, no padding
+#define LDC 132           // fp32 staging of the output tile [128][132]
+#define GEMM_SMEM 69632   // max(2 stages x 2 operands x 16 KiB, 128 x 132 x 4 B) -> 2 workgroups per CU
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
 
-__device__ __forceinline__ bf16x8 zero8() {
-  bf16x8 z;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) z[i] = (bf16)0.f;
-  return z;
-}
+// 16 zero bytes in global memory: source of every out-of-range / padded 16-byte vector of the LDS-DMA loads
+__device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
 
-// fragment read, K-contiguous tile: row r, k offset
-__device__ __forceinline__ bf16x8 frag_kc(const bf16* tile, int r, int kofs) {
-  return *(const bf16x8*)(tile + r * LDK + kofs);
+// ---- LDS images -----------------------------------------------------------------------------------------
+// Tiles are written by global_load_lds_dwordx4 (LDS-DMA: 64 lanes x 16 B = one contiguous 1 KiB chunk per wave
+// instruction, no VGPR round trip, no ds_write).  The DMA destination is lane-linear, so the bank swizzle is
+// applied on the per-lane SOURCE address and again on the fragment read (same involution on both sides).
+//  K-contiguous tile [128][64]: 128-B rows, 1 KiB chunk = 8 rows; logical 16-B vector kv of row r sits at
+//     r*128 + ((kv ^ (r & 7)) << 4)                      -> ds_read_b128 fragments conflict-free
+//  N-contiguous tile [64][128]: 256-B rows, 1 KiB chunk = 4 rows; logical vector v of k-row k sits at
+//     k*256 + ((v ^ (F(k) << 1)) << 4),  F(k) = (k & 3) | (((k >> 3) & 1) << 2)
+//                                                        -> ds_read_b64_tr_b16 fragments conflict-free
+__device__ __forceinline__ int swzF(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+__device__ __forceinline__ bf16x8 frag_kc(const char* tile, int r, int kv) {
+  return *(const bf16x8*)(tile + r * 128 + ((kv ^ (r & 7)) << 4));
 }
-// fragment read, N-contiguous tile via transpose read: 8 k-rows starting at krow, 16 columns at col0.
-// Lane i of a 16-lane group supplies the address of 4 contiguous bf16 of row (i>>2), cols 4*(i&3)..;
-// it receives column i of the 4x16 block (rows krow..krow+3), then the same for rows krow+4..+7.
-__device__ __forceinline__ bf16x8 frag_nc(const bf16* tile, int krow, int col0, int lane16) {
-  const bf16* p0 = tile + (krow + (lane16 >> 2)) * LDN + col0 + (lane16 & 3) * 4;
+// 8 k-rows starting at kb (multiple of 8), 16 columns starting at col0 (multiple of 16): lane i of each 16-lane
+// group supplies the address of 4 contiguous bf16 of row (i>>2), columns 4*(i&3).., and receives column i.
+__device__ __forceinline__ bf16x8 frag_nc(const char* tile, int kb, int col0, int l16) {
+  const int krow = kb + (l16 >> 2);
+  const int v = (col0 >> 3) + ((l16 >> 1) & 1);
+  const char* p0 = tile + krow * 256 + ((v ^ (swzF(krow) << 1)) << 4) + (l16 & 1) * 8;
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * LDN));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * 256));   // rows +4: same F (bit 2 unused)
   union { s16x4 s[2]; bf16x8 v; } u;
   u.s[0] = lo;
   u.s[1] = hi;
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int l16 = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * BN;
@@ -107,18 +114,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
     kt_end = ktiles_per_tap * p.taps;
   }
 
-  // ---- per-thread load descriptors (4 x 16-byte vectors per operand per K-step) ----
-  // K-contiguous tile: vector id = v*256+tid -> row id>>3, k offset (id&7)*8
-  // N-contiguous tile: vector id -> k row id>>4, column offset (id&15)*8
+  // ---- per-lane LDS-DMA descriptors: this wave fills chunks wave*4 .. wave*4+3 of each operand tile ----
+  // K-contiguous tile: chunk c = rows 8c..8c+7 ; lane -> row 8c + (lane>>3), physical vector lane&7
+  // N-contiguous tile: chunk c = k-rows 4c..4c+3 ; lane -> k-row 4c + (lane>>4), physical vector lane&15
+  const int kc_rowl = lane >> 3, kc_pv = lane & 7;
+  const int nc_rowl = lane >> 4, nc_pv = lane & 15;
   PixRow arow[4];
   if (CONV && FORM != GEMM_TN) {
 #pragma unroll
-    for (int v = 0; v < 4; ++v) arow[v] = decode_pix(m0 + ((v * 256 + tid) >> 3), p.M, p.Hm, p.Wm);
+    for (int j = 0; j < 4; ++j) arow[j] = decode_pix(m0 + (wave * 4 + j) * 8 + kc_rowl, p.M, p.Hm, p.Wm);
   }
+  const bf16* zsrc = (const bf16*)g_zero16;
 
-  bf16x8 ra[4], rb[4];
-
-  auto load_tiles = [&](int kt) {
+  auto stage = [&](int kt, int buf) {
     int tap = 0, c0;
     if (FORM == GEMM_TN) {
       tap = tap_fixed;
@@ -128,89 +136,56 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
       c0 = (kt - tap * ktiles_per_tap) * BK;
     }
     const int dy = tap / 3, dx = tap - dy * 3;
-    // ---------------- A ----------------
-    if (FORM == GEMM_TN) {
+    char* At = smem + (buf * 2 + 0) * TILE_BYTES;
+    char* Bt = smem + (buf * 2 + 1) * TILE_BYTES;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        int id = v * 256 + tid;
-        int kk = c0 + (id >> 4);
-        int m = m0 + (id & 15) * 8;
-        bool ok = kk < p.K && m < p.M;
-        ra[v] = ok ? *(const bf16x8*)(p.A + (long)kk * p.lda + m) : zero8();
-      }
-    } else {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        int id = v * 256 + tid;
-        int c = c0 + (id & 7) * 8;
-        long rowoff;
-        bool ok;
+    for (int j = 0; j < 4; ++j) {
+      const int c = wave * 4 + j;
+      // ---------------- A ----------------
+      const bf16* src;
+      if (FORM == GEMM_TN) {
+        const int krow = c * 4 + nc_rowl;
+        const int kk = c0 + krow;
+        const int m = m0 + ((nc_pv ^ (swzF(krow) << 1)) << 3);
+        src = (kk < p.K && m < p.M) ? p.A + (long)kk * p.lda + m : zsrc;
+      } else {
+        const int row = c * 8 + kc_rowl;
+        const int kofs = c0 + ((kc_pv ^ (row & 7)) << 3);
         if (CONV) {
-          long src = gather_src(arow[v], dy, dx, p);
-          ok = src >= 0 && c < p.K;
-          rowoff = src * p.lda;
+          long s = gather_src(arow[j], dy, dx, p);
+          src = (s >= 0 && kofs < p.K) ? p.A + s * p.lda + kofs : zsrc;
         } else {
-          int m = m0 + (id >> 3);
-          ok = m < p.M && c < p.K;
-          rowoff = (long)m * p.lda;
+          const int m = m0 + row;
+          src = (m < p.M && kofs < p.K) ? p.A + (long)m * p.lda + kofs : zsrc;
         }
-        ra[v] = ok ? *(const bf16x8*)(p.A + rowoff + c) : zero8();
       }
-    }
-    // ---------------- B ----------------
-    if (FORM == GEMM_NT) {
-      const int wtap = p.flip ? (p.taps - 1 - tap) : tap;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        int id = v * 256 + tid;
-        int n = n0 + (id >> 3);
-        int c = c0 + (id & 7) * 8;
-        bool ok = n < p.N && c < p.K;
-        rb[v] = ok ? *(const bf16x8*)(p.B + (long)n * p.ldb + (long)wtap * p.b_tap_stride + c) : zero8();
-      }
-    } else if (FORM == GEMM_NN) {
-      const int wtap = p.flip ? (p.taps - 1 - tap) : tap;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        int id = v * 256 + tid;
-        int kk = c0 + (id >> 4);
-        int n = n0 + (id & 15) * 8;
-        bool ok = kk < p.K && n < p.N;
-        rb[v] = ok ? *(const bf16x8*)(p.B + (long)kk * p.ldb + (long)wtap * p.b_tap_stride + n) : zero8();
-      }
-    } else {  // TN: rows are reduction pixels, optionally gathered
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        int id = v * 256 + tid;
-        int kk = c0 + (id >> 4);
-        int n = n0 + (id & 15) * 8;
-        long src;
-        if (CONV) {
-          PixRow r = decode_pix(kk, p.K, p.Hm, p.Wm);
-          src = gather_src(r, dy, dx, p);
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(At + c * 1024), 16, 0, 0);
+      // ---------------- B ----------------
+      if (FORM == GEMM_NT) {
+        const int wtap = p.flip ? (p.taps - 1 - tap) : tap;
+        const int row = c * 8 + kc_rowl;
+        const int n = n0 + row;
+        const int kofs = c0 + ((kc_pv ^ (row & 7)) << 3);
+        src = (n < p.N && kofs < p.K) ? p.B + (long)n * p.ldb + (long)wtap * p.b_tap_stride + kofs : zsrc;
+      } else {
+        const int krow = c * 4 + nc_rowl;
+        const int kk = c0 + krow;
+        const int n = n0 + ((nc_pv ^ (swzF(krow) << 1)) << 3);
+        if (FORM == GEMM_NN) {
+          const int wtap = p.flip ? (p.taps - 1 - tap) : tap;
+          src = (kk < p.K && n < p.N) ? p.B + (long)kk * p.ldb + (long)wtap * p.b_tap_stride + n : zsrc;
         } else {
-          src = kk < p.K ? kk : -1;
+          long s;
+          if (CONV) {
+            PixRow r = decode_pix(kk, p.K, p.Hm, p.Wm);
+            s = gather_src(r, dy, dx, p);
+          } else {
+            s = kk < p.K ? kk : -1;
+          }
+          src = (s >= 0 && n < p.N) ? p.B + s * p.ldb + n : zsrc;
         }
-        bool ok = src >= 0 && n < p.N;
-        rb[v] = ok ? *(const bf16x8*)(p.B + src * p.ldb + n) : zero8();
       }
-    }
-  };
-
-  auto store_tiles = [&](int buf) {
-    bf16* At = (bf16*)(smem + (buf * 2 + 0) * TILE_BYTES);
-    bf16* Bt = (bf16*)(smem + (buf * 2 + 1) * TILE_BYTES);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      int id = v * 256 + tid;
-      if (FORM == GEMM_TN)
-        *(bf16x8*)(At + (id >> 4) * LDN + (id & 15) * 8) = ra[v];
-      else
-        *(bf16x8*)(At + (id >> 3) * LDK + (id & 7) * 8) = ra[v];
-      if (FORM == GEMM_NT)
-        *(bf16x8*)(Bt + (id >> 3) * LDK + (id & 7) * 8) = rb[v];
-      else
-        *(bf16x8*)(Bt + (id >> 4) * LDN + (id & 15) * 8) = rb[v];
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(Bt + c * 1024), 16, 0, 0);
     }
   };
 
@@ -220,18 +195,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  if (kt_begin < kt_end) {
-    load_tiles(kt_begin);
-    store_tiles(0);
-  }
-  __syncthreads();
+  if (kt_begin < kt_end) stage(kt_begin, 0);
+  __syncthreads();  // the barrier's release waits vmcnt(0): tile 0 has landed for every wave
 
   int buf = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const bool more = kt + 1 < kt_end;
-    if (more) load_tiles(kt + 1);
-    const bf16* At = (const bf16*)(smem + (buf * 2 + 0) * TILE_BYTES);
-    const bf16* Bt = (const bf16*)(smem + (buf * 2 + 1) * TILE_BYTES);
+    if (kt + 1 < kt_end) stage(kt + 1, buf ^ 1);  // next tile's DMA flies under this tile's MFMAs
+    const char* At = smem + (buf * 2 + 0) * TILE_BYTES;
+    const char* Bt = smem + (buf * 2 + 1) * TILE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[4], bfr[4];
@@ -240,23 +211,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
         if (FORM == GEMM_TN)
           af[i] = frag_nc(At, ks * 32 + g * 8, wm * 64 + i * 16, l16);
         else
-          af[i] = frag_kc(At, wm * 64 + i * 16 + l16, ks * 32 + g * 8);
+          af[i] = frag_kc(At, wm * 64 + i * 16 + l16, ks * 4 + g);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (FORM == GEMM_NT)
-          bfr[j] = frag_kc(Bt, wn * 64 + j * 16 + l16, ks * 32 + g * 8);
+          bfr[j] = frag_kc(Bt, wn * 64 + j * 16 + l16, ks * 4 + g);
         else
           bfr[j] = frag_nc(Bt, ks * 32 + g * 8, wn * 64 + j * 16, l16);
       }
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
     }
-    if (more) store_tiles(buf ^ 1);
-    __syncthreads();
+    __syncthreads();  // vmcnt(0) + barrier: next tile landed, everyone done reading this one
     buf ^= 1;
   }
 
@@ -286,9 +258,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
     }
     if (p.out_f32) {
       float* c = (float*)p.C + (long)m * p.ldc + (long)tap_fixed * p.c_tap_stride + n;
-      if (p.splitk > 1) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(c + e, x[e]);
+      if (p.splitk > 1) {  // deterministic split-K: partial tile to this split's slab, summed by splitk_reduce_kernel
+        float* sl = p.slab + ((long)split * p.M + m) * p.slab_ld + (long)tap_fixed * p.c_tap_stride + n;
+        *(f32x4*)sl = (f32x4){x[0], x[1], x[2], x[3]};
+        *(f32x4*)(sl + 4) = (f32x4){x[4], x[5], x[6], x[7]};
       } else if (p.accumulate) {
         f32x4 a = *(f32x4*)c, b = *(f32x4*)(c + 4);
         a[0] += x[0]; a[1] += x[1]; a[2] += x[2]; a[3] += x[3];
@@ -322,6 +295,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
     }
   }
 }
+
+// C[m][0..cols) (+)= sum_s slab[s][m][0..cols)   (fixed summation order)
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, int M, int cols, long ldc,
+                                     long slab_ld, int splitk, int accumulate) {
+  const int vpr = cols / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)M * vpr; i += (long)gridDim.x * blockDim.x) {
+    long m = i / vpr;
+    int c = (int)(i - m * vpr) * 4;
+    f32x4 a = accumulate ? *(const f32x4*)(C + m * ldc + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < splitk; ++s) {
+      f32x4 v = *(const f32x4*)(slab + ((long)s * M + m) * slab_ld + c);
+      a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+    }
+    *(f32x4*)(C + m * ldc + c) = a;
+  }
+}
+
+size_t gemm_slab_floats(int M, int N, int taps, int splitk) { return splitk > 1 ? (size_t)splitk * M * N * taps : 0; }
 
 void gemm_defaults(GemmP* p) {
   memset(p, 0, sizeof(*p));
@@ -410,12 +401,29 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
     if (p.accumulate) { p.resid = (const bf16*)p.C; p.ldr = p.ldc; }
   }
   if (p.splitk < 1) p.splitk = 1;
+  if (p.splitk > 1) {
+    ARG_CHECK(p.form == GEMM_TN, "gemm: split-K only for the TN (wgrad) form");
+    ARG_CHECK(p.slab != nullptr, "gemm: split-K needs a slab scratch buffer");
+    p.slab_ld = (long)p.N * p.taps;
+  }
   dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), p.form == GEMM_TN ? p.taps * p.splitk : 1);
   const bool conv = p.taps == 9;
+  int rc;
   switch (p.form) {
     case GEMM_NT: return conv ? launch_one<GEMM_NT, true>(p, grid, st) : launch_one<GEMM_NT, false>(p, grid, st);
     case GEMM_NN: return conv ? launch_one<GEMM_NN, true>(p, grid, st) : launch_one<GEMM_NN, false>(p, grid, st);
-    case GEMM_TN: return conv ? launch_one<GEMM_TN, true>(p, grid, st) : launch_one<GEMM_TN, false>(p, grid, st);
+    case GEMM_TN:
+      rc = conv ? launch_one<GEMM_TN, true>(p, grid, st) : launch_one<GEMM_TN, false>(p, grid, st);
+      if (rc == 0 && p.splitk > 1) {
+        const int cols = p.N * p.taps;
+        long nv = (long)p.M * (cols / 4);
+        int g = (int)((nv + 255) / 256);
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, st, p.slab, (float*)p.C, p.M, cols, p.ldc,
+                           p.slab_ld, p.splitk, p.accumulate);
+        HIP_CHECK_RET(hipGetLastError());
+      }
+      return rc;
   }
   ARG_CHECK(false, "gemm: unknown form %d", p.form);
 }

@@ -35,11 +35,16 @@ struct GemmP {
   const bf16* rowvec;
   long ldv;
   int rows_per_batch;
-  // fp32 output (wgrad): C_f32 (+)= acc ; atomic when splitk > 1
+  // fp32 output (wgrad): C_f32 (+)= acc.  splitk > 1: each split writes its partial [M][N*taps] tile set to
+  // slab[split] (plain stores) and a reduce kernel sums the slabs in a fixed order (deterministic, no atomics);
+  // the conv form requires C to be the dense [M][taps*N] weight-gradient matrix (ldc == N*taps).
   int out_f32;
   int accumulate;
   int splitk;
+  float* slab;     // splitk * M * N * taps floats
+  long slab_ld;    // set by the launcher
 };
+size_t gemm_slab_floats(int M, int N, int taps, int splitk);
 void gemm_defaults(GemmP* p);
 int launch_gemm(const GemmP& p, hipStream_t st);
 // per-launch HIP-event timing of every GEMM launch between begin and end (end synchronises the device)
