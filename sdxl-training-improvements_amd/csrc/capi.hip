@@ -1,6 +1,8 @@
 // extern "C" surface of libsdxlstep (see include/sdxlstep.h for the contract of every entry point).
 #include "engine.h"
 
+#include <stdlib.h>
+
 const char* sdxl_get_error();
 
 struct StepState {  // what backward needs from the preceding forward
@@ -57,6 +59,12 @@ int sdxl_create(const sdxl_unet_config* cfg, int device, sdxl_handle** out) {
   h->e.cfg = *cfg;
   h->e.device = device;
   h->e.build(nullptr);
+  const char* ns = getenv("SDXL_NO_SIDE_STREAM");
+  h->e.use_side = !(ns && ns[0] == '1');
+  if (h->e.use_side) {
+    HIP_CHECK_RET(hipStreamCreateWithFlags(&h->e.side, hipStreamNonBlocking));
+    HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_join, hipEventDisableTiming));
+  }
   *out = h;
   return 0;
 }
@@ -66,6 +74,9 @@ int sdxl_destroy(sdxl_handle* h) {
   if (h->e.own_weights && h->e.weights) (void)hipFree(h->e.weights);
   if (h->e.own_grads && h->e.grads) (void)hipFree(h->e.grads);
   if (h->e.own_ws && h->e.ws) (void)hipFree(h->e.ws);
+  for (hipEvent_t ev : h->e.ev_pool) (void)hipEventDestroy(ev);
+  if (h->e.ev_join) (void)hipEventDestroy(h->e.ev_join);
+  if (h->e.side) (void)hipStreamDestroy(h->e.side);
   delete h;
   return 0;
 }
@@ -252,7 +263,12 @@ int sdxl_segment_range(sdxl_handle* h, int k, size_t* off, size_t* n) {
 static int run_backward_segment(Engine& e, int k, bool first, hipStream_t st) {
   Plan& p = *e.cur;
   int s = e.nseg - 1 - k;
+  e.ev_used = 0;   // per-op events are consumed in order; a segment's waits are all enqueued before the pool is reused
   for (int i = p.seg_last_op[s]; i >= p.seg_first_op[s] && i >= 0; --i) CHK(p.ops[i]->bwd(p, st, first));
+  if (e.use_side && e.side) {  // the segment's weight gradients are complete once `st` passes this point
+    HIP_CHECK_RET(hipEventRecord(e.ev_join, e.side));
+    HIP_CHECK_RET(hipStreamWaitEvent(st, e.ev_join, 0));
+  }
   return 0;
 }
 
@@ -434,7 +450,7 @@ int sdxl_op_groupnorm_bwd(const void* x, const void* dy, const void* gamma, cons
                           float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int G, int silu, int accumulate,
                           void* st) {
   return launch_groupnorm_bwd((const bf16*)x, (const bf16*)dy, (const bf16*)gamma, (const bf16*)beta, stats, (bf16*)dx,
-                              dgamma, dbeta, ws, B, HW, C, G, silu, accumulate, (hipStream_t)st);
+                              accumulate ? (const bf16*)dx : nullptr, dgamma, dbeta, ws, B, HW, C, G, silu, (hipStream_t)st);
 }
 int sdxl_op_layernorm_fwd(const void* x, void* y, const void* gamma, const void* beta, float* stats, int M, int C,
                           float eps, void* st) {
@@ -443,8 +459,8 @@ int sdxl_op_layernorm_fwd(const void* x, void* y, const void* gamma, const void*
 }
 int sdxl_op_layernorm_bwd(const void* x, const void* dy, const void* gamma, const float* stats, void* dx, float* dgamma,
                           float* dbeta, int M, int C, int accumulate, void* st) {
-  return launch_layernorm_bwd((const bf16*)x, (const bf16*)dy, (const bf16*)gamma, stats, (bf16*)dx, dgamma, dbeta, M, C,
-                              accumulate, (hipStream_t)st);
+  return launch_layernorm_bwd((const bf16*)x, (const bf16*)dy, (const bf16*)gamma, stats, (bf16*)dx,
+                              accumulate ? (const bf16*)dx : nullptr, dgamma, dbeta, M, C, (hipStream_t)st);
 }
 int sdxl_op_geglu_fwd(const void* u, void* g, int M, int C4, void* st) {
   return launch_geglu_fwd((const bf16*)u, (bf16*)g, M, C4, (hipStream_t)st);

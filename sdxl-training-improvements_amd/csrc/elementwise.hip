@@ -69,11 +69,11 @@ __global__ void silu_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y
   }
 }
 template <bool ACC>
-__global__ void silu_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, bf16* __restrict__ dx,
+__global__ void silu_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, bf16* dx, const bf16* addend,
                                 long nvec) {
   VEC_LOOP(i, nvec) {
     bf16x8 v = *(const bf16x8*)(x + i * 8), d = *(const bf16x8*)(dy + i * 8), o;
-    if (ACC) o = *(const bf16x8*)(dx + i * 8);
+    if (ACC) o = *(const bf16x8*)(addend + i * 8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float g = (float)d[e] * silu_grad_f((float)v[e]);
@@ -97,10 +97,10 @@ int launch_silu_fwd(const bf16* x, bf16* y, long n, hipStream_t st) {
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-int launch_silu_bwd(const bf16* x, const bf16* dy, bf16* dx, long n, int accumulate, hipStream_t st) {
+int launch_silu_bwd(const bf16* x, const bf16* dy, bf16* dx, const bf16* addend, long n, hipStream_t st) {
   ARG_CHECK(n % 8 == 0, "silu: n=%ld", n);
-  if (accumulate) hipLaunchKernelGGL(silu_bwd_kernel<true>, dim3(ew_grid(n / 8)), dim3(EW_BLOCK), 0, st, x, dy, dx, n / 8);
-  else hipLaunchKernelGGL(silu_bwd_kernel<false>, dim3(ew_grid(n / 8)), dim3(EW_BLOCK), 0, st, x, dy, dx, n / 8);
+  if (addend) hipLaunchKernelGGL(silu_bwd_kernel<true>, dim3(ew_grid(n / 8)), dim3(EW_BLOCK), 0, st, x, dy, dx, addend, n / 8);
+  else hipLaunchKernelGGL(silu_bwd_kernel<false>, dim3(ew_grid(n / 8)), dim3(EW_BLOCK), 0, st, x, dy, dx, addend, n / 8);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -122,16 +122,18 @@ __global__ void concat_kernel(const bf16* __restrict__ a, int Ca, const bf16* __
     *(bf16x8*)(o + i * 8) = x;
   }
 }
-__global__ void split_add_kernel(const bf16* __restrict__ g, bf16* __restrict__ ga, int Ca, int acc_a,
-                                 bf16* __restrict__ gb, int Cb, int acc_b, long rows) {
+__global__ void split_add_kernel(const bf16* __restrict__ g, bf16* ga, int Ca, const bf16* add_a, bf16* gb, int Cb,
+                                 const bf16* add_b, long rows) {
   const int va = Ca / 8, vt = (Ca + Cb) / 8;
   VEC_LOOP(i, rows * vt) {
     long r = i / vt;
     int v = (int)(i - r * vt);
     bf16x8 x = *(const bf16x8*)(g + i * 8);
-    bf16* dst = v < va ? ga + r * Ca + v * 8 : gb + r * Cb + (v - va) * 8;
-    if (v < va ? acc_a : acc_b) {
-      bf16x8 y = *(const bf16x8*)dst;
+    const long off = v < va ? r * Ca + v * 8 : r * Cb + (v - va) * 8;
+    bf16* dst = (v < va ? ga : gb) + off;
+    const bf16* add = v < va ? add_a : add_b;
+    if (add) {
+      bf16x8 y = *(const bf16x8*)(add + off);
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = (bf16)((float)x[e] + (float)y[e]);
     }
@@ -145,11 +147,11 @@ int launch_concat(const bf16* a, int Ca, const bf16* b, int Cb, bf16* o, long ro
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-int launch_split_add(const bf16* g, bf16* ga, int Ca, int acc_a, bf16* gb, int Cb, int acc_b, long rows,
+int launch_split_add(const bf16* g, bf16* ga, int Ca, const bf16* add_a, bf16* gb, int Cb, const bf16* add_b, long rows,
                      hipStream_t st) {
   ARG_CHECK(Ca % 8 == 0 && Cb % 8 == 0, "split: Ca=%d Cb=%d", Ca, Cb);
   long nv = rows * ((Ca + Cb) / 8);
-  hipLaunchKernelGGL(split_add_kernel, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, g, ga, Ca, acc_a, gb, Cb, acc_b, rows);
+  hipLaunchKernelGGL(split_add_kernel, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, g, ga, Ca, add_a, gb, Cb, add_b, rows);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -170,7 +172,7 @@ __global__ void upsample2x_kernel(const bf16* __restrict__ x, bf16* __restrict__
   }
 }
 template <bool ACC>
-__global__ void upsample2x_bwd_kernel(const bf16* __restrict__ dy, bf16* __restrict__ dx, int B, int H, int W, int C) {
+__global__ void upsample2x_bwd_kernel(const bf16* __restrict__ dy, bf16* dx, const bf16* addend, int B, int H, int W, int C) {
   const int vpr = C / 8;
   const long n = (long)B * H * W * vpr;
   VEC_LOOP(i, n) {
@@ -193,7 +195,7 @@ __global__ void upsample2x_bwd_kernel(const bf16* __restrict__ dy, bf16* __restr
         for (int e = 0; e < 8; ++e) s[e] += (float)g[e];
       }
     bf16x8 o;
-    if (ACC) o = *(const bf16x8*)(dx + i * 8);
+    if (ACC) o = *(const bf16x8*)(addend + i * 8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (bf16)(ACC ? s[e] + (float)o[e] : s[e]);
     *(bf16x8*)(dx + i * 8) = o;
@@ -206,11 +208,11 @@ int launch_upsample2x(const bf16* x, bf16* y, int B, int H, int W, int C, hipStr
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-int launch_upsample2x_bwd(const bf16* dy, bf16* dx, int B, int H, int W, int C, int accumulate, hipStream_t st) {
+int launch_upsample2x_bwd(const bf16* dy, bf16* dx, const bf16* addend, int B, int H, int W, int C, hipStream_t st) {
   ARG_CHECK(C % 8 == 0, "upsample: C=%d", C);
   long nv = (long)B * H * W * (C / 8);
-  if (accumulate) hipLaunchKernelGGL(upsample2x_bwd_kernel<true>, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, dy, dx, B, H, W, C);
-  else hipLaunchKernelGGL(upsample2x_bwd_kernel<false>, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, dy, dx, B, H, W, C);
+  if (addend) hipLaunchKernelGGL(upsample2x_bwd_kernel<true>, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, dy, dx, addend, B, H, W, C);
+  else hipLaunchKernelGGL(upsample2x_bwd_kernel<false>, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, dy, dx, addend, B, H, W, C);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

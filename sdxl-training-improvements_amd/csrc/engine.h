@@ -68,8 +68,14 @@ struct Plan {
 
   Act* new_act(long rows, int cols, bool need_grad = true);
   size_t alloc(size_t bytes);
-  int grad_write(Act* a);           // reverse planning: returns accumulate flag; allocates on first write
-  bool grad_alias(Act* x, Act* y);  // x.g := y.g when x has none yet
+  // reverse planning.  Gradient buffers are WRITE-ONCE: the first writer of a tensor's gradient gets a fresh buffer,
+  // every later writer gets another fresh buffer plus the previous one as addend (out = addend + contribution), so a
+  // buffer is never modified after it has been produced -- deferred / concurrent readers (the wgrad GEMMs on the
+  // side stream) need no ordering against later accumulations.
+  struct GradDst { size_t out = NONE, addend = NONE; };
+  GradDst grad_dst(Act* a);
+  bool grad_alias(Act* x, Act* y);  // x.g := y.g when x has none yet (residual pass-through, no copy)
+  bf16* GP(size_t off) const;       // workspace pointer of a gradient offset (nullptr for NONE)
   template <class T, class... A>
   T* add(A&&... a);
   // pointers (valid once a workspace is bound)
@@ -98,6 +104,13 @@ struct Engine {
   char* ws = nullptr;
   size_t ws_cap = 0;
   bool own_ws = false;
+  // backward concurrency: weight-gradient GEMMs (and bias column sums) run on a side stream, off the dgrad chain
+  hipStream_t side = nullptr;
+  hipEvent_t ev_join = nullptr;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  bool use_side = true;
+  hipEvent_t next_event();
   // builder state
   bool registering = true;
   size_t native_cursor = 0;
@@ -114,6 +127,7 @@ struct Engine {
 inline bf16* Plan::P(const Act* a) const { return (bf16*)(eng->ws + a->off); }
 inline bf16* Plan::G(const Act* a) const { return a->goff == NONE ? nullptr : (bf16*)(eng->ws + a->goff); }
 inline float* Plan::F(size_t off) const { return (float*)(eng->ws + off); }
+inline bf16* Plan::GP(size_t off) const { return off == NONE ? nullptr : (bf16*)(eng->ws + off); }
 template <class T, class... A>
 T* Plan::add(A&&... a) {
   T* o = new T(std::forward<A>(a)...);

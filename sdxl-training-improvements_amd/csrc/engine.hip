@@ -40,12 +40,31 @@ Act* Plan::new_act(long rows, int cols, bool need_grad) {
   acts.emplace_back(a);
   return a;
 }
-int Plan::grad_write(Act* a) {
-  if (a->goff == NONE) {
-    a->goff = alloc((size_t)a->rows * a->cols * sizeof(bf16));
-    return 0;
+Plan::GradDst Plan::grad_dst(Act* a) {
+  GradDst d;
+  d.addend = a->goff;
+  a->goff = alloc((size_t)a->rows * a->cols * sizeof(bf16));
+  d.out = a->goff;
+  return d;
+}
+hipEvent_t Engine::next_event() {
+  if (ev_used == ev_pool.size()) {
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    ev_pool.push_back(e);
   }
-  return 1;
+  return ev_pool[ev_used++];
+}
+// run `fn(stream)` for the weight-gradient work of one op: on the side stream once `main` has reached this point
+template <class F>
+static int on_side(Plan& p, hipStream_t main, F&& fn) {
+  Engine& e = *p.eng;
+  if (!e.use_side || !e.side) return fn(main);
+  hipEvent_t ev = e.next_event();
+  if (!ev) { sdxl_set_error("hipEventCreate failed"); return 2; }
+  HIP_CHECK_RET(hipEventRecord(ev, main));
+  HIP_CHECK_RET(hipStreamWaitEvent(e.side, ev, 0));
+  return fn(e.side);
 }
 bool Plan::grad_alias(Act* x, Act* y) {
   if (x->goff == NONE) {
@@ -79,7 +98,9 @@ struct LinearOp : Op {
   Act *x, *y, *resid;
   PRef w, b;
   int K, N;
-  int acc_x = 0, resid_alias = 0, splitk = 1;
+  int resid_alias = 0, splitk = 1;
+  size_t dy_off = NONE;
+  Plan::GradDst dx, dres;
   LinearOp(Act* x_, Act* y_, PRef w_, PRef b_, int K_, int N_, Act* resid_) : x(x_), y(y_), resid(resid_), w(w_), b(b_), K(K_), N(N_) {}
   int fwd(Plan& p, hipStream_t st) override {
     GemmP g;
@@ -93,26 +114,20 @@ struct LinearOp : Op {
     return launch_gemm(g, st);
   }
   void plan_bwd(Plan& p) override {
-    if (resid) resid_alias = p.grad_alias(resid, y) ? 1 : 0;
-    if (x->need_grad) acc_x = p.grad_write(x);
+    dy_off = y->goff;
+    if (resid) {
+      resid_alias = p.grad_alias(resid, y) ? 1 : 0;
+      if (!resid_alias) dres = p.grad_dst(resid);
+    }
+    if (x->need_grad) dx = p.grad_dst(x);
     splitk = pick_splitk(N, K, 1, x->rows);
     want_slab(p, N, K, 1, splitk);
   }
   int bwd(Plan& p, hipStream_t st, bool first) override {
-    const bf16* dy = p.G(y);
+    const bf16* dy = p.GP(dy_off);
     const int M = (int)x->rows;
-    if (resid && !resid_alias) CHK(launch_add(p.G(resid), dy, p.G(resid), (long)M * N, st));
-    if (x->need_grad) {
-      GemmP g;
-      gemm_defaults(&g);
-      g.form = GEMM_NN;
-      g.A = dy; g.B = p.eng->Wp(w); g.C = p.G(x);
-      g.M = M; g.N = K; g.K = N;
-      g.lda = N; g.ldb = K; g.ldc = K;
-      g.accumulate = acc_x;
-      CHK(launch_gemm(g, st));
-    }
-    {
+    if (resid && !resid_alias) CHK(launch_add(p.GP(dres.addend), dy, p.GP(dres.out), (long)M * N, st));
+    CHK(on_side(p, st, [&](hipStream_t s2) -> int {
       GemmP g;
       gemm_defaults(&g);
       g.form = GEMM_TN;
@@ -123,9 +138,20 @@ struct LinearOp : Op {
       g.splitk = splitk;
       g.slab = p.F(p.slab_off);
       g.accumulate = first ? 0 : 1;
+      CHK(launch_gemm(g, s2));
+      if (b.off != NONE) CHK(launch_colsum_f32(dy, p.eng->Gp(b), M, N, N, s2));
+      return 0;
+    }));
+    if (x->need_grad) {
+      GemmP g;
+      gemm_defaults(&g);
+      g.form = GEMM_NN;
+      g.A = dy; g.B = p.eng->Wp(w); g.C = p.GP(dx.out);
+      g.M = M; g.N = K; g.K = N;
+      g.lda = N; g.ldb = K; g.ldc = K;
+      if (dx.addend != NONE) { g.resid = p.GP(dx.addend); g.ldr = K; }
       CHK(launch_gemm(g, st));
     }
-    if (b.off != NONE) CHK(launch_colsum_f32(dy, p.eng->Gp(b), M, N, N, st));
     return 0;
   }
 };
@@ -134,8 +160,10 @@ struct ConvOp : Op {
   Act *x, *y, *resid, *rowvec;
   PRef w, b;
   int Bn, H, W, Cin, Cout, stride, Ho, Wo;
-  int acc_x = 0, resid_alias = 0, acc_rv = 0, splitk = 1;
+  int resid_alias = 0, splitk = 1;
   size_t tmp_off = NONE;  // fp32 [B][Cout] for the rowvec gradient
+  size_t dy_off = NONE;
+  Plan::GradDst dx, dres, drv;
   ConvOp(Act* x_, Act* y_, PRef w_, PRef b_, int B_, int H_, int W_, int Cin_, int Cout_, int stride_, Act* resid_,
          Act* rowvec_)
       : x(x_), y(y_), resid(resid_), rowvec(rowvec_), w(w_), b(b_), Bn(B_), H(H_), W(W_), Cin(Cin_), Cout(Cout_),
@@ -158,40 +186,21 @@ struct ConvOp : Op {
     return launch_gemm(g, st);
   }
   void plan_bwd(Plan& p) override {
-    if (resid) resid_alias = p.grad_alias(resid, y) ? 1 : 0;
-    if (rowvec) { acc_rv = p.grad_write(rowvec); tmp_off = p.alloc(sizeof(float) * Bn * Cout); }
-    if (x->need_grad) acc_x = p.grad_write(x);
+    dy_off = y->goff;
+    if (resid) {
+      resid_alias = p.grad_alias(resid, y) ? 1 : 0;
+      if (!resid_alias) dres = p.grad_dst(resid);
+    }
+    if (rowvec) { drv = p.grad_dst(rowvec); tmp_off = p.alloc(sizeof(float) * Bn * Cout); }
+    if (x->need_grad) dx = p.grad_dst(x);
     splitk = pick_splitk(Cout, Cin, 9, (long)Bn * Ho * Wo);
     want_slab(p, Cout, Cin, 9, splitk);
   }
   int bwd(Plan& p, hipStream_t st, bool first) override {
-    const bf16* dy = p.G(y);
+    const bf16* dy = p.GP(dy_off);
     const long Mo = (long)Bn * Ho * Wo;
-    if (resid && !resid_alias) CHK(launch_add(p.G(resid), dy, p.G(resid), Mo * Cout, st));
-    if (rowvec) {
-      float* tmp = p.F(tmp_off);
-      HIP_CHECK_RET(hipMemsetAsync(tmp, 0, sizeof(float) * Bn * Cout, st));
-      for (int bi = 0; bi < Bn; ++bi)
-        CHK(launch_colsum_f32(dy + (long)bi * Ho * Wo * Cout, tmp + (long)bi * Cout, Ho * Wo, Cout, Cout, st));
-      if (acc_rv) {
-        sdxl_set_error("conv: accumulating rowvec gradient is not supported");
-        return 3;
-      }
-      CHK(launch_f32_to_bf16(tmp, p.G(rowvec), (long)Bn * Cout, 1.f, st));
-    }
-    if (x->need_grad) {
-      GemmP g;
-      gemm_defaults(&g);
-      g.form = GEMM_NN;
-      g.A = dy; g.B = p.eng->Wp(w); g.C = p.G(x);
-      g.M = Bn * H * W; g.N = Cin; g.K = Cout;
-      g.lda = Cout; g.ldb = 9L * Cin; g.ldc = Cin;
-      g.taps = 9; g.Hm = H; g.Wm = W; g.Hs = Ho; g.Ws = Wo; g.sm = 1; g.sd = stride;
-      g.flip = 1; g.b_tap_stride = Cin;
-      g.accumulate = acc_x;
-      CHK(launch_gemm(g, st));
-    }
-    {
+    if (resid && !resid_alias) CHK(launch_add(p.GP(dres.addend), dy, p.GP(dres.out), Mo * Cout, st));
+    CHK(on_side(p, st, [&](hipStream_t s2) -> int {
       GemmP g;
       gemm_defaults(&g);
       g.form = GEMM_TN;
@@ -204,9 +213,30 @@ struct ConvOp : Op {
       g.splitk = splitk;
       g.slab = p.F(p.slab_off);
       g.accumulate = first ? 0 : 1;
+      CHK(launch_gemm(g, s2));
+      CHK(launch_colsum_f32(dy, p.eng->Gp(b), (int)Mo, Cout, Cout, s2));
+      return 0;
+    }));
+    if (rowvec) {
+      if (drv.addend != NONE) { sdxl_set_error("conv: time-embedding row vector has another gradient writer"); return 3; }
+      float* tmp = p.F(tmp_off);
+      HIP_CHECK_RET(hipMemsetAsync(tmp, 0, sizeof(float) * Bn * Cout, st));
+      for (int bi = 0; bi < Bn; ++bi)
+        CHK(launch_colsum_f32(dy + (long)bi * Ho * Wo * Cout, tmp + (long)bi * Cout, Ho * Wo, Cout, Cout, st));
+      CHK(launch_f32_to_bf16(tmp, p.GP(drv.out), (long)Bn * Cout, 1.f, st));
+    }
+    if (x->need_grad) {
+      GemmP g;
+      gemm_defaults(&g);
+      g.form = GEMM_NN;
+      g.A = dy; g.B = p.eng->Wp(w); g.C = p.GP(dx.out);
+      g.M = Bn * H * W; g.N = Cin; g.K = Cout;
+      g.lda = Cout; g.ldb = 9L * Cin; g.ldc = Cin;
+      g.taps = 9; g.Hm = H; g.Wm = W; g.Hs = Ho; g.Ws = Wo; g.sm = 1; g.sd = stride;
+      g.flip = 1; g.b_tap_stride = Cin;
+      if (dx.addend != NONE) { g.resid = p.GP(dx.addend); g.ldr = Cin; }
       CHK(launch_gemm(g, st));
     }
-    CHK(launch_colsum_f32(dy, p.eng->Gp(b), (int)Mo, Cout, Cout, st));
     return 0;
   }
 };
@@ -217,7 +247,8 @@ struct GroupNormOp : Op {
   int Bn, HW, C, G, silu;
   float eps;
   size_t stats_off;
-  int acc_x = 0;
+  size_t dy_off = NONE;
+  Plan::GradDst dx;
   GroupNormOp(Plan& p, Act* x_, Act* y_, PRef g_, PRef b_, int B_, int HW_, int C_, int G_, float eps_, int silu_)
       : x(x_), y(y_), gm(g_), bt(b_), Bn(B_), HW(HW_), C(C_), G(G_), silu(silu_), eps(eps_) {
     stats_off = p.alloc(sizeof(float) * Bn * G * 2);
@@ -228,10 +259,10 @@ struct GroupNormOp : Op {
     return launch_groupnorm_fwd(p.P(x), p.P(y), p.eng->Wp(gm), p.eng->Wp(bt), p.F(stats_off), p.F(p.gn_ws_off), Bn, HW, C, G,
                                 eps, silu, st);
   }
-  void plan_bwd(Plan& p) override { acc_x = p.grad_write(x); }
+  void plan_bwd(Plan& p) override { dy_off = y->goff; dx = p.grad_dst(x); }
   int bwd(Plan& p, hipStream_t st, bool) override {
-    return launch_groupnorm_bwd(p.P(x), p.G(y), p.eng->Wp(gm), p.eng->Wp(bt), p.F(stats_off), p.G(x), p.eng->Gp(gm),
-                                p.eng->Gp(bt), p.F(p.gn_ws_off), Bn, HW, C, G, silu, acc_x, st);
+    return launch_groupnorm_bwd(p.P(x), p.GP(dy_off), p.eng->Wp(gm), p.eng->Wp(bt), p.F(stats_off), p.GP(dx.out),
+                                p.GP(dx.addend), p.eng->Gp(gm), p.eng->Gp(bt), p.F(p.gn_ws_off), Bn, HW, C, G, silu, st);
   }
 };
 
@@ -241,17 +272,18 @@ struct LayerNormOp : Op {
   int C;
   float eps;
   size_t stats_off;
-  int acc_x = 0;
+  size_t dy_off = NONE;
+  Plan::GradDst dx;
   LayerNormOp(Plan& p, Act* x_, Act* y_, PRef g_, PRef b_, int C_, float eps_) : x(x_), y(y_), gm(g_), bt(b_), C(C_), eps(eps_) {
     stats_off = p.alloc(sizeof(float) * x->rows * 2);
   }
   int fwd(Plan& p, hipStream_t st) override {
     return launch_layernorm_fwd(p.P(x), p.P(y), p.eng->Wp(gm), p.eng->Wp(bt), p.F(stats_off), (int)x->rows, C, eps, st);
   }
-  void plan_bwd(Plan& p) override { acc_x = p.grad_write(x); }
+  void plan_bwd(Plan& p) override { dy_off = y->goff; dx = p.grad_dst(x); }
   int bwd(Plan& p, hipStream_t st, bool) override {
-    return launch_layernorm_bwd(p.P(x), p.G(y), p.eng->Wp(gm), p.F(stats_off), p.G(x), p.eng->Gp(gm), p.eng->Gp(bt),
-                                (int)x->rows, C, acc_x, st);
+    return launch_layernorm_bwd(p.P(x), p.GP(dy_off), p.eng->Wp(gm), p.F(stats_off), p.GP(dx.out), p.GP(dx.addend),
+                                p.eng->Gp(gm), p.eng->Gp(bt), (int)x->rows, C, st);
   }
 };
 
@@ -279,14 +311,14 @@ struct AttnOp : Op {
     a.O = p.P(o); a.ldo = C;
     a.LSE = p.F(lse_off);
     if (grads) {
-      a.dO = p.G(o); a.lddo = C;
+      a.dO = p.GP(do_off); a.lddo = C;
       a.Delta = p.F(delta_off);
       if (self) {
-        a.dQ = p.G(q); a.dK = p.G(q) + C; a.dV = p.G(q) + 2 * C;
+        a.dQ = p.GP(dq.out); a.dK = a.dQ + C; a.dV = a.dQ + 2 * C;
         a.lddq = a.lddk = a.lddv = 3L * C;
       } else {
-        a.dQ = p.G(q); a.lddq = C;
-        a.dK = p.G(kv); a.dV = p.G(kv) + C; a.lddk = a.lddv = 2L * C;
+        a.dQ = p.GP(dq.out); a.lddq = C;
+        a.dK = p.GP(dkv.out); a.dV = a.dK + C; a.lddk = a.lddv = 2L * C;
       }
     }
   }
@@ -296,9 +328,13 @@ struct AttnOp : Op {
     return launch_attn_fwd(a, st);
   }
   bool bad = false;
+  size_t do_off = NONE;
+  Plan::GradDst dq, dkv;
   void plan_bwd(Plan& p) override {
-    if (p.grad_write(q)) bad = true;
-    if (!self && p.grad_write(kv)) bad = true;
+    do_off = o->goff;
+    dq = p.grad_dst(q);
+    if (dq.addend != NONE) bad = true;
+    if (!self) { dkv = p.grad_dst(kv); if (dkv.addend != NONE) bad = true; }
   }
   int bwd(Plan& p, hipStream_t st, bool) override {
     if (bad) { sdxl_set_error("attention: operand gradient has another writer"); return 3; }
@@ -312,44 +348,53 @@ struct GegluOp : Op {
   Act *u, *g;
   int C4;
   bool bad = false;
+  size_t dg_off = NONE;
+  Plan::GradDst du;
   GegluOp(Act* u_, Act* g_, int C4_) : u(u_), g(g_), C4(C4_) {}
   int fwd(Plan& p, hipStream_t st) override { return launch_geglu_fwd(p.P(u), p.P(g), (int)u->rows, C4, st); }
-  void plan_bwd(Plan& p) override { if (p.grad_write(u)) bad = true; }
+  void plan_bwd(Plan& p) override { dg_off = g->goff; du = p.grad_dst(u); if (du.addend != NONE) bad = true; }
   int bwd(Plan& p, hipStream_t st, bool) override {
     if (bad) { sdxl_set_error("geglu: operand gradient has another writer"); return 3; }
-    return launch_geglu_bwd(p.P(u), p.G(g), p.G(u), (int)u->rows, C4, st);
+    return launch_geglu_bwd(p.P(u), p.GP(dg_off), p.GP(du.out), (int)u->rows, C4, st);
   }
 };
 
 struct SiluOp : Op {
   Act *x, *y;
-  int acc = 0;
+  size_t dy_off = NONE;
+  Plan::GradDst dx;
   SiluOp(Act* x_, Act* y_) : x(x_), y(y_) {}
   int fwd(Plan& p, hipStream_t st) override { return launch_silu_fwd(p.P(x), p.P(y), x->rows * x->cols, st); }
-  void plan_bwd(Plan& p) override { acc = p.grad_write(x); }
+  void plan_bwd(Plan& p) override { dy_off = y->goff; dx = p.grad_dst(x); }
   int bwd(Plan& p, hipStream_t st, bool) override {
-    return launch_silu_bwd(p.P(x), p.G(y), p.G(x), x->rows * x->cols, acc, st);
+    return launch_silu_bwd(p.P(x), p.GP(dy_off), p.GP(dx.out), p.GP(dx.addend), x->rows * x->cols, st);
   }
 };
 
 struct ConcatOp : Op {
   Act *a, *b, *o;
-  int acc_a = 0, acc_b = 0;
+  size_t do_off = NONE;
+  Plan::GradDst da, db;
   ConcatOp(Act* a_, Act* b_, Act* o_) : a(a_), b(b_), o(o_) {}
   int fwd(Plan& p, hipStream_t st) override { return launch_concat(p.P(a), a->cols, p.P(b), b->cols, p.P(o), a->rows, st); }
-  void plan_bwd(Plan& p) override { acc_a = p.grad_write(a); acc_b = p.grad_write(b); }
+  void plan_bwd(Plan& p) override { do_off = o->goff; da = p.grad_dst(a); db = p.grad_dst(b); }
   int bwd(Plan& p, hipStream_t st, bool) override {
-    return launch_split_add(p.G(o), p.G(a), a->cols, acc_a, p.G(b), b->cols, acc_b, a->rows, st);
+    return launch_split_add(p.GP(do_off), p.GP(da.out), a->cols, p.GP(da.addend), p.GP(db.out), b->cols, p.GP(db.addend),
+                            a->rows, st);
   }
 };
 
 struct UpsampleOp : Op {
   Act *x, *y;
-  int Bn, H, W, C, acc = 0;
+  int Bn, H, W, C;
+  size_t dy_off = NONE;
+  Plan::GradDst dx;
   UpsampleOp(Act* x_, Act* y_, int B_, int H_, int W_, int C_) : x(x_), y(y_), Bn(B_), H(H_), W(W_), C(C_) {}
   int fwd(Plan& p, hipStream_t st) override { return launch_upsample2x(p.P(x), p.P(y), Bn, H, W, C, st); }
-  void plan_bwd(Plan& p) override { acc = p.grad_write(x); }
-  int bwd(Plan& p, hipStream_t st, bool) override { return launch_upsample2x_bwd(p.G(y), p.G(x), Bn, H, W, C, acc, st); }
+  void plan_bwd(Plan& p) override { dy_off = y->goff; dx = p.grad_dst(x); }
+  int bwd(Plan& p, hipStream_t st, bool) override {
+    return launch_upsample2x_bwd(p.GP(dy_off), p.GP(dx.out), p.GP(dx.addend), Bn, H, W, C, st);
+  }
 };
 
 // conditioning embeddings (inputs only: no gradient).  t -> sincos(320); time_ids -> sincos(256) x 6;
@@ -640,7 +685,7 @@ void Engine::build(Plan* plan) {
   } else {
     plan->gn_ws_off = plan->alloc(sizeof(float) * plan->gn_ws_floats);
     // reverse planning: the loss writes d(pred)
-    plan->grad_write(plan->pred);
+    plan->grad_dst(plan->pred);
     for (int i = (int)plan->ops.size() - 1; i >= 0; --i) plan->ops[i]->plan_bwd(*plan);
     plan->slab_off = plan->alloc(sizeof(float) * (plan->slab_floats ? plan->slab_floats : 4));
     plan->seg_first_op.assign(nseg, -1);

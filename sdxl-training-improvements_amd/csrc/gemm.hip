@@ -1,7 +1,7 @@
 // bf16 MFMA GEMM family for gfx950 (MI355X): Linear / conv3x3 forward, dgrad and wgrad.
 //
-// One workgroup = 256 threads = 4 waves (2x2), block tile 128x128, K-step 64.
-// Each wave owns a 64x64 sub-tile = 4x4 fragments of v_mfma_f32_16x16x32_bf16.
+// One workgroup = 256 threads = 4 waves (2x2), block tile 128 x BN (BN = 160 or 128), K-step 64.
+// Each wave owns a 64 x BN/2 sub-tile = 4 x (BN/32) fragments of v_mfma_f32_16x16x32_bf16.
 // Operand tiles go global -> LDS directly (global_load_lds_dwordx4, LDS-DMA; two LDS stages, the next tile's DMA
 // in flight under the current tile's MFMAs; XOR-swizzled images, see below).  An operand whose reduction dimension is the
 // contiguous one is read from LDS with ds_read_b128; an operand whose reduction dimension is the
@@ -16,12 +16,11 @@
 // C/D layout: col = l & 15, row = 4*(l>>4) + reg.
 #include "kernels.h"
 
+#include <stdlib.h>
+
 #define BM 128
-#define BN 128
 #define BK 64
-#define TILE_BYTES 16384  // one operand tile: [128 rows][64 k] or [64 k][128 cols] bf16, XOR-swizzled, no padding
-#define LDC 132           // fp32 staging of the output tile [128][132]
-#define GEMM_SMEM 69632   // max(2 stages x 2 operands x 16 KiB, 128 x 132 x 4 B) -> 2 workgroups per CU
+#define A_TILE_BYTES 16384  // [128 rows][64 k] or [64 k][128 cols] bf16, swizzled, no padding
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef __attribute__((address_space(3))) void lds_void;
@@ -33,25 +32,40 @@ __device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u
 // ---- LDS images -----------------------------------------------------------------------------------------
 // Tiles are written by global_load_lds_dwordx4 (LDS-DMA: 64 lanes x 16 B = one contiguous 1 KiB chunk per wave
 // instruction, no VGPR round trip, no ds_write).  The DMA destination is lane-linear, so the bank swizzle is
-// applied on the per-lane SOURCE address and again on the fragment read (same involution on both sides).
-//  K-contiguous tile [128][64]: 128-B rows, 1 KiB chunk = 8 rows; logical 16-B vector kv of row r sits at
+// applied on the per-lane SOURCE address and again on the fragment read (same permutation on both sides).
+//  K-contiguous tile [R][64]: 128-B rows, 1 KiB chunk = 8 rows; logical 16-B vector kv of row r sits at
 //     r*128 + ((kv ^ (r & 7)) << 4)                      -> ds_read_b128 fragments conflict-free
-//  N-contiguous tile [64][128]: 256-B rows, 1 KiB chunk = 4 rows; logical vector v of k-row k sits at
-//     k*256 + ((v ^ (F(k) << 1)) << 4),  F(k) = (k & 3) | (((k >> 3) & 1) << 2)
+//  N-contiguous tile [64][W] (W = 128 or 160 columns, V = W/8 vectors per k-row):
+//     W = 128: vector v of k-row k sits at k*256 + ((v ^ (F(k) << 1)) << 4),  F(k) = (k & 3) | (((k >> 3) & 1) << 2)
+//     W = 160: 320-B rows already spread 4 consecutive k-rows over disjoint banks; rows k and k+8 would collide, so
+//              rows with bit 3 set are rotated by 2 vectors: vector v sits at k*320 + (((v + 2*((k>>3)&1)) % 20) << 4)
 //                                                        -> ds_read_b64_tr_b16 fragments conflict-free
 __device__ __forceinline__ int swzF(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+template <int W>
+__device__ __forceinline__ int nc_phys(int k, int v) {  // physical vector slot of logical vector v in k-row k
+  if (W == 128) return v ^ (swzF(k) << 1);
+  int q = v + 2 * ((k >> 3) & 1);
+  return q >= 20 ? q - 20 : q;
+}
+template <int W>
+__device__ __forceinline__ int nc_logical(int k, int pv) {  // inverse of nc_phys
+  if (W == 128) return pv ^ (swzF(k) << 1);
+  int q = pv - 2 * ((k >> 3) & 1);
+  return q < 0 ? q + 20 : q;
+}
 
 __device__ __forceinline__ bf16x8 frag_kc(const char* tile, int r, int kv) {
   return *(const bf16x8*)(tile + r * 128 + ((kv ^ (r & 7)) << 4));
 }
 // 8 k-rows starting at kb (multiple of 8), 16 columns starting at col0 (multiple of 16): lane i of each 16-lane
 // group supplies the address of 4 contiguous bf16 of row (i>>2), columns 4*(i&3).., and receives column i.
+template <int W>
 __device__ __forceinline__ bf16x8 frag_nc(const char* tile, int kb, int col0, int l16) {
   const int krow = kb + (l16 >> 2);
   const int v = (col0 >> 3) + ((l16 >> 1) & 1);
-  const char* p0 = tile + krow * 256 + ((v ^ (swzF(krow) << 1)) << 4) + (l16 & 1) * 8;
+  const char* p0 = tile + krow * (W * 2) + (nc_phys<W>(krow, v) << 4) + (l16 & 1) * 8;
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * 256));   // rows +4: same F (bit 2 unused)
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * (W * 2)));  // rows +4: same swizzle
   union { s16x4 s[2]; bf16x8 v; } u;
   u.s[0] = lo;
   u.s[1] = hi;
@@ -87,8 +101,20 @@ __device__ __forceinline__ long gather_src(const PixRow& r, int dy, int dx, cons
   return ((long)r.b * p.Hs + ys) * p.Ws + xs;
 }
 
-template <int FORM, bool CONV>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// FORM / CONV as above; BN = 128 or 160 output columns per workgroup; S = LDS ring depth (S-1 K-steps of DMA in flight)
+template <int FORM, bool CONV, int BN, int S>
+__global__ __launch_bounds__(256, (S == 2 ? 2 : 1)) void gemm_kernel(const GemmP p) {
+  constexpr int B_TILE_BYTES = BN * 128;                    // [BN][64] or [64][BN] bf16
+  constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
+  constexpr int NJ = BN / 32;                               // B fragments per wave (wave tile 64 x BN/2)
+  constexpr int BCH = BN / 32;                              // 1 KiB B chunks per wave per K-step
+  constexpr int NL = 4 + BCH;                               // LDS-DMA instructions per wave per K-step
+  constexpr int LDC = BN + 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -114,11 +140,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
     kt_end = ktiles_per_tap * p.taps;
   }
 
-  // ---- per-lane LDS-DMA descriptors: this wave fills chunks wave*4 .. wave*4+3 of each operand tile ----
+  // ---- per-lane LDS-DMA descriptors ----
   // K-contiguous tile: chunk c = rows 8c..8c+7 ; lane -> row 8c + (lane>>3), physical vector lane&7
-  // N-contiguous tile: chunk c = k-rows 4c..4c+3 ; lane -> k-row 4c + (lane>>4), physical vector lane&15
+  // N-contiguous tile of width Wd: chunk c = vectors 64c..64c+63 of the [64][Wd/8] vector grid
   const int kc_rowl = lane >> 3, kc_pv = lane & 7;
-  const int nc_rowl = lane >> 4, nc_pv = lane & 15;
   PixRow arow[4];
   if (CONV && FORM != GEMM_TN) {
 #pragma unroll
@@ -136,17 +161,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
       c0 = (kt - tap * ktiles_per_tap) * BK;
     }
     const int dy = tap / 3, dx = tap - dy * 3;
-    char* At = smem + (buf * 2 + 0) * TILE_BYTES;
-    char* Bt = smem + (buf * 2 + 1) * TILE_BYTES;
+    char* At = smem + buf * STAGE_BYTES;
+    char* Bt = At + A_TILE_BYTES;
+    // ---------------- A : 4 chunks per wave ----------------
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = wave * 4 + j;
-      // ---------------- A ----------------
       const bf16* src;
       if (FORM == GEMM_TN) {
-        const int krow = c * 4 + nc_rowl;
+        const int krow = c * 4 + (lane >> 4);
         const int kk = c0 + krow;
-        const int m = m0 + ((nc_pv ^ (swzF(krow) << 1)) << 3);
+        const int m = m0 + (nc_logical<128>(krow, lane & 15) << 3);
         src = (kk < p.K && m < p.M) ? p.A + (long)kk * p.lda + m : zsrc;
       } else {
         const int row = c * 8 + kc_rowl;
@@ -160,7 +185,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
         }
       }
       __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(At + c * 1024), 16, 0, 0);
-      // ---------------- B ----------------
+    }
+    // ---------------- B : BCH chunks per wave ----------------
+#pragma unroll
+    for (int j = 0; j < BCH; ++j) {
+      const int c = wave * BCH + j;
+      const bf16* src;
       if (FORM == GEMM_NT) {
         const int wtap = p.flip ? (p.taps - 1 - tap) : tap;
         const int row = c * 8 + kc_rowl;
@@ -168,9 +198,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
         const int kofs = c0 + ((kc_pv ^ (row & 7)) << 3);
         src = (n < p.N && kofs < p.K) ? p.B + (long)n * p.ldb + (long)wtap * p.b_tap_stride + kofs : zsrc;
       } else {
-        const int krow = c * 4 + nc_rowl;
+        constexpr int V = BN / 8;
+        const int q = c * 64 + lane;
+        const int krow = q / V, pv = q - krow * V;
         const int kk = c0 + krow;
-        const int n = n0 + ((nc_pv ^ (swzF(krow) << 1)) << 3);
+        const int n = n0 + (nc_logical<BN>(krow, pv) << 3);
         if (FORM == GEMM_NN) {
           const int wtap = p.flip ? (p.taps - 1 - tap) : tap;
           src = (kk < p.K && n < p.N) ? p.B + (long)kk * p.ldb + (long)wtap * p.b_tap_stride + n : zsrc;
@@ -189,64 +221,69 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
     }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  if (kt_begin < kt_end) stage(kt_begin, 0);
-  __syncthreads();  // the barrier's release waits vmcnt(0): tile 0 has landed for every wave
-
-  int buf = 0;
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    if (kt + 1 < kt_end) stage(kt + 1, buf ^ 1);  // next tile's DMA flies under this tile's MFMAs
-    const char* At = smem + (buf * 2 + 0) * TILE_BYTES;
-    const char* Bt = smem + (buf * 2 + 1) * TILE_BYTES;
+  // ---- S-deep ring: K-steps t+1 .. t+S-1 are in flight (LDS-DMA) while step t is multiplied ----
+  const int T = kt_end - kt_begin;
+#pragma unroll
+  for (int d = 0; d < S - 1; ++d)
+    if (d < T) stage(kt_begin + d, d);
+  int rd = 0, wr = S - 1;  // ring slots: read slot of step t, write slot of step t+S-1
+  for (int t = 0; t < T; ++t) {
+    // step t has landed once at most the later steps' DMAs of this wave are still outstanding ...
+    if (S == 3 && t + 1 < T) wait_vmcnt<NL>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave has finished reading slot `wr` (step t-1)
+    if (t + S - 1 < T) stage(kt_begin + t + S - 1, wr);
+    const char* At = smem + rd * STAGE_BYTES;
+    const char* Bt = At + A_TILE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bfr[4];
+      bf16x8 af[4], bfr[NJ];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (FORM == GEMM_TN)
-          af[i] = frag_nc(At, ks * 32 + g * 8, wm * 64 + i * 16, l16);
+          af[i] = frag_nc<128>(At, ks * 32 + g * 8, wm * 64 + i * 16, l16);
         else
           af[i] = frag_kc(At, wm * 64 + i * 16 + l16, ks * 4 + g);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         if (FORM == GEMM_NT)
-          bfr[j] = frag_kc(Bt, wn * 64 + j * 16 + l16, ks * 4 + g);
+          bfr[j] = frag_kc(Bt, wn * (BN / 2) + j * 16 + l16, ks * 4 + g);
         else
-          bfr[j] = frag_nc(Bt, ks * 32 + g * 8, wn * 64 + j * 16, l16);
+          bfr[j] = frag_nc<BN>(Bt, ks * 32 + g * 8, wn * (BN / 2) + j * 16, l16);
       }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     }
-    __syncthreads();  // vmcnt(0) + barrier: next tile landed, everyone done reading this one
-    buf ^= 1;
+    rd = rd + 1 == S ? 0 : rd + 1;
+    wr = wr + 1 == S ? 0 : wr + 1;
   }
+  __syncthreads();  // all fragment reads done before the ring is reused as the fp32 staging tile
 
   // ---- epilogue: stage fp32 tile in LDS, then row-contiguous 16-byte stores ----
   float* Cs = (float*)smem;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        Cs[(wm * 64 + i * 16 + g * 4 + r) * LDC + wn * 64 + j * 16 + l16] = acc[i][j][r];
+        Cs[(wm * 64 + i * 16 + g * 4 + r) * LDC + wn * (BN / 2) + j * 16 + l16] = acc[i][j][r];
   __syncthreads();
 
-#pragma unroll
-  for (int v = 0; v < 8; ++v) {
-    int id = v * 256 + tid;
-    int row = id >> 4, col = (id & 15) * 8;
+  constexpr int VPR = BN / 8;                 // 8-column vectors per tile row
+  for (int id = tid; id < BM * VPR; id += 256) {
+    int row = id / VPR, col = (id - row * VPR) * 8;
     int m = m0 + row, n = n0 + col;
     if (m >= p.M || n >= p.N) continue;
     float x[8];
@@ -323,17 +360,44 @@ void gemm_defaults(GemmP* p) {
   p->rows_per_batch = 1;
 }
 
-template <int FORM, bool CONV>
-static int launch_one(const GemmP& p, dim3 grid, hipStream_t st) {
+static constexpr int gemm_smem_bytes(int BN, int S) {
+  int ring = S * (A_TILE_BYTES + BN * 128), stg = BM * (BN + 4) * 4;
+  return ring > stg ? ring : stg;
+}
+
+template <int FORM, bool CONV, int BN, int S>
+static int launch_cfg(const GemmP& p, hipStream_t st) {
   static bool attr_set = false;
+  constexpr int smem = gemm_smem_bytes(BN, S);
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<FORM, CONV>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_SMEM));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<FORM, CONV, BN, S>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<FORM, CONV>), grid, dim3(256), GEMM_SMEM, st, p);
+  dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), FORM == GEMM_TN ? p.taps * p.splitk : 1);
+  hipLaunchKernelGGL((gemm_kernel<FORM, CONV, BN, S>), grid, dim3(256), smem, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
+}
+
+// tile / pipeline selection.  BN = 160 when it divides N (1280, 640, 320, 3840, 5120, 10240, 2560, 1920 ... all do):
+// at B=4, 1024^2 every Linear / conv output then tiles into an exact multiple of 256 workgroups (one per CU).
+// SDXL_GEMM_CFG=<bn><s> (e.g. 1282, 1283, 1603) forces a configuration (benchmarking).
+static int g_force_cfg = -1;
+template <int FORM, bool CONV>
+static int launch_one(const GemmP& p, hipStream_t st) {
+  if (g_force_cfg < 0) {
+    const char* e = getenv("SDXL_GEMM_CFG");
+    g_force_cfg = e ? atoi(e) : 0;
+  }
+  // measured on MI355X (round 1): two co-resident 128x128 workgroups per CU (S = 2, 68 KiB LDS each) beat the
+  // one-per-CU 3-deep rings (128x128 or 128x160, ~100 KiB LDS) on every shape but the K >= 2560 ones in isolation, and
+  // on the whole step even there: a one-per-CU kernel leaves no LDS for the side stream's wgrad workgroups to co-run.
+  int bn = 128, s = 2;
+  if (g_force_cfg) { bn = g_force_cfg / 10; s = g_force_cfg % 10; if (bn == 160 && p.N % 8) bn = 128; }
+  if (bn == 160) return launch_cfg<FORM, CONV, 160, 3>(p, st);
+  if (s == 2) return launch_cfg<FORM, CONV, 128, 2>(p, st);
+  return launch_cfg<FORM, CONV, 128, 3>(p, st);
 }
 
 // ---- optional per-launch timing (bench.py roofline): HIP events on the launch stream around every GEMM launch ----
@@ -406,14 +470,13 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
     ARG_CHECK(p.slab != nullptr, "gemm: split-K needs a slab scratch buffer");
     p.slab_ld = (long)p.N * p.taps;
   }
-  dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), p.form == GEMM_TN ? p.taps * p.splitk : 1);
   const bool conv = p.taps == 9;
   int rc;
   switch (p.form) {
-    case GEMM_NT: return conv ? launch_one<GEMM_NT, true>(p, grid, st) : launch_one<GEMM_NT, false>(p, grid, st);
-    case GEMM_NN: return conv ? launch_one<GEMM_NN, true>(p, grid, st) : launch_one<GEMM_NN, false>(p, grid, st);
+    case GEMM_NT: return conv ? launch_one<GEMM_NT, true>(p, st) : launch_one<GEMM_NT, false>(p, st);
+    case GEMM_NN: return conv ? launch_one<GEMM_NN, true>(p, st) : launch_one<GEMM_NN, false>(p, st);
     case GEMM_TN:
-      rc = conv ? launch_one<GEMM_TN, true>(p, grid, st) : launch_one<GEMM_TN, false>(p, grid, st);
+      rc = conv ? launch_one<GEMM_TN, true>(p, st) : launch_one<GEMM_TN, false>(p, st);
       if (rc == 0 && p.splitk > 1) {
         const int cols = p.N * p.taps;
         long nv = (long)p.M * (cols / 4);

@@ -82,14 +82,15 @@ int launch_groupnorm_fwd(const bf16* x, bf16* y, const bf16* gamma, const bf16* 
                          float* ws, int B, int HW, int C, int G, float eps, int silu,
                          hipStream_t st);
 // dx (+)= ; dgamma/dbeta fp32 += .  ws: same scratch
+// dx = (addend ? addend : 0) + grad   (addend may alias dx; a distinct addend keeps gradient buffers write-once)
 int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const bf16* beta,
-                         const float* stats, bf16* dx, float* dgamma, float* dbeta, float* ws, int B, int HW,
-                         int C, int G, int silu, int accumulate, hipStream_t st);
+                         const float* stats, bf16* dx, const bf16* addend, float* dgamma, float* dbeta, float* ws,
+                         int B, int HW, int C, int G, int silu, hipStream_t st);
 // LayerNorm over rows of [M][C]; stats [M][2] = mean, rstd
 int launch_layernorm_fwd(const bf16* x, bf16* y, const bf16* gamma, const bf16* beta, float* stats, int M,
                          int C, float eps, hipStream_t st);
 int launch_layernorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const float* stats, bf16* dx,
-                         float* dgamma, float* dbeta, int M, int C, int accumulate, hipStream_t st);
+                         const bf16* addend, float* dgamma, float* dbeta, int M, int C, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
 // elementwise / small (elementwise.hip)
@@ -97,14 +98,14 @@ int launch_layernorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const
 int launch_geglu_fwd(const bf16* u, bf16* g, int M, int C4, hipStream_t st);            // u [M][2*C4]
 int launch_geglu_bwd(const bf16* u, const bf16* dg, bf16* du, int M, int C4, hipStream_t st);
 int launch_silu_fwd(const bf16* x, bf16* y, long n, hipStream_t st);
-int launch_silu_bwd(const bf16* x, const bf16* dy, bf16* dx, long n, int accumulate, hipStream_t st);
+int launch_silu_bwd(const bf16* x, const bf16* dy, bf16* dx, const bf16* addend, long n, hipStream_t st);
 int launch_add(const bf16* a, const bf16* b, bf16* o, long n, hipStream_t st);           // o = a + b
 int launch_colsum_f32(const bf16* x, float* out, int M, int N, long ldx, hipStream_t st);  // out[n] += sum_m
 int launch_concat(const bf16* a, int Ca, const bf16* b, int Cb, bf16* o, long rows, hipStream_t st);
-int launch_split_add(const bf16* g, bf16* ga, int Ca, int acc_a, bf16* gb, int Cb, int acc_b, long rows,
-                     hipStream_t st);                                                  // concat backward
+int launch_split_add(const bf16* g, bf16* ga, int Ca, const bf16* add_a, bf16* gb, int Cb, const bf16* add_b,
+                     long rows, hipStream_t st);                                                  // concat backward
 int launch_upsample2x(const bf16* x, bf16* y, int B, int H, int W, int C, hipStream_t st);
-int launch_upsample2x_bwd(const bf16* dy, bf16* dx, int B, int H, int W, int C, int accumulate, hipStream_t st);
+int launch_upsample2x_bwd(const bf16* dy, bf16* dx, const bf16* addend, int B, int H, int W, int C, hipStream_t st);
 // sinusoidal embedding, cos first: out[r][0:half]=cos(t*f_i), out[r][half:]=sin ; out row stride ldo
 int launch_sincos(const float* t, bf16* out, int rows, int dim, long ldo, hipStream_t st);
 int launch_copy_cols(const bf16* src, long lds, bf16* dst, long ldd, int rows, int cols, hipStream_t st);

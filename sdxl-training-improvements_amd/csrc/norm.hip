@@ -291,7 +291,7 @@ template <bool SILU, bool ACC>
 __global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                     const bf16* __restrict__ gamma, const bf16* __restrict__ beta,
                                     const float* __restrict__ stats, const float* __restrict__ coef,
-                                    bf16* __restrict__ dx, int HW, int C, int G, int vpr, int rpi,
+                                    bf16* dx, const bf16* addend, int HW, int C, int G, int vpr, int rpi,
                                     int rows_per_chunk) {
   const int b = blockIdx.y;
   const int vec = threadIdx.x % vpr, rsub = threadIdx.x / vpr;
@@ -310,13 +310,14 @@ __global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __re
   const bf16* xb = x + (long)b * HW * C;
   const bf16* db = dy + (long)b * HW * C;
   bf16* ob = dx + (long)b * HW * C;
+  const bf16* ab = addend + (long)b * HW * C;
   const int r0 = blockIdx.x * rows_per_chunk;
   const int r1 = min(HW, r0 + rows_per_chunk);
   for (int r = r0 + rsub; r < r1; r += rpi) {
     bf16x8 v = *(const bf16x8*)(xb + (long)r * C + vec * 8);
     bf16x8 d = *(const bf16x8*)(db + (long)r * C + vec * 8);
     bf16x8 o;
-    if (ACC) o = *(const bf16x8*)(ob + (long)r * C + vec * 8);
+    if (ACC) o = *(const bf16x8*)(ab + (long)r * C + vec * 8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float xv = (float)v[e];
@@ -331,8 +332,9 @@ __global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __re
 }
 
 int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const bf16* beta, const float* stats,
-                         bf16* dx, float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int G, int silu,
-                         int accumulate, hipStream_t st) {
+                         bf16* dx, const bf16* addend, float* dgamma, float* dbeta, float* ws, int B, int HW, int C,
+                         int G, int silu, hipStream_t st) {
+  const int accumulate = addend != nullptr;
   ARG_CHECK(C % 8 == 0 && C % G == 0 && G <= 64, "groupnorm bwd: C=%d G=%d unsupported", C, G);
   GnGeom g = gn_geom(HW, C);
   float* part = ws;                                      // [chunks][B][C][2]
@@ -350,7 +352,7 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const
                      gamma, stats, coef, dgamma, dbeta, HW, C, G);
 #define GN_BWD_APPLY(S, A)                                                                                          \
   hipLaunchKernelGGL((gn_bwd_apply_kernel<S, A>), dim3(g.chunks, B), dim3(g.threads), 0, st, x, dy, gamma, beta, stats, \
-                     coef, dx, HW, C, G, g.vpr, g.rpi, g.rows_per_chunk)
+                     coef, dx, addend, HW, C, G, g.vpr, g.rpi, g.rows_per_chunk)
   if (silu) { if (accumulate) GN_BWD_APPLY(true, true); else GN_BWD_APPLY(true, false); }
   else      { if (accumulate) GN_BWD_APPLY(false, true); else GN_BWD_APPLY(false, false); }
 #undef GN_BWD_APPLY
@@ -419,7 +421,7 @@ int launch_layernorm_fwd(const bf16* x, bf16* y, const bf16* gamma, const bf16* 
 template <int NV, bool ACC>
 __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                  const bf16* __restrict__ gamma, const float* __restrict__ stats,
-                                 bf16* __restrict__ dx, int M) {
+                                 bf16* dx, const bf16* addend, int M) {
   constexpr int C = NV * 128;
   const int sub = threadIdx.x & 15;
   const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16* __restrict__
   for (int i = 0; i < NV; ++i) {
     bf16x8 gv = *(const bf16x8*)(gamma + (i * 16 + sub) * 8);
     bf16x8 o;
-    if (ACC) o = *(const bf16x8*)(dx + (long)row * C + (i * 16 + sub) * 8);
+    if (ACC) o = *(const bf16x8*)(addend + (long)row * C + (i * 16 + sub) * 8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float h = ((float)v[i][e] - mean) * rstd;
@@ -515,14 +517,15 @@ static void col_reduce_geom(int M, int C, dim3* grid, int* rows_per_chunk) {
 }
 
 int launch_layernorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const float* stats, bf16* dx,
-                         float* dgamma, float* dbeta, int M, int C, int accumulate, hipStream_t st) {
+                         const bf16* addend, float* dgamma, float* dbeta, int M, int C, hipStream_t st) {
   ARG_CHECK(C % 128 == 0, "layernorm bwd: C=%d must be a multiple of 128", C);
+  const int accumulate = addend != nullptr;
   dim3 grid(cdiv(M, 16)), blk(256);
   switch (C / 128) {
 #define LN_CASE(NV)                                                                                            \
   case NV:                                                                                                     \
-    if (accumulate) hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, true>), grid, blk, 0, st, x, dy, gamma, stats, dx, M); \
-    else hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, false>), grid, blk, 0, st, x, dy, gamma, stats, dx, M);         \
+    if (accumulate) hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, true>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, M); \
+    else hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, false>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, M);         \
     break;
     LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(8) LN_CASE(10)
 #undef LN_CASE
