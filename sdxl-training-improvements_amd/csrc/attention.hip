@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       float mnew = fmaxf(mrow[qb], mx);
-      float alpha = exp2f((mrow[qb] - mnew) * c);
+      float alpha = __builtin_amdgcn_exp2f((mrow[qb] - mnew) * c);
       mrow[qb] = mnew;
       float ls = 0.f;
       float mc = mnew * c;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float e = exp2f(st[kb][qb][r] * c - mc);
+          float e = __builtin_amdgcn_exp2f(st[kb][qb][r] * c - mc);
           st[kb][qb][r] = e;
           ls += e;
         }
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           int key = t * 64 + kb * 16 + g * 4 + r;
-          float pr = key < p.Nk ? exp2f(st[kb][qb][r] * c - lse2[qb]) : 0.f;
+          float pr = key < p.Nk ? __builtin_amdgcn_exp2f(st[kb][qb][r] * c - lse2[qb]) : 0.f;
           st[kb][qb][r] = pr * (dp[kb][qb][r] - delta[qb]) * SCALE;
         }
       dsf[0][qb] = pack8(st[0][qb], st[1][qb]);
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int q = t * 64 + qb * 16 + g * 4 + r;
-        float e = (q < p.Nq && kok) ? exp2f(s[qb][r] * c - l2[r]) : 0.f;
+        float e = (q < p.Nq && kok) ? __builtin_amdgcn_exp2f(s[qb][r] * c - l2[r]) : 0.f;
         pr[qb][r] = e;
         s[qb][r] = e * (dp[qb][r] - dl[r]) * SCALE;
       }

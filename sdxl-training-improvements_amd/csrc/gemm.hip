@@ -19,8 +19,6 @@
 #include <stdlib.h>
 
 #define BM 128
-#define BK 64
-#define A_TILE_BYTES 16384  // [128 rows][64 k] or [64 k][128 cols] bf16, swizzled, no padding
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef __attribute__((address_space(3))) void lds_void;
@@ -54,8 +52,17 @@ __device__ __forceinline__ int nc_logical(int k, int pv) {  // inverse of nc_phy
   return q < 0 ? q + 20 : q;
 }
 
+// K-contiguous tile [R][BKT]: BKT = 64 -> 128-B rows, 8 vectors: slot = kv ^ (r & 7)
+//                             BKT = 32 ->  64-B rows, 4 vectors: slot = kv ^ P[(r >> 2) & 3], P = {0,2,3,1}
+// (both conflict-free for the ds_read_b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31})
+template <int BKT>
+__device__ __forceinline__ int kc_swz(int r) {
+  if (BKT == 64) return r & 7;
+  return (0x78 >> (((r >> 2) & 3) * 2)) & 3;  // 0b01_11_10_00 -> {0,2,3,1}
+}
+template <int BKT>
 __device__ __forceinline__ bf16x8 frag_kc(const char* tile, int r, int kv) {
-  return *(const bf16x8*)(tile + r * 128 + ((kv ^ (r & 7)) << 4));
+  return *(const bf16x8*)(tile + r * (BKT * 2) + ((kv ^ kc_swz<BKT>(r)) << 4));
 }
 // 8 k-rows starting at kb (multiple of 8), 16 columns starting at col0 (multiple of 16): lane i of each 16-lane
 // group supplies the address of 4 contiguous bf16 of row (i>>2), columns 4*(i&3).., and receives column i.
@@ -106,14 +113,18 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// FORM / CONV as above; BN = 128 or 160 output columns per workgroup; S = LDS ring depth (S-1 K-steps of DMA in flight)
-template <int FORM, bool CONV, int BN, int S>
-__global__ __launch_bounds__(256, (S == 2 ? 2 : 1)) void gemm_kernel(const GemmP p) {
-  constexpr int B_TILE_BYTES = BN * 128;                    // [BN][64] or [64][BN] bf16
+// FORM / CONV as above; BN = 128 or 160 output columns per workgroup; S = LDS ring depth (S-1 K-steps of DMA in
+// flight); BK = 64 or 32 reduction elements per K-step (BK = 32: 34 KiB of LDS -> 3-4 workgroups per CU)
+template <int FORM, bool CONV, int BN, int S, int BK>
+__global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_kernel(const GemmP p) {
+  constexpr int A_TILE_BYTES = BM * BK * 2;                 // [128][BK] or [BK][128] bf16
+  constexpr int B_TILE_BYTES = BN * BK * 2;                 // [BN][BK] or [BK][BN] bf16
   constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
   constexpr int NJ = BN / 32;                               // B fragments per wave (wave tile 64 x BN/2)
-  constexpr int BCH = BN / 32;                              // 1 KiB B chunks per wave per K-step
-  constexpr int NL = 4 + BCH;                               // LDS-DMA instructions per wave per K-step
+  constexpr int ACH = A_TILE_BYTES / 4096;                  // 1 KiB A chunks per wave per K-step
+  constexpr int BCH = B_TILE_BYTES / 4096;                  // 1 KiB B chunks per wave per K-step
+  constexpr int NL = ACH + BCH;                             // LDS-DMA instructions per wave per K-step
+  constexpr int VR = BK / 8;                                // vectors per K-contiguous row
   constexpr int LDC = BN + 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -143,11 +154,12 @@ __global__ __launch_bounds__(256, (S == 2 ? 2 : 1)) void gemm_kernel(const GemmP
   // ---- per-lane LDS-DMA descriptors ----
   // K-contiguous tile: chunk c = rows 8c..8c+7 ; lane -> row 8c + (lane>>3), physical vector lane&7
   // N-contiguous tile of width Wd: chunk c = vectors 64c..64c+63 of the [64][Wd/8] vector grid
-  const int kc_rowl = lane >> 3, kc_pv = lane & 7;
-  PixRow arow[4];
+  const int kc_rowl = lane / VR, kc_pv = lane % VR;
+  constexpr int KC_ROWS = 64 / VR;  // rows of a K-contiguous tile per 1 KiB chunk
+  PixRow arow[ACH];
   if (CONV && FORM != GEMM_TN) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) arow[j] = decode_pix(m0 + (wave * 4 + j) * 8 + kc_rowl, p.M, p.Hm, p.Wm);
+    for (int j = 0; j < ACH; ++j) arow[j] = decode_pix(m0 + (wave * ACH + j) * KC_ROWS + kc_rowl, p.M, p.Hm, p.Wm);
   }
   const bf16* zsrc = (const bf16*)g_zero16;
 
@@ -163,10 +175,10 @@ __global__ __launch_bounds__(256, (S == 2 ? 2 : 1)) void gemm_kernel(const GemmP
     const int dy = tap / 3, dx = tap - dy * 3;
     char* At = smem + buf * STAGE_BYTES;
     char* Bt = At + A_TILE_BYTES;
-    // ---------------- A : 4 chunks per wave ----------------
+    // ---------------- A : ACH chunks per wave ----------------
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = wave * 4 + j;
+    for (int j = 0; j < ACH; ++j) {
+      const int c = wave * ACH + j;
       const bf16* src;
       if (FORM == GEMM_TN) {
         const int krow = c * 4 + (lane >> 4);
@@ -174,8 +186,8 @@ __global__ __launch_bounds__(256, (S == 2 ? 2 : 1)) void gemm_kernel(const GemmP
         const int m = m0 + (nc_logical<128>(krow, lane & 15) << 3);
         src = (kk < p.K && m < p.M) ? p.A + (long)kk * p.lda + m : zsrc;
       } else {
-        const int row = c * 8 + kc_rowl;
-        const int kofs = c0 + ((kc_pv ^ (row & 7)) << 3);
+        const int row = c * KC_ROWS + kc_rowl;
+        const int kofs = c0 + ((kc_pv ^ kc_swz<BK>(row)) << 3);
         if (CONV) {
           long s = gather_src(arow[j], dy, dx, p);
           src = (s >= 0 && kofs < p.K) ? p.A + s * p.lda + kofs : zsrc;
@@ -193,9 +205,9 @@ __global__ __launch_bounds__(256, (S == 2 ? 2 : 1)) void gemm_kernel(const GemmP
       const bf16* src;
       if (FORM == GEMM_NT) {
         const int wtap = p.flip ? (p.taps - 1 - tap) : tap;
-        const int row = c * 8 + kc_rowl;
+        const int row = c * KC_ROWS + kc_rowl;
         const int n = n0 + row;
-        const int kofs = c0 + ((kc_pv ^ (row & 7)) << 3);
+        const int kofs = c0 + ((kc_pv ^ kc_swz<BK>(row)) << 3);
         src = (n < p.N && kofs < p.K) ? p.B + (long)n * p.ldb + (long)wtap * p.b_tap_stride + kofs : zsrc;
       } else {
         constexpr int V = BN / 8;
@@ -241,19 +253,19 @@ __global__ __launch_bounds__(256, (S == 2 ? 2 : 1)) void gemm_kernel(const GemmP
     const char* At = smem + rd * STAGE_BYTES;
     const char* Bt = At + A_TILE_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BK / 32; ++ks) {
       bf16x8 af[4], bfr[NJ];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (FORM == GEMM_TN)
           af[i] = frag_nc<128>(At, ks * 32 + g * 8, wm * 64 + i * 16, l16);
         else
-          af[i] = frag_kc(At, wm * 64 + i * 16 + l16, ks * 4 + g);
+          af[i] = frag_kc<BK>(At, wm * 64 + i * 16 + l16, ks * 4 + g);
       }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         if (FORM == GEMM_NT)
-          bfr[j] = frag_kc(Bt, wn * (BN / 2) + j * 16 + l16, ks * 4 + g);
+          bfr[j] = frag_kc<BK>(Bt, wn * (BN / 2) + j * 16 + l16, ks * 4 + g);
         else
           bfr[j] = frag_nc<BN>(Bt, ks * 32 + g * 8, wn * (BN / 2) + j * 16, l16);
       }
@@ -270,21 +282,24 @@ __global__ __launch_bounds__(256, (S == 2 ? 2 : 1)) void gemm_kernel(const GemmP
   }
   __syncthreads();  // all fragment reads done before the ring is reused as the fp32 staging tile
 
-  // ---- epilogue: stage fp32 tile in LDS, then row-contiguous 16-byte stores ----
+  // ---- epilogue: stage the fp32 tile in LDS 64 rows at a time (34 KiB), then row-contiguous 16-byte stores ----
   float* Cs = (float*)smem;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        Cs[(wm * 64 + i * 16 + g * 4 + r) * LDC + wn * (BN / 2) + j * 16 + l16] = acc[i][j][r];
-  __syncthreads();
-
   constexpr int VPR = BN / 8;                 // 8-column vectors per tile row
-  for (int id = tid; id < BM * VPR; id += 256) {
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            Cs[(i * 16 + g * 4 + r) * LDC + wn * (BN / 2) + j * 16 + l16] = acc[i][j][r];
+    }
+    __syncthreads();
+  for (int id = tid; id < 64 * VPR; id += 256) {
     int row = id / VPR, col = (id - row * VPR) * 8;
-    int m = m0 + row, n = n0 + col;
+    int m = m0 + half * 64 + row, n = n0 + col;
     if (m >= p.M || n >= p.N) continue;
     float x[8];
     {
@@ -331,6 +346,8 @@ __global__ __launch_bounds__(256, (S == 2 ? 2 : 1)) void gemm_kernel(const GemmP
       *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + n) = o;
     }
   }
+    __syncthreads();
+  }
 }
 
 // C[m][0..cols) (+)= sum_s slab[s][m][0..cols)   (fixed summation order)
@@ -360,22 +377,22 @@ void gemm_defaults(GemmP* p) {
   p->rows_per_batch = 1;
 }
 
-static constexpr int gemm_smem_bytes(int BN, int S) {
-  int ring = S * (A_TILE_BYTES + BN * 128), stg = BM * (BN + 4) * 4;
+static constexpr int gemm_smem_bytes(int BN, int S, int BK) {
+  int ring = S * (BM + BN) * BK * 2, stg = 64 * (BN + 4) * 4;
   return ring > stg ? ring : stg;
 }
 
-template <int FORM, bool CONV, int BN, int S>
+template <int FORM, bool CONV, int BN, int S, int BK>
 static int launch_cfg(const GemmP& p, hipStream_t st) {
   static bool attr_set = false;
-  constexpr int smem = gemm_smem_bytes(BN, S);
+  constexpr int smem = gemm_smem_bytes(BN, S, BK);
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<FORM, CONV, BN, S>,
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<FORM, CONV, BN, S, BK>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
   dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), FORM == GEMM_TN ? p.taps * p.splitk : 1);
-  hipLaunchKernelGGL((gemm_kernel<FORM, CONV, BN, S>), grid, dim3(256), smem, st, p);
+  hipLaunchKernelGGL((gemm_kernel<FORM, CONV, BN, S, BK>), grid, dim3(256), smem, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -394,10 +411,18 @@ static int launch_one(const GemmP& p, hipStream_t st) {
   // one-per-CU 3-deep rings (128x128 or 128x160, ~100 KiB LDS) on every shape but the K >= 2560 ones in isolation, and
   // on the whole step even there: a one-per-CU kernel leaves no LDS for the side stream's wgrad workgroups to co-run.
   int bn = 128, s = 2;
+  // the transpose-read forms (dgrad / wgrad) spend twice the LDS-read issue slots per K-step: when the grid is large
+  // enough to actually keep 3-4 workgroups resident per CU, the BK = 32 variant (34 KiB LDS) hides that better
+  // (measured +13..30 % on those shapes, -15..25 % on grids of <= 320 workgroups).
+  {
+    const long blocks = (long)cdiv(p.M, BM) * cdiv(p.N, 128) * (FORM == GEMM_TN ? p.taps * p.splitk : 1);
+    if (FORM != GEMM_NT && blocks >= 700) bn = 32;
+  }
   if (g_force_cfg) { bn = g_force_cfg / 10; s = g_force_cfg % 10; if (bn == 160 && p.N % 8) bn = 128; }
-  if (bn == 160) return launch_cfg<FORM, CONV, 160, 3>(p, st);
-  if (s == 2) return launch_cfg<FORM, CONV, 128, 2>(p, st);
-  return launch_cfg<FORM, CONV, 128, 3>(p, st);
+  if (bn == 160) return launch_cfg<FORM, CONV, 160, 3, 64>(p, st);
+  if (bn == 32) return launch_cfg<FORM, CONV, 128, 2, 32>(p, st);   // SDXL_GEMM_CFG=322: BK = 32, 3-4 workgroups per CU
+  if (s == 2) return launch_cfg<FORM, CONV, 128, 2, 64>(p, st);
+  return launch_cfg<FORM, CONV, 128, 3, 64>(p, st);
 }
 
 // ---- optional per-launch timing (bench.py roofline): HIP events on the launch stream around every GEMM launch ----
