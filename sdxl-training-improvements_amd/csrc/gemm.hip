@@ -115,7 +115,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // FORM / CONV as above; BN = 128 or 160 output columns per workgroup; S = LDS ring depth (S-1 K-steps of DMA in
 // flight); BK = 64 or 32 reduction elements per K-step (BK = 32: 34 KiB of LDS -> 3-4 workgroups per CU)
-template <int FORM, bool CONV, int BN, int S, int BK>
+// FAST (non-conv, reduction length a multiple of BK): every lane's DMA source is a running pointer advanced by a
+// per-lane constant each K-step (0 for out-of-range rows, which keep pointing at the zero vector) -- two VALU adds
+// per load instead of the general path's predicates, 64-bit multiplies and tap arithmetic.
+template <int FORM, bool CONV, int BN, int S, int BK, bool FAST>
 __global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_kernel(const GemmP p) {
   constexpr int A_TILE_BYTES = BM * BK * 2;                 // [128][BK] or [BK][128] bf16
   constexpr int B_TILE_BYTES = BN * BK * 2;                 // [BN][BK] or [BK][BN] bf16
@@ -132,8 +135,34 @@ __global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_k
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int l16 = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * BN;
-  const int m0 = blockIdx.y * BM;
+  // XCD-aware tile order: hardware workgroup id i runs on XCD i % 8 (observed; used for speed only).  The 8 XCDs are
+  // laid out as a px x py grid over the (n, m) tile grid (chosen by the launcher to minimise the A-panel + B-panel
+  // footprint per XCD) so that each private 4 MiB L2 sees a compact rectangle of output tiles; inside a rectangle
+  // tiles go n-fastest in strips of 8 columns.  Falls back to the identity when the grid does not divide.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (p.xcd_px > 0 && gridDim.x % p.xcd_px == 0 && gridDim.y % (8 / p.xcd_px) == 0) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int px = p.xcd_px, py = 8 / px;
+    const int tn = gx / px, tm = gy / py;            // tiles per XCD rectangle (exact: checked by the launcher)
+    const int id = blockIdx.y * gx + blockIdx.x;
+    const int xcd = id & 7, li = id >> 3;            // li in [0, tn*tm)
+    const int sw = tn < 8 ? tn : 8;                  // strip width
+    const int full = (tn / sw) * sw * tm;            // tiles covered by full strips
+    int ln, lm;
+    if (li < full) {
+      const int strip = li / (sw * tm), w = li - strip * (sw * tm);
+      lm = w / sw;
+      ln = strip * sw + (w - lm * sw);
+    } else {                                         // ragged last strip
+      const int rw = tn - (tn / sw) * sw, w = li - full;
+      lm = w / rw;
+      ln = (tn / sw) * sw + (w - lm * rw);
+    }
+    bx = (xcd % px) * tn + ln;
+    by = (xcd / px) * tm + lm;
+  }
+  const int n0 = bx * BN;
+  const int m0 = by * BM;
 
   // reduction schedule
   int tap_fixed = 0, split = 0;
@@ -163,7 +192,64 @@ __global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_k
   }
   const bf16* zsrc = (const bf16*)g_zero16;
 
-  auto stage = [&](int kt, int buf) {
+  // FAST path state: running source pointers + per-lane step (elements) for this wave's chunks
+  const bf16* pa[ACH];
+  const bf16* pb[BCH];
+  long sa[ACH], sb[BCH];
+  if (FAST) {
+#pragma unroll
+    for (int j = 0; j < ACH; ++j) {
+      const int c = wave * ACH + j;
+      if (FORM == GEMM_TN) {
+        const int krow = c * 4 + (lane >> 4);
+        const int m = m0 + (nc_logical<128>(krow, lane & 15) << 3);
+        const bool ok = m < p.M;
+        pa[j] = ok ? p.A + ((long)kt_begin * BK + krow) * p.lda + m : zsrc;
+        sa[j] = ok ? (long)BK * p.lda : 0;
+      } else {
+        const int row = c * KC_ROWS + kc_rowl;
+        const int m = m0 + row;
+        const bool ok = m < p.M;
+        pa[j] = ok ? p.A + (long)m * p.lda + ((kc_pv ^ kc_swz<BK>(row)) << 3) : zsrc;
+        sa[j] = ok ? BK : 0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BCH; ++j) {
+      const int c = wave * BCH + j;
+      if (FORM == GEMM_NT) {
+        const int row = c * KC_ROWS + kc_rowl;
+        const int n = n0 + row;
+        const bool ok = n < p.N;
+        pb[j] = ok ? p.B + (long)n * p.ldb + ((kc_pv ^ kc_swz<BK>(row)) << 3) : zsrc;
+        sb[j] = ok ? BK : 0;
+      } else {
+        constexpr int V = BN / 8;
+        const int q = c * 64 + lane;
+        const int krow = q / V, pv = q - krow * V;
+        const int n = n0 + (nc_logical<BN>(krow, pv) << 3);
+        const bool ok = n < p.N;
+        pb[j] = ok ? p.B + ((long)kt_begin * BK + krow) * p.ldb + n : zsrc;
+        sb[j] = ok ? (long)BK * p.ldb : 0;
+      }
+    }
+  }
+  auto stage_fast = [&](int buf) {
+    char* At = smem + buf * STAGE_BYTES;
+    char* Bt = At + A_TILE_BYTES;
+#pragma unroll
+    for (int j = 0; j < ACH; ++j) {
+      __builtin_amdgcn_global_load_lds((gbl_void*)pa[j], (lds_void*)(At + (wave * ACH + j) * 1024), 16, 0, 0);
+      pa[j] += sa[j];
+    }
+#pragma unroll
+    for (int j = 0; j < BCH; ++j) {
+      __builtin_amdgcn_global_load_lds((gbl_void*)pb[j], (lds_void*)(Bt + (wave * BCH + j) * 1024), 16, 0, 0);
+      pb[j] += sb[j];
+    }
+  };
+
+  auto stage_gen = [&](int kt, int buf) {
     int tap = 0, c0;
     if (FORM == GEMM_TN) {
       tap = tap_fixed;
@@ -238,6 +324,10 @@ __global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_k
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int kt, int buf) {
+    if (FAST) stage_fast(buf); else stage_gen(kt, buf);   // FAST: steps are always staged in increasing order
+  };
 
   // ---- S-deep ring: K-steps t+1 .. t+S-1 are in flight (LDS-DMA) while step t is multiplied ----
   const int T = kt_end - kt_begin;
@@ -382,19 +472,24 @@ static constexpr int gemm_smem_bytes(int BN, int S, int BK) {
   return ring > stg ? ring : stg;
 }
 
-template <int FORM, bool CONV, int BN, int S, int BK>
-static int launch_cfg(const GemmP& p, hipStream_t st) {
+template <int FORM, bool CONV, int BN, int S, int BK, bool FAST>
+static int launch_k(const GemmP& p, hipStream_t st) {
   static bool attr_set = false;
   constexpr int smem = gemm_smem_bytes(BN, S, BK);
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<FORM, CONV, BN, S, BK>,
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<FORM, CONV, BN, S, BK, FAST>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
   dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), FORM == GEMM_TN ? p.taps * p.splitk : 1);
-  hipLaunchKernelGGL((gemm_kernel<FORM, CONV, BN, S, BK>), grid, dim3(256), smem, st, p);
+  hipLaunchKernelGGL((gemm_kernel<FORM, CONV, BN, S, BK, FAST>), grid, dim3(256), smem, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
+}
+template <int FORM, bool CONV, int BN, int S, int BK>
+static int launch_cfg(const GemmP& p, hipStream_t st) {
+  if (!CONV && p.K % BK == 0 && !getenv("SDXL_GEMM_NOFAST")) return launch_k<FORM, false, BN, S, BK, true>(p, st);
+  return launch_k<FORM, CONV, BN, S, BK, false>(p, st);
 }
 
 // tile / pipeline selection.  BN = 160 when it divides N (1280, 640, 320, 3840, 5120, 10240, 2560, 1920 ... all do):
@@ -490,6 +585,21 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
     if (p.accumulate) { p.resid = (const bf16*)p.C; p.ldr = p.ldc; }
   }
   if (p.splitk < 1) p.splitk = 1;
+  {
+    static int xs = -1;
+    if (xs < 0) { const char* e = getenv("SDXL_GEMM_XCD"); xs = e ? atoi(e) : 1; }
+    p.xcd_px = 0;
+    if (xs) {   // px x (8/px) XCD grid over (n, m) tiles minimising per-XCD operand footprint ~ N/px + M/py
+      const int gx = cdiv(p.N, 128), gy = cdiv(p.M, BM);
+      double best = 1e30;
+      for (int px = 1; px <= 8; px *= 2) {
+        const int py = 8 / px;
+        if (gx % px || gy % py) continue;
+        double cost = (double)p.N / px + (double)p.M / py;
+        if (cost < best) { best = cost; p.xcd_px = px; }
+      }
+    }
+  }
   if (p.splitk > 1) {
     ARG_CHECK(p.form == GEMM_TN, "gemm: split-K only for the TN (wgrad) form");
     ARG_CHECK(p.slab != nullptr, "gemm: split-K needs a slab scratch buffer");

@@ -43,6 +43,7 @@ struct GemmP {
   int splitk;
   float* slab;     // splitk * M * N * taps floats
   long slab_ld;    // set by the launcher
+  int xcd_px;      // set by the launcher: XCD grid width over n-tiles (0 = identity order; SDXL_GEMM_XCD=0 disables)
 };
 size_t gemm_slab_floats(int M, int N, int taps, int splitk);
 void gemm_defaults(GemmP* p);
