@@ -249,6 +249,28 @@ __global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_k
     }
   };
 
+  // FAST path, interleaved form: DMA piece `pc` (A chunks first, then B chunks) of the step being staged into ring
+  // slot `buf`; `live` = false re-targets the load at the zero vector (branch-free tail).  One piece is issued
+  // after every group of 4 MFMAs so its ~60-180 cycle issue cost hides under the matrix pipe instead of in front of it.
+  auto issue_piece = [&](int pc, int buf, bool live) {
+    char* At = smem + buf * STAGE_BYTES;
+    char* Bt = At + A_TILE_BYTES;
+#pragma unroll
+    for (int j = 0; j < ACH; ++j)
+      if (pc == j) {
+        const bf16* src = live ? pa[j] : zsrc;
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(At + (wave * ACH + j) * 1024), 16, 0, 0);
+        pa[j] += sa[j];
+      }
+#pragma unroll
+    for (int j = 0; j < BCH; ++j)
+      if (pc == ACH + j) {
+        const bf16* src = live ? pb[j] : zsrc;
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(Bt + (wave * BCH + j) * 1024), 16, 0, 0);
+        pb[j] += sb[j];
+      }
+  };
+
   auto stage_gen = [&](int kt, int buf) {
     int tap = 0, c0;
     if (FORM == GEMM_TN) {
@@ -328,6 +350,7 @@ __global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_k
   auto stage = [&](int kt, int buf) {
     if (FAST) stage_fast(buf); else stage_gen(kt, buf);   // FAST: steps are always staged in increasing order
   };
+  (void)stage_fast;
 
   // ---- S-deep ring: K-steps t+1 .. t+S-1 are in flight (LDS-DMA) while step t is multiplied ----
   const int T = kt_end - kt_begin;
@@ -339,7 +362,8 @@ __global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_k
     // step t has landed once at most the later steps' DMAs of this wave are still outstanding ...
     if (S == 3 && t + 1 < T) wait_vmcnt<NL>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave has finished reading slot `wr` (step t-1)
-    if (t + S - 1 < T) stage(kt_begin + t + S - 1, wr);
+    const bool live = t + S - 1 < T;
+    if (!FAST && live) stage(kt_begin + t + S - 1, wr);
     const char* At = smem + rd * STAGE_BYTES;
     const char* Bt = At + A_TILE_BYTES;
 #pragma unroll
@@ -359,13 +383,21 @@ __global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_k
         else
           bfr[j] = frag_nc<BN>(Bt, ks * 32 + g * 8, wn * (BN / 2) + j * 16, l16);
       }
-      __builtin_amdgcn_s_setprio(1);
+      if (!FAST) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+        if (FAST) {
+          constexpr int NSLOT = (BK / 32) * 4;
+          const int slot = ks * 4 + i;
+#pragma unroll
+          for (int pc = 0; pc < NL; ++pc)
+            if (pc % NSLOT == slot) issue_piece(pc, wr, live);
+        }
+      }
+      if (!FAST) __builtin_amdgcn_s_setprio(0);
     }
     rd = rd + 1 == S ? 0 : rd + 1;
     wr = wr + 1 == S ? 0 : wr + 1;
