@@ -85,7 +85,9 @@ int sdxl_plan(sdxl_handle* h, int B, int H, int W, int ctx_len, size_t* workspac
 int sdxl_bind_workspace(sdxl_handle* h, void* ws_dev, size_t bytes);   /* NULL = library allocates */
 
 /* ---- the step (replaces compute_loss()/training_step() + loss.backward()) -------------------------------------- */
-/* grads = 0 for the parameters that accumulate atomically; the rest are overwritten by the first micro-step */
+/* start of an accumulation cycle: zeroes the bias / norm gradient vectors (accumulated with atomics); the weight-matrix
+ * gradients are NOT touched -- the first micro-step (first_micro != 0) overwrites them.  A cycle must therefore start
+ * with first_micro = 1. */
 int sdxl_zero_grads(sdxl_handle* h, void* stream);
 /* loss preparation + UNet forward + loss.  Leaves loss/metrics on device. */
 int sdxl_forward_loss(sdxl_handle* h, const sdxl_loss_config* lc, const sdxl_batch* b, void* stream);

@@ -64,6 +64,7 @@ int sdxl_create(const sdxl_unet_config* cfg, int device, sdxl_handle** out) {
   if (h->e.use_side) {
     HIP_CHECK_RET(hipStreamCreateWithFlags(&h->e.side, hipStreamNonBlocking));
     HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_join, hipEventDisableTiming));
+    HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_hoist, hipEventDisableTiming));
   }
   *out = h;
   return 0;
@@ -76,7 +77,9 @@ int sdxl_destroy(sdxl_handle* h) {
   if (h->e.own_ws && h->e.ws) (void)hipFree(h->e.ws);
   for (hipEvent_t ev : h->e.ev_pool) (void)hipEventDestroy(ev);
   if (h->e.ev_join) (void)hipEventDestroy(h->e.ev_join);
+  if (h->e.ev_hoist) (void)hipEventDestroy(h->e.ev_hoist);
   if (h->e.side) (void)hipStreamDestroy(h->e.side);
+  if (h->e.small_ranges_dev) (void)hipFree(h->e.small_ranges_dev);
   delete h;
   return 0;
 }
@@ -182,10 +185,26 @@ static int ready(Engine& e) {
   return 0;
 }
 
+// zero the gradient ranges that are accumulated with atomics (bias / norm vectors: ~2.6 M of the 2.57 G elements);
+// the weight matrices are overwritten by the first micro-step's wgrad GEMMs (first_micro) and need no zeroing
+__global__ void zero_ranges_kernel(float* __restrict__ g, const unsigned long long* __restrict__ ranges) {
+  const unsigned long long off = ranges[2 * blockIdx.x], n = ranges[2 * blockIdx.x + 1];
+  for (unsigned long long i = threadIdx.x; i < n; i += blockDim.x) g[off + i] = 0.f;
+}
+
 int sdxl_zero_grads(sdxl_handle* h, void* st) {
   H_CHECK(h);
-  ARG_CHECK(h->e.grads, "grads are not bound");
-  HIP_CHECK_RET(hipMemsetAsync(h->e.grads, 0, h->e.param_elems * sizeof(float), (hipStream_t)st));
+  Engine& e = h->e;
+  ARG_CHECK(e.grads, "grads are not bound");
+  if (!e.small_ranges_dev) {
+    std::vector<unsigned long long> flat;
+    for (auto& r : e.small_ranges) { flat.push_back(r.first); flat.push_back(r.second); }
+    HIP_CHECK_RET(hipMalloc((void**)&e.small_ranges_dev, flat.size() * sizeof(unsigned long long)));
+    HIP_CHECK_RET(hipMemcpy(e.small_ranges_dev, flat.data(), flat.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+  }
+  hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)e.small_ranges.size()), dim3(256), 0, (hipStream_t)st, e.grads,
+                     e.small_ranges_dev);
+  HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
 
@@ -226,7 +245,22 @@ static void fill_loss(Engine& e, const sdxl_loss_config* lc, const sdxl_batch* b
 
 static int run_forward_ops(Engine& e, hipStream_t st) {
   Plan& p = *e.cur;
-  for (auto& op : p.ops) CHK(op->fwd(p, st));
+  const bool side = e.use_side && e.side && !gemm_profiling();
+  if (side) {   // hoisted ops (inputs-only dependencies) run on the side stream, concurrently with the first layers
+    HIP_CHECK_RET(hipEventRecord(e.ev_hoist, st));
+    HIP_CHECK_RET(hipStreamWaitEvent(e.side, e.ev_hoist, 0));
+    for (auto& op : p.ops) if (op->hoist_fwd) CHK(op->fwd(p, e.side));
+    HIP_CHECK_RET(hipEventRecord(e.ev_hoist, e.side));
+  }
+  bool waited = false;
+  for (auto& op : p.ops) {
+    if (side && op->hoist_fwd) continue;
+    if (side && op->needs_hoisted && !waited) {
+      HIP_CHECK_RET(hipStreamWaitEvent(st, e.ev_hoist, 0));
+      waited = true;
+    }
+    CHK(op->fwd(p, st));
+  }
   return 0;
 }
 

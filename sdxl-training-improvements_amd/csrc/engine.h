@@ -46,6 +46,9 @@ struct Plan;
 
 struct Op {
   int seg = 0;
+  bool hoist_fwd = false;   // forward depends on the inputs only (cross-attention K/V projections of the prompt
+                            // embeddings): launched on the side stream at the start of the forward
+  bool needs_hoisted = false;  // consumes a hoisted op's output: main stream waits for the side stream first
   virtual ~Op() {}
   virtual int fwd(Plan& p, hipStream_t st) = 0;
   virtual void plan_bwd(Plan& p) = 0;
@@ -106,7 +109,7 @@ struct Engine {
   bool own_ws = false;
   // backward concurrency: weight-gradient GEMMs (and bias column sums) run on a side stream, off the dgrad chain
   hipStream_t side = nullptr;
-  hipEvent_t ev_join = nullptr;
+  hipEvent_t ev_join = nullptr, ev_hoist = nullptr;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
   bool use_side = true;
@@ -116,7 +119,9 @@ struct Engine {
   size_t native_cursor = 0;
   Plan* bp = nullptr;  // plan being built (nullptr while registering parameters)
 
-  PRef param(size_t numel);
+  PRef param(size_t numel, bool small = false);   // small: bias / norm vectors, accumulated with atomics -> zeroed per cycle
+  std::vector<std::pair<size_t, size_t>> small_ranges;   // (elem offset, elems) of the small parameters
+  unsigned long long* small_ranges_dev = nullptr;         // same list on the device (pairs), for the zeroing kernel
   void map_src(const std::string& name, std::vector<long> shape, PRef p, int kind, size_t elem_off, int ci_pad);
   int seg_of(size_t elem_off) const;
   void build(Plan* plan);  // registers parameters (plan == nullptr) or builds a plan

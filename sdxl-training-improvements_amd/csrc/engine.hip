@@ -59,7 +59,7 @@ hipEvent_t Engine::next_event() {
 template <class F>
 static int on_side(Plan& p, hipStream_t main, F&& fn) {
   Engine& e = *p.eng;
-  if (!e.use_side || !e.side) return fn(main);
+  if (!e.use_side || !e.side || gemm_profiling()) return fn(main);
   hipEvent_t ev = e.next_event();
   if (!ev) { sdxl_set_error("hipEventCreate failed"); return 2; }
   HIP_CHECK_RET(hipEventRecord(ev, main));
@@ -138,8 +138,8 @@ struct LinearOp : Op {
       g.splitk = splitk;
       g.slab = p.F(p.slab_off);
       g.accumulate = first ? 0 : 1;
+      g.bias_grad = b.off != NONE ? p.eng->Gp(b) : nullptr;   // column sums of dY ride along on the matrix pipe
       CHK(launch_gemm(g, s2));
-      if (b.off != NONE) CHK(launch_colsum_f32(dy, p.eng->Gp(b), M, N, N, s2));
       return 0;
     }));
     if (x->need_grad) {
@@ -213,8 +213,8 @@ struct ConvOp : Op {
       g.splitk = splitk;
       g.slab = p.F(p.slab_off);
       g.accumulate = first ? 0 : 1;
+      g.bias_grad = p.eng->Gp(b);
       CHK(launch_gemm(g, s2));
-      CHK(launch_colsum_f32(dy, p.eng->Gp(b), (int)Mo, Cout, Cout, s2));
       return 0;
     }));
     if (rowvec) {
@@ -415,13 +415,14 @@ struct EmbedInOp : Op {
 // ================================================================================================
 // Parameters
 // ================================================================================================
-PRef Engine::param(size_t numel) {
+PRef Engine::param(size_t numel, bool small) {
   if (registering) {
     PRef p;
     p.off = param_elems;
     p.numel = numel;
     param_elems = align_up(param_elems + numel, 64);
     natives.push_back(p);
+    if (small) small_ranges.emplace_back(p.off, numel);
     return p;
   }
   PRef p = natives.at(native_cursor++);
@@ -477,7 +478,7 @@ struct Builder {
     if (conv1x1) e.map_src(name + ".weight", {N, K, 1, 1}, w, 0, 0, 0);
     else e.map_src(name + ".weight", {N, K}, w, 0, 0, 0);
     PRef b;
-    if (bias) { b = e.param(N); e.map_src(name + ".bias", {N}, b, 0, 0, 0); }
+    if (bias) { b = e.param(N, true); e.map_src(name + ".bias", {N}, b, 0, 0, 0); }
     if (!pl) return nullptr;
     Act* y = pl->new_act(x->rows, N);
     tagseg(pl->add<LinearOp>(x, y, w, b, K, N, resid), w);
@@ -499,7 +500,7 @@ struct Builder {
     if (cout_src < 0) cout_src = cout;
     PRef w = e.param((size_t)cout * 9 * cin);
     e.map_src(name + ".weight", {cout_src, cin_src, 3, 3}, w, 1, 0, cin);
-    PRef b = e.param(cout);
+    PRef b = e.param(cout, true);
     e.map_src(name + ".bias", {cout_src}, b, 0, 0, 0);
     if (!pl) return nullptr;
     int ho = (h - 1) / stride + 1, wo = (w_ - 1) / stride + 1;
@@ -508,9 +509,9 @@ struct Builder {
     return y;
   }
   Act* groupnorm(const std::string& name, Act* x, int hw, int C, float eps, int silu) {
-    PRef g = e.param(C);
+    PRef g = e.param(C, true);
     e.map_src(name + ".weight", {C}, g, 0, 0, 0);
-    PRef b = e.param(C);
+    PRef b = e.param(C, true);
     e.map_src(name + ".bias", {C}, b, 0, 0, 0);
     if (!pl) return nullptr;
     Act* y = pl->new_act(x->rows, C);
@@ -518,9 +519,9 @@ struct Builder {
     return y;
   }
   Act* layernorm(const std::string& name, Act* x, int C) {
-    PRef g = e.param(C);
+    PRef g = e.param(C, true);
     e.map_src(name + ".weight", {C}, g, 0, 0, 0);
-    PRef b = e.param(C);
+    PRef b = e.param(C, true);
     e.map_src(name + ".bias", {C}, b, 0, 0, 0);
     if (!pl) return nullptr;
     Act* y = pl->new_act(x->rows, C);
@@ -557,10 +558,11 @@ struct Builder {
     Act* l2 = layernorm(b + ".norm2", x1, C);
     Act* q = linear(b + ".attn2.to_q", l2, C, C, false, nullptr);
     Act* kv = linear_fused({b + ".attn2.to_k", b + ".attn2.to_v"}, ehs, cross, C);
+    if (pl) pl->ops.back()->hoist_fwd = true;
     Act* a2 = nullptr;
     if (pl) {
       a2 = pl->new_act(x->rows, C);
-      tagseg(pl->add<AttnOp>(*pl, q, kv, a2, B, heads, N, ctx, C, false), PRef());
+      tagseg(pl->add<AttnOp>(*pl, q, kv, a2, B, heads, N, ctx, C, false), PRef())->needs_hoisted = true;
     }
     Act* x2 = linear(b + ".attn2.to_out.0", a2, C, C, true, x1);
     Act* l3 = layernorm(b + ".norm3", x2, C);

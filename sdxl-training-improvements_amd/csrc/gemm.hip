@@ -346,6 +346,15 @@ __global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_k
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // bias gradient (TN): column sums of the A operand = A^T . ones, on the matrix pipe, by one wave column of the
+  // workgroups that own n-tile 0 (and tap 0)
+  const bool do_bias = FORM == GEMM_TN && p.bias_grad != nullptr && bx == 0 && tap_fixed == 0 && wn == 0;
+  f32x4 accb[4];
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
   auto stage = [&](int kt, int buf) {
     if (FAST) stage_fast(buf); else stage_gen(kt, buf);   // FAST: steps are always staged in increasing order
@@ -383,6 +392,10 @@ __global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_k
         else
           bfr[j] = frag_nc<BN>(Bt, ks * 32 + g * 8, wn * (BN / 2) + j * 16, l16);
       }
+      if (FORM == GEMM_TN && do_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+      }
       if (!FAST) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -403,6 +416,15 @@ __global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_k
     wr = wr + 1 == S ? 0 : wr + 1;
   }
   __syncthreads();  // all fragment reads done before the ring is reused as the fp32 staging tile
+  if (FORM == GEMM_TN && do_bias && l16 == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 64 + i * 16 + g * 4 + r;
+        if (m < p.M) atomicAdd(p.bias_grad + m, accb[i][r]);
+      }
+  }
 
   // ---- epilogue: stage the fp32 tile in LDS 64 rows at a time (34 KiB), then row-contiguous 16-byte stores ----
   float* Cs = (float*)smem;
@@ -561,6 +583,7 @@ struct GemmProf {
   std::vector<double> flops;
 };
 static GemmProf g_prof;
+bool gemm_profiling() { return g_prof.on; }
 int gemm_profile_begin() {
   g_prof.on = true;
   g_prof.used = 0;

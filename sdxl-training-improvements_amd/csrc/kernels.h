@@ -43,6 +43,8 @@ struct GemmP {
   int splitk;
   float* slab;     // splitk * M * N * taps floats
   long slab_ld;    // set by the launcher
+  float* bias_grad;  // TN only, optional: bias_grad[m] += sum_k A(k, m)  (column sums of dY, computed on the matrix pipe
+                     // by the n-tile-0 / tap-0 workgroups with an all-ones B fragment; fp32 atomics, 128 per workgroup)
   int xcd_px;      // set by the launcher: XCD grid width over n-tiles (0 = identity order; SDXL_GEMM_XCD=0 disables)
 };
 size_t gemm_slab_floats(int M, int N, int taps, int splitk);
@@ -50,6 +52,7 @@ void gemm_defaults(GemmP* p);
 int launch_gemm(const GemmP& p, hipStream_t st);
 // per-launch HIP-event timing of every GEMM launch between begin and end (end synchronises the device)
 int gemm_profile_begin();
+bool gemm_profiling();   // true between begin and end: the engine then runs everything on one stream (clean durations)
 int gemm_profile_end(double* flops, double* ms, int* launches);
 
 // ------------------------------------------------------------------------------------------------
