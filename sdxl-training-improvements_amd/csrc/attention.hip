@@ -365,7 +365,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
   for (int i = 0; i < 4; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   const float c = SCALE * LOG2E;
 
-  const int ntiles = (p.Nq + 63) / 64;
+  const int ntiles_all = (p.Nq + 63) / 64;
+  const int per = (ntiles_all + p.qsplit - 1) / p.qsplit;
+  const int t_begin = blockIdx.z * per;
+  const int ntiles = min(ntiles_all, t_begin + per);
   bf16x8 rq[2], rd[2];
   float rs = 0.f;
   auto load_stats = [&](int t) {
@@ -376,15 +379,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
       rs = v;
     }
   };
-  tile_load(Qb, p.ldq, 0, p.Nq, tid, rq);
-  tile_load(dOb, p.lddo, 0, p.Nq, tid, rd);
-  load_stats(0);
+  tile_load(Qb, p.ldq, t_begin * 64, p.Nq, tid, rq);
+  tile_load(dOb, p.lddo, t_begin * 64, p.Nq, tid, rd);
+  load_stats(t_begin);
   tile_store(sm, tid, rq);
   tile_store(sm + TILE_ELEMS, tid, rd);
   if (tid < 128) sstat[0][tid >> 6][tid & 63] = rs;
   __syncthreads();
   int buf = 0;
-  for (int t = 0; t < ntiles; ++t) {
+  for (int t = t_begin; t < ntiles; ++t) {
     const bool more = t + 1 < ntiles;
     if (more) {
       tile_load(Qb, p.ldq, (t + 1) * 64, p.Nq, tid, rq);
@@ -439,7 +442,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     __syncthreads();
     buf ^= 1;
   }
-  if (kok) {
+  if (p.qsplit > 1) {   // fp32 partials: part[z][bh][key_local][2][64]
+    const int kvt = (p.Nk + 63) / 64;
+    float* base = p.part + ((((long)blockIdx.z * gridDim.y + bh) * kvt * 64 + (blockIdx.x * 64 + wave * 16 + l16)) * 2) * 64;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      *(f32x4*)(base + db * 16 + g * 4) = dk[db];
+      *(f32x4*)(base + 64 + db * 16 + g * 4) = dv[db];
+    }
+  } else if (kok) {
     bf16* kr = p.dK + ((long)b * p.Nk + key) * p.lddk + h * HD;
     bf16* vr = p.dV + ((long)b * p.Nk + key) * p.lddv + h * HD;
 #pragma unroll
@@ -451,6 +462,42 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
       *(bf16x4*)(vr + db * 16 + g * 4) = c2;
     }
   }
+}
+
+// dK/dV = sum over query splits of the fp32 partials (fixed order), cast to bf16
+__global__ void attn_dkv_reduce_kernel(const AttnP p) {
+  const int kvt = (p.Nk + 63) / 64;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over B*H * Nk * 2 * 16 (float4 groups)
+  const long total = (long)p.B * p.H * p.Nk * 32;
+  if (i >= total) return;
+  const int v4 = (int)(i & 15), which = (int)((i >> 4) & 1);
+  const long rk = i >> 5;
+  const int key = (int)(rk % p.Nk);
+  const long bh = rk / p.Nk;
+  const int b = (int)(bh / p.H), h = (int)(bh - (long)b * p.H);
+  f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < p.qsplit; ++z) {
+    const float* src = p.part + ((((long)z * p.B * p.H + bh) * kvt * 64 + key) * 2 + which) * 64 + v4 * 4;
+    f32x4 v = *(const f32x4*)src;
+    a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+  }
+  bf16x4 o;
+  o[0] = (bf16)a[0]; o[1] = (bf16)a[1]; o[2] = (bf16)a[2]; o[3] = (bf16)a[3];
+  bf16* dst = which == 0 ? p.dK + ((long)b * p.Nk + key) * p.lddk + h * HD : p.dV + ((long)b * p.Nk + key) * p.lddv + h * HD;
+  *(bf16x4*)(dst + v4 * 4) = o;
+}
+
+size_t attn_part_floats(int B, int H, int Nk, int qsplit) {
+  return qsplit > 1 ? (size_t)qsplit * B * H * ((Nk + 63) / 64) * 64 * 2 * 64 : 0;
+}
+int attn_pick_qsplit(int B, int H, int Nq, int Nk) {
+  long blocks = (long)((Nk + 63) / 64) * B * H;
+  int qt = (Nq + 63) / 64;
+  int s = (int)(640 / blocks);
+  if (s < 1) s = 1;
+  if (s > qt / 2) s = qt / 2 > 0 ? qt / 2 : 1;
+  if (s > 16) s = 16;
+  return s;
 }
 
 static int check_attn(const AttnP& p) {
@@ -475,7 +522,13 @@ int launch_attn_bwd(const AttnP& p, hipStream_t st) {
   long rows = (long)p.B * p.H * p.Nq;
   hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(rows, 16)), dim3(256), 0, st, p);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(cdiv(p.Nq, 128), p.B * p.H), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(cdiv(p.Nk, 64), p.B * p.H), dim3(256), 0, st, p);
+  AttnP q = p;
+  if (q.qsplit < 1 || !q.part) q.qsplit = 1;
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(cdiv(p.Nk, 64), p.B * p.H, q.qsplit), dim3(256), 0, st, q);
+  if (q.qsplit > 1) {
+    long total = (long)p.B * p.H * p.Nk * 32;
+    hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, q);
+  }
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -472,6 +472,8 @@ int sdxl_op_attention_bwd(const void* q, const void* k, const void* v, const voi
   a.B = B; a.H = heads; a.Nq = Nq; a.Nk = Nk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.dO = (const bf16*)d_o; a.lddo = ldo; a.Delta = delta;
   a.dQ = (bf16*)dq; a.dK = (bf16*)dk; a.dV = (bf16*)dv; a.lddq = ldq; a.lddk = ldk; a.lddv = ldv;
+  a.qsplit = attn_pick_qsplit(B, heads, Nq, Nk);
+  if (a.qsplit > 1) CHK(test_slab(attn_part_floats(B, heads, Nk, a.qsplit), &a.part));
   return launch_attn_bwd(a, (hipStream_t)st);
 }
 

@@ -68,6 +68,7 @@ struct Plan {
   size_t t_off = NONE, tid_off = NONE, loss_off = NONE;
   size_t gn_ws_off = NONE, gn_ws_floats = 0;  // GroupNorm scratch shared by all (stream-ordered) norm ops
   size_t slab_off = NONE, slab_floats = 0;    // split-K partial slabs of the wgrad GEMMs (shared, stream-ordered)
+  size_t apart_off = NONE, apart_floats = 0;  // query-split partials of the cross-attention dK/dV kernel (main stream)
 
   Act* new_act(long rows, int cols, bool need_grad = true);
   size_t alloc(size_t bytes);

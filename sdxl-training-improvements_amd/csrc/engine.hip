@@ -292,11 +292,15 @@ struct AttnOp : Op {
   Act *q, *kv, *o;  // self: q == kv == qkv tensor
   int Bn, heads, Nq, Nk, C;
   bool self;
+  int qsplit = 1;
   size_t lse_off, delta_off;
   AttnOp(Plan& p, Act* q_, Act* kv_, Act* o_, int B_, int heads_, int Nq_, int Nk_, int C_, bool self_)
       : q(q_), kv(kv_), o(o_), Bn(B_), heads(heads_), Nq(Nq_), Nk(Nk_), C(C_), self(self_) {
     lse_off = p.alloc(sizeof(float) * (size_t)Bn * heads * Nq);
     delta_off = p.alloc(sizeof(float) * (size_t)Bn * heads * Nq);
+    qsplit = attn_pick_qsplit(Bn, heads, Nq, Nk);
+    size_t need = attn_part_floats(Bn, heads, Nk, qsplit);
+    if (need > p.apart_floats) p.apart_floats = need;
   }
   void fill(Plan& p, AttnP& a, bool grads) {
     memset(&a, 0, sizeof(a));
@@ -313,6 +317,8 @@ struct AttnOp : Op {
     if (grads) {
       a.dO = p.GP(do_off); a.lddo = C;
       a.Delta = p.F(delta_off);
+      a.qsplit = qsplit;
+      a.part = p.F(p.apart_off);
       if (self) {
         a.dQ = p.GP(dq.out); a.dK = a.dQ + C; a.dV = a.dQ + 2 * C;
         a.lddq = a.lddk = a.lddv = 3L * C;
@@ -690,6 +696,7 @@ void Engine::build(Plan* plan) {
     plan->grad_dst(plan->pred);
     for (int i = (int)plan->ops.size() - 1; i >= 0; --i) plan->ops[i]->plan_bwd(*plan);
     plan->slab_off = plan->alloc(sizeof(float) * (plan->slab_floats ? plan->slab_floats : 4));
+    plan->apart_off = plan->alloc(sizeof(float) * (plan->apart_floats ? plan->apart_floats : 4));
     plan->seg_first_op.assign(nseg, -1);
     plan->seg_last_op.assign(nseg, -2);
     for (int i = 0; i < (int)plan->ops.size(); ++i) {

@@ -72,7 +72,13 @@ struct AttnP {
   long lddq, lddk, lddv;
   float* Delta;        // [B*H][Nq]  rowsum(dO * O)
   int accumulate;      // dQ/dK/dV += (else =)
+  // dK/dV kernel, short key sequences (cross attention, Nk = 77): the query loop is split over grid.z so the
+  // kernel fills the chip; each split writes fp32 partials to `part` and a reduce kernel sums them (fixed order)
+  int qsplit;
+  float* part;         // qsplit * B*H * kvtiles*64 * 64 * 2 floats
 };
+size_t attn_part_floats(int B, int H, int Nk, int qsplit);
+int attn_pick_qsplit(int B, int H, int Nq, int Nk);
 int launch_attn_fwd(const AttnP& p, hipStream_t st);
 int launch_attn_bwd(const AttnP& p, hipStream_t st);
 
