@@ -15,11 +15,14 @@
 #include "kernels.h"
 
 #define HD 64
-#define LDT 72  // LDS row stride (bf16) of every [rows][64] tile: 144 B
 #define SCALE 0.125f
 #define LOG2E 1.4426950408889634f
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __attribute__((aligned(16))) const unsigned int g_attn_zero16[4] = {0u, 0u, 0u, 0u};
 
 __device__ __forceinline__ bf16x8 z8() {
   bf16x8 z;
@@ -27,14 +30,20 @@ __device__ __forceinline__ bf16x8 z8() {
   for (int i = 0; i < 8; ++i) z[i] = (bf16)0.f;
   return z;
 }
-// b128 fragment: row r, 8 contiguous columns at c
-__device__ __forceinline__ bf16x8 ld_frag(const bf16* t, int r, int c) { return *(const bf16x8*)(t + r * LDT + c); }
-// transpose-read fragment for one 32-deep step t over tile rows: block rows per the slot convention,
-// 16 columns at col0; lane16 = lane & 15, g = lane >> 4
+// LDS image of every [64 rows][64 cols] bf16 tile: 128-byte rows, no padding, 16-byte vector v of row r stored at
+// slot v ^ (r & 7).  Written by LDS-DMA (global_load_lds_dwordx4: the swizzle is applied on the per-lane source
+// address), read conflict-free both as rows (ds_read_b128 fragments) and transposed (ds_read_b64_tr_b16).
+// b128 fragment: row r, 8 contiguous columns starting at c (multiple of 8)
+__device__ __forceinline__ bf16x8 ld_frag(const bf16* t, int r, int c) {
+  return *(const bf16x8*)(t + r * 64 + ((((c >> 3) ^ (r & 7))) << 3));
+}
+// transpose-read fragment for one 32-deep step t over tile rows (slot convention above), 16 columns at col0
 __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int t, int col0, int lane16, int g) {
-  const bf16* p0 = tile + (t * 32 + g * 4 + (lane16 >> 2)) * LDT + col0 + (lane16 & 3) * 4;
+  const int r = t * 32 + g * 4 + (lane16 >> 2);
+  const int v = (col0 >> 3) + ((lane16 >> 1) & 1);
+  const bf16* p0 = tile + r * 64 + ((v ^ (r & 7)) << 3) + (lane16 & 1) * 4;
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 16 * LDT));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 16 * 64));   // rows +16: same r & 7
   union { s16x4 s[2]; bf16x8 v; } u;
   u.s[0] = lo;
   u.s[1] = hi;
@@ -46,31 +55,27 @@ __device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
   o[4] = (bf16)b[0]; o[5] = (bf16)b[1]; o[6] = (bf16)b[2]; o[7] = (bf16)b[3];
   return o;
 }
-// cooperative load of a [64][64] bf16 tile (rows row0.., zero beyond nrows) into 2 regs per thread
-__device__ __forceinline__ void tile_load(const bf16* base, long ld, int row0, int nrows, int tid, bf16x8 (&r)[2]) {
+// LDS-DMA of a [64][64] bf16 tile (rows row0.., zero beyond nrows): 8 chunks of 1 KiB = 8 rows each, 2 per wave
+__device__ __forceinline__ void tile_dma(const bf16* base, long ld, int row0, int nrows, bf16* tile, int wave, int lane) {
 #pragma unroll
-  for (int v = 0; v < 2; ++v) {
-    int id = v * 256 + tid;
-    int row = row0 + (id >> 3);
-    r[v] = row < nrows ? *(const bf16x8*)(base + (long)row * ld + (id & 7) * 8) : z8();
-  }
-}
-__device__ __forceinline__ void tile_store(bf16* tile, int tid, const bf16x8 (&r)[2]) {
-#pragma unroll
-  for (int v = 0; v < 2; ++v) {
-    int id = v * 256 + tid;
-    *(bf16x8*)(tile + (id >> 3) * LDT + (id & 7) * 8) = r[v];
+  for (int j = 0; j < 2; ++j) {
+    const int c = wave * 2 + j;
+    const int r = c * 8 + (lane >> 3);
+    const int lv = (lane & 7) ^ (r & 7);
+    const int row = row0 + r;
+    const bf16* src = row < nrows ? base + (long)row * ld + lv * 8 : (const bf16*)g_attn_zero16;
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(tile + c * 512), 16, 0, 0);
   }
 }
 
-#define TILE_ELEMS (64 * LDT)
+#define TILE_ELEMS (64 * 64)
 
 // ------------------------------------------------------------------------------------------------
 // forward: block = 128 queries (4 waves x 32), loop over 64-key tiles
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
   __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE_ELEMS];  // K0 V0 K1 V1
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l16 = lane & 15, g = lane >> 4;
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
   const int q0 = blockIdx.x * 128 + wave * 32;
   const bf16* Qb = p.Q + (long)b * p.Nq * p.ldq + h * HD;
@@ -95,18 +100,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
   const float c = SCALE * LOG2E;
 
   const int ntiles = (p.Nk + 63) / 64;
-  bf16x8 rk[2], rv[2];
-  tile_load(Kb, p.ldk, 0, p.Nk, tid, rk);
-  tile_load(Vb, p.ldv, 0, p.Nk, tid, rv);
-  tile_store(sm, tid, rk);
-  tile_store(sm + TILE_ELEMS, tid, rv);
-  __syncthreads();
+  tile_dma(Kb, p.ldk, 0, p.Nk, sm, wave, lane);
+  tile_dma(Vb, p.ldv, 0, p.Nk, sm + TILE_ELEMS, wave, lane);
   int buf = 0;
   for (int t = 0; t < ntiles; ++t) {
-    const bool more = t + 1 < ntiles;
-    if (more) {
-      tile_load(Kb, p.ldk, (t + 1) * 64, p.Nk, tid, rk);
-      tile_load(Vb, p.ldv, (t + 1) * 64, p.Nk, tid, rv);
+    __syncthreads();  // vmcnt(0) + barrier: tile t landed for every wave, everyone done with the other buffer
+    if (t + 1 < ntiles) {
+      tile_dma(Kb, p.ldk, (t + 1) * 64, p.Nk, sm + ((buf ^ 1) * 2) * TILE_ELEMS, wave, lane);
+      tile_dma(Vb, p.ldv, (t + 1) * 64, p.Nk, sm + ((buf ^ 1) * 2 + 1) * TILE_ELEMS, wave, lane);
     }
     const bf16* Kt = sm + (buf * 2) * TILE_ELEMS;
     const bf16* Vt = Kt + TILE_ELEMS;
@@ -176,11 +177,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
         for (int qb = 0; qb < 2; ++qb)
           ot[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t2][qb], ot[db][qb], 0, 0, 0);
       }
-    if (more) {
-      tile_store(sm + ((buf ^ 1) * 2) * TILE_ELEMS, tid, rk);
-      tile_store(sm + ((buf ^ 1) * 2 + 1) * TILE_ELEMS, tid, rv);
-    }
-    __syncthreads();
     buf ^= 1;
   }
   // finalize
@@ -231,7 +227,7 @@ __global__ void attn_delta_kernel(const AttnP p) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE_ELEMS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l16 = lane & 15, g = lane >> 4;
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
   const int q0 = blockIdx.x * 128 + wave * 32;
   const bf16* Qb = p.Q + (long)b * p.Nq * p.ldq + h * HD;
@@ -261,18 +257,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   const float c = SCALE * LOG2E;
 
   const int ntiles = (p.Nk + 63) / 64;
-  bf16x8 rk[2], rv[2];
-  tile_load(Kb, p.ldk, 0, p.Nk, tid, rk);
-  tile_load(Vb, p.ldv, 0, p.Nk, tid, rv);
-  tile_store(sm, tid, rk);
-  tile_store(sm + TILE_ELEMS, tid, rv);
-  __syncthreads();
+  tile_dma(Kb, p.ldk, 0, p.Nk, sm, wave, lane);
+  tile_dma(Vb, p.ldv, 0, p.Nk, sm + TILE_ELEMS, wave, lane);
   int buf = 0;
   for (int t = 0; t < ntiles; ++t) {
-    const bool more = t + 1 < ntiles;
-    if (more) {
-      tile_load(Kb, p.ldk, (t + 1) * 64, p.Nk, tid, rk);
-      tile_load(Vb, p.ldv, (t + 1) * 64, p.Nk, tid, rv);
+    __syncthreads();
+    if (t + 1 < ntiles) {
+      tile_dma(Kb, p.ldk, (t + 1) * 64, p.Nk, sm + ((buf ^ 1) * 2) * TILE_ELEMS, wave, lane);
+      tile_dma(Vb, p.ldv, (t + 1) * 64, p.Nk, sm + ((buf ^ 1) * 2 + 1) * TILE_ELEMS, wave, lane);
     }
     const bf16* Kt = sm + (buf * 2) * TILE_ELEMS;
     const bf16* Vt = Kt + TILE_ELEMS;
@@ -316,11 +308,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
         for (int qb = 0; qb < 2; ++qb)
           dq[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf[t2][qb], dq[db][qb], 0, 0, 0);
       }
-    if (more) {
-      tile_store(sm + ((buf ^ 1) * 2) * TILE_ELEMS, tid, rk);
-      tile_store(sm + ((buf ^ 1) * 2 + 1) * TILE_ELEMS, tid, rv);
-    }
-    __syncthreads();
     buf ^= 1;
   }
 #pragma unroll
@@ -344,9 +331,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 // dK^T = Q^T . dS as B operands, dO^T / Q^T come from transpose reads of the row-major tiles.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
-  __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE_ELEMS];  // Q0 dO0 Q1 dO1
-  __shared__ __attribute__((aligned(16))) float sstat[2][2][64];                                   // [buf][lse2|delta][q]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
+  // ONE LDS object (a second one makes hipcc drain the LDS-DMA before every ds_read): Q0 dO0 Q1 dO1 | stats
+  __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE_ELEMS + 512];
+  float (*sstat)[2][64] = (float (*)[2][64])(sm + 4 * TILE_ELEMS);                                   // [buf][lse2|delta][q]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l16 = lane & 15, g = lane >> 4;
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
   const int key = blockIdx.x * 64 + wave * 16 + l16;  // this lane's key column
   const bf16* Qb = p.Q + (long)b * p.Nq * p.ldq + h * HD;
@@ -369,7 +357,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
   const int per = (ntiles_all + p.qsplit - 1) / p.qsplit;
   const int t_begin = blockIdx.z * per;
   const int ntiles = min(ntiles_all, t_begin + per);
-  bf16x8 rq[2], rd[2];
   float rs = 0.f;
   auto load_stats = [&](int t) {
     if (tid < 128) {
@@ -379,19 +366,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
       rs = v;
     }
   };
-  tile_load(Qb, p.ldq, t_begin * 64, p.Nq, tid, rq);
-  tile_load(dOb, p.lddo, t_begin * 64, p.Nq, tid, rd);
+  tile_dma(Qb, p.ldq, t_begin * 64, p.Nq, sm, wave, lane);
+  tile_dma(dOb, p.lddo, t_begin * 64, p.Nq, sm + TILE_ELEMS, wave, lane);
   load_stats(t_begin);
-  tile_store(sm, tid, rq);
-  tile_store(sm + TILE_ELEMS, tid, rd);
   if (tid < 128) sstat[0][tid >> 6][tid & 63] = rs;
-  __syncthreads();
   int buf = 0;
   for (int t = t_begin; t < ntiles; ++t) {
     const bool more = t + 1 < ntiles;
+    __syncthreads();   // tile t (DMA) and its statistics landed; everyone done with the other buffer
     if (more) {
-      tile_load(Qb, p.ldq, (t + 1) * 64, p.Nq, tid, rq);
-      tile_load(dOb, p.lddo, (t + 1) * 64, p.Nq, tid, rd);
+      tile_dma(Qb, p.ldq, (t + 1) * 64, p.Nq, sm + ((buf ^ 1) * 2) * TILE_ELEMS, wave, lane);
+      tile_dma(dOb, p.lddo, (t + 1) * 64, p.Nq, sm + ((buf ^ 1) * 2 + 1) * TILE_ELEMS, wave, lane);
       load_stats(t + 1);
     }
     const bf16* Qt = sm + (buf * 2) * TILE_ELEMS;
@@ -434,12 +419,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
         bf16x8 qt = tr_frag(Qt, t2, db * 16, l16, g);
         dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf[t2], dk[db], 0, 0, 0);
       }
-    if (more) {
-      tile_store(sm + ((buf ^ 1) * 2) * TILE_ELEMS, tid, rq);
-      tile_store(sm + ((buf ^ 1) * 2 + 1) * TILE_ELEMS, tid, rd);
-      if (tid < 128) sstat[buf ^ 1][tid >> 6][tid & 63] = rs;
-    }
-    __syncthreads();
+    if (more && tid < 128) sstat[buf ^ 1][tid >> 6][tid & 63] = rs;
     buf ^= 1;
   }
   if (p.qsplit > 1) {   // fp32 partials: part[z][bh][key_local][2][64]

@@ -1,22 +1,23 @@
 // bf16 MFMA GEMM family for gfx950 (MI355X): Linear / conv3x3 forward, dgrad and wgrad.
 //
-// One workgroup = 256 threads = 4 waves (2x2), block tile 128 x BN (BN = 160 or 128), K-step 64.
-// Each wave owns a 64 x BN/2 sub-tile = 4 x (BN/32) fragments of v_mfma_f32_16x16x32_bf16.
-// Operand tiles go global -> LDS directly (global_load_lds_dwordx4, LDS-DMA; two LDS stages, the next tile's DMA
-// in flight under the current tile's MFMAs; XOR-swizzled images, see below).  An operand whose reduction dimension is the
-// contiguous one is read from LDS with ds_read_b128; an operand whose reduction dimension is the
-// strided one (dgrad's weights, both wgrad operands) is read with the gfx950 transpose read
-// ds_read_b64_tr_b16, so no transposed copies of weights or activations are ever materialised.
-// The 3x3 convolution is an implicit GEMM: the gathered operand's rows are pixels and each K-step
-// is (tap, channel chunk) with zero fill at the image border.
+// One workgroup = NW waves (4 or 8) in a (NW/2) x 2 grid over a 128 x BN block tile (BN = 128 or 160), K-step BK
+// (64 or 32).  Each wave owns a (256/NW) x (BN/2) sub-tile of v_mfma_f32_16x16x32_bf16 fragments.
+// Operand tiles go global -> LDS directly (global_load_lds_dwordx4, LDS-DMA) into an S-deep ring: S-1 K-steps of DMA
+// are in flight under the current step's MFMAs (counted s_waitcnt vmcnt + raw s_barrier, one barrier per K-step).
+// An operand whose reduction dimension is the contiguous one is read from LDS with ds_read_b128; an operand whose
+// reduction dimension is the strided one (dgrad's weights, both wgrad operands) is read with the gfx950 transpose
+// read ds_read_b64_tr_b16, so no transposed copies of weights or activations are ever materialised.
+// The 3x3 convolution is an implicit GEMM: the gathered operand's rows are pixels and each K-step is
+// (tap, channel chunk) with zero fill at the image border.
 //
-// MFMA operand slots: lane l holds slot (g = l>>4, j = 0..7) of row/col (l & 15).  The hardware
-// pairs A slot (g,j) with B slot (g,j); both operands map slot (g,j) to k = 8g + j of the 32-deep
-// step, so the two read paths (b128 / transpose) agree by construction.
-// C/D layout: col = l & 15, row = 4*(l>>4) + reg.
+// MFMA operand slots: lane l holds slot (g = l>>4, j = 0..7) of row/col (l & 15).  The hardware pairs A slot (g,j)
+// with B slot (g,j); both operands map slot (g,j) to k = 8g + j of the 32-deep step, so the two read paths
+// (b128 / transpose) agree by construction.  C/D layout: col = l & 15, row = 4*(l>>4) + reg.
 #include "kernels.h"
 
 #include <stdlib.h>
+
+#include <vector>
 
 #define BM 128
 
@@ -28,33 +29,30 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 __device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
 
 // ---- LDS images -----------------------------------------------------------------------------------------
-// Tiles are written by global_load_lds_dwordx4 (LDS-DMA: 64 lanes x 16 B = one contiguous 1 KiB chunk per wave
-// instruction, no VGPR round trip, no ds_write).  The DMA destination is lane-linear, so the bank swizzle is
-// applied on the per-lane SOURCE address and again on the fragment read (same permutation on both sides).
-//  K-contiguous tile [R][64]: 128-B rows, 1 KiB chunk = 8 rows; logical 16-B vector kv of row r sits at
-//     r*128 + ((kv ^ (r & 7)) << 4)                      -> ds_read_b128 fragments conflict-free
-//  N-contiguous tile [64][W] (W = 128 or 160 columns, V = W/8 vectors per k-row):
-//     W = 128: vector v of k-row k sits at k*256 + ((v ^ (F(k) << 1)) << 4),  F(k) = (k & 3) | (((k >> 3) & 1) << 2)
+// Tiles are written by global_load_lds_dwordx4 (64 lanes x 16 B = one contiguous 1 KiB chunk per wave instruction,
+// no VGPR round trip, no ds_write).  The DMA destination is lane-linear, so the bank swizzle is applied on the
+// per-lane SOURCE address and again on the fragment read (same permutation on both sides).
+//  K-contiguous tile [R][BK]: BK = 64 -> 128-B rows, 8 vectors: slot = kv ^ (r & 7)
+//                             BK = 32 ->  64-B rows, 4 vectors: slot = kv ^ P[(r >> 2) & 3], P = {0,2,3,1}
+//     (conflict-free for the ds_read_b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31})
+//  N-contiguous tile [BK][W] (W = 128 or 160 columns, V = W/8 vectors per k-row):
+//     W = 128: vector v of k-row k sits at slot v ^ (F(k) << 1),  F(k) = (k & 3) | (((k >> 3) & 1) << 2)
 //     W = 160: 320-B rows already spread 4 consecutive k-rows over disjoint banks; rows k and k+8 would collide, so
-//              rows with bit 3 set are rotated by 2 vectors: vector v sits at k*320 + (((v + 2*((k>>3)&1)) % 20) << 4)
-//                                                        -> ds_read_b64_tr_b16 fragments conflict-free
+//              rows with bit 3 set are rotated by 2 vectors: slot = (v + 2*((k>>3)&1)) % 20
+//     (conflict-free for ds_read_b64_tr_b16)
 __device__ __forceinline__ int swzF(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 template <int W>
-__device__ __forceinline__ int nc_phys(int k, int v) {  // physical vector slot of logical vector v in k-row k
+__device__ __forceinline__ int nc_phys(int k, int v) {
   if (W == 128) return v ^ (swzF(k) << 1);
   int q = v + 2 * ((k >> 3) & 1);
   return q >= 20 ? q - 20 : q;
 }
 template <int W>
-__device__ __forceinline__ int nc_logical(int k, int pv) {  // inverse of nc_phys
+__device__ __forceinline__ int nc_logical(int k, int pv) {
   if (W == 128) return pv ^ (swzF(k) << 1);
   int q = pv - 2 * ((k >> 3) & 1);
   return q < 0 ? q + 20 : q;
 }
-
-// K-contiguous tile [R][BKT]: BKT = 64 -> 128-B rows, 8 vectors: slot = kv ^ (r & 7)
-//                             BKT = 32 ->  64-B rows, 4 vectors: slot = kv ^ P[(r >> 2) & 3], P = {0,2,3,1}
-// (both conflict-free for the ds_read_b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31})
 template <int BKT>
 __device__ __forceinline__ int kc_swz(int r) {
   if (BKT == 64) return r & 7;
@@ -82,7 +80,6 @@ __device__ __forceinline__ bf16x8 frag_nc(const char* tile, int kb, int col0, in
 struct PixRow {  // decoded pixel of a gathered row
   int b, y, x, ok;
 };
-
 __device__ __forceinline__ PixRow decode_pix(int m, int Mlimit, int Hm, int Wm) {
   PixRow r;
   r.ok = m < Mlimit;
@@ -93,7 +90,6 @@ __device__ __forceinline__ PixRow decode_pix(int m, int Mlimit, int Hm, int Wm) 
   r.x = rem - r.y * Wm;
   return r;
 }
-
 // source pixel index (in pixels) for tap (dy,dx) or -1
 __device__ __forceinline__ long gather_src(const PixRow& r, int dy, int dx, const GemmP& p) {
   int ys = r.y * p.sm + dy - 1;
@@ -113,22 +109,32 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// FORM / CONV as above; BN = 128 or 160 output columns per workgroup; S = LDS ring depth (S-1 K-steps of DMA in
-// flight); BK = 64 or 32 reduction elements per K-step (BK = 32: 34 KiB of LDS -> 3-4 workgroups per CU)
-// FAST (non-conv, reduction length a multiple of BK): every lane's DMA source is a running pointer advanced by a
-// per-lane constant each K-step (0 for out-of-range rows, which keep pointing at the zero vector) -- two VALU adds
-// per load instead of the general path's predicates, 64-bit multiplies and tap arithmetic.
-template <int FORM, bool CONV, int BN, int S, int BK, bool FAST>
-__global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_kernel(const GemmP p) {
-  constexpr int A_TILE_BYTES = BM * BK * 2;                 // [128][BK] or [BK][128] bf16
-  constexpr int B_TILE_BYTES = BN * BK * 2;                 // [BN][BK] or [BK][BN] bf16
+static constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
+
+// FORM : GEMM_NT / NN / TN        CONV : implicit-GEMM 3x3 gather
+// BN   : 128 or 160 output columns per workgroup          S : LDS ring depth (S-1 K-steps of DMA in flight)
+// BK   : 64 or 32 reduction elements per K-step           NW: waves per workgroup (4: 2x2, 8: 4x2)
+// FAST : non-conv, reduction length a multiple of BK: every lane's DMA source is a running pointer advanced by a
+//        per-lane constant each K-step (0 for out-of-range rows, which keep pointing at the zero vector), and the DMA
+//        pieces are issued between groups of MFMAs so their issue cost hides under the matrix pipe.
+template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (S == 2 ? (BK == 32 ? 3 : 2) : 1))) void gemm_kernel(const GemmP p) {
+  constexpr int A_TILE_BYTES = BM * BK * 2;       // [128][BK] or [BK][128] bf16
+  constexpr int B_TILE_BYTES = BN * BK * 2;       // [BN][BK] or [BK][BN] bf16
   constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
-  constexpr int NJ = BN / 32;                               // B fragments per wave (wave tile 64 x BN/2)
-  constexpr int ACH = A_TILE_BYTES / 4096;                  // 1 KiB A chunks per wave per K-step
-  constexpr int BCH = B_TILE_BYTES / 4096;                  // 1 KiB B chunks per wave per K-step
-  constexpr int NL = ACH + BCH;                             // LDS-DMA instructions per wave per K-step
-  constexpr int VR = BK / 8;                                // vectors per K-contiguous row
+  constexpr int RING_BYTES = S * STAGE_BYTES;     // followed by 1 KiB that absorbs the padding DMA pieces
+  constexpr int WGM = NW / 2;                     // wave grid WGM x 2
+  constexpr int MI = BM / (WGM * 16);             // A fragments per wave (4 or 2)
+  constexpr int NJ = BN / 32;                     // B fragments per wave (wave tile (16 MI) x BN/2)
+  constexpr int NCA = A_TILE_BYTES / 1024;        // 1 KiB DMA chunks of the A tile
+  constexpr int NCB = B_TILE_BYTES / 1024;
+  constexpr int ACH = cdiv_c(NCA, NW);            // chunks per wave (chunk id = wave + j*NW; ids >= NC* are padding
+  constexpr int BCH = cdiv_c(NCB, NW);            //  pieces so that every wave issues the same number of loads)
+  constexpr int NL = ACH + BCH;                   // LDS-DMA instructions per wave per K-step
+  constexpr int VR = BK / 8;                      // vectors per K-contiguous row
+  constexpr int KC_ROWS = 64 / VR;                // rows of a K-contiguous tile per 1 KiB chunk
   constexpr int LDC = BN + 4;
+  constexpr int NT = NW * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -143,17 +149,17 @@ __global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_k
   if (p.xcd_px > 0 && gridDim.x % p.xcd_px == 0 && gridDim.y % (8 / p.xcd_px) == 0) {
     const int gx = gridDim.x, gy = gridDim.y;
     const int px = p.xcd_px, py = 8 / px;
-    const int tn = gx / px, tm = gy / py;            // tiles per XCD rectangle (exact: checked by the launcher)
+    const int tn = gx / px, tm = gy / py;
     const int id = blockIdx.y * gx + blockIdx.x;
-    const int xcd = id & 7, li = id >> 3;            // li in [0, tn*tm)
-    const int sw = tn < 8 ? tn : 8;                  // strip width
-    const int full = (tn / sw) * sw * tm;            // tiles covered by full strips
+    const int xcd = id & 7, li = id >> 3;
+    const int sw = tn < 8 ? tn : 8;
+    const int full = (tn / sw) * sw * tm;
     int ln, lm;
     if (li < full) {
       const int strip = li / (sw * tm), w = li - strip * (sw * tm);
       lm = w / sw;
       ln = strip * sw + (w - lm * sw);
-    } else {                                         // ragged last strip
+    } else {
       const int rw = tn - (tn / sw) * sw, w = li - full;
       lm = w / rw;
       ln = (tn / sw) * sw + (w - lm * rw);
@@ -181,16 +187,16 @@ __global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_k
   }
 
   // ---- per-lane LDS-DMA descriptors ----
-  // K-contiguous tile: chunk c = rows 8c..8c+7 ; lane -> row 8c + (lane>>3), physical vector lane&7
-  // N-contiguous tile of width Wd: chunk c = vectors 64c..64c+63 of the [64][Wd/8] vector grid
+  // K-contiguous tile: chunk c = rows KC_ROWS*c .. ; lane -> row KC_ROWS*c + lane/VR, physical vector lane%VR
+  // N-contiguous tile of width Wd: chunk c = vectors 64c..64c+63 of the [BK][Wd/8] vector grid
   const int kc_rowl = lane / VR, kc_pv = lane % VR;
-  constexpr int KC_ROWS = 64 / VR;  // rows of a K-contiguous tile per 1 KiB chunk
   PixRow arow[ACH];
   if (CONV && FORM != GEMM_TN) {
 #pragma unroll
-    for (int j = 0; j < ACH; ++j) arow[j] = decode_pix(m0 + (wave * ACH + j) * KC_ROWS + kc_rowl, p.M, p.Hm, p.Wm);
+    for (int j = 0; j < ACH; ++j) arow[j] = decode_pix(m0 + (wave + j * NW) * KC_ROWS + kc_rowl, p.M, p.Hm, p.Wm);
   }
   const bf16* zsrc = (const bf16*)g_zero16;
+  char* const pad_dst = smem + RING_BYTES;   // 1 KiB: destination of the padding pieces
 
   // FAST path state: running source pointers + per-lane step (elements) for this wave's chunks
   const bf16* pa[ACH];
@@ -199,28 +205,30 @@ __global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_k
   if (FAST) {
 #pragma unroll
     for (int j = 0; j < ACH; ++j) {
-      const int c = wave * ACH + j;
+      const int c = wave + j * NW;
+      bool ok = c < NCA;
       if (FORM == GEMM_TN) {
         const int krow = c * 4 + (lane >> 4);
         const int m = m0 + (nc_logical<128>(krow, lane & 15) << 3);
-        const bool ok = m < p.M;
+        ok = ok && m < p.M;
         pa[j] = ok ? p.A + ((long)kt_begin * BK + krow) * p.lda + m : zsrc;
         sa[j] = ok ? (long)BK * p.lda : 0;
       } else {
         const int row = c * KC_ROWS + kc_rowl;
         const int m = m0 + row;
-        const bool ok = m < p.M;
+        ok = ok && m < p.M;
         pa[j] = ok ? p.A + (long)m * p.lda + ((kc_pv ^ kc_swz<BK>(row)) << 3) : zsrc;
         sa[j] = ok ? BK : 0;
       }
     }
 #pragma unroll
     for (int j = 0; j < BCH; ++j) {
-      const int c = wave * BCH + j;
+      const int c = wave + j * NW;
+      bool ok = c < NCB;
       if (FORM == GEMM_NT) {
         const int row = c * KC_ROWS + kc_rowl;
         const int n = n0 + row;
-        const bool ok = n < p.N;
+        ok = ok && n < p.N;
         pb[j] = ok ? p.B + (long)n * p.ldb + ((kc_pv ^ kc_swz<BK>(row)) << 3) : zsrc;
         sb[j] = ok ? BK : 0;
       } else {
@@ -228,49 +236,38 @@ __global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_k
         const int q = c * 64 + lane;
         const int krow = q / V, pv = q - krow * V;
         const int n = n0 + (nc_logical<BN>(krow, pv) << 3);
-        const bool ok = n < p.N;
+        ok = ok && n < p.N;
         pb[j] = ok ? p.B + ((long)kt_begin * BK + krow) * p.ldb + n : zsrc;
         sb[j] = ok ? (long)BK * p.ldb : 0;
       }
     }
   }
-  auto stage_fast = [&](int buf) {
-    char* At = smem + buf * STAGE_BYTES;
-    char* Bt = At + A_TILE_BYTES;
-#pragma unroll
-    for (int j = 0; j < ACH; ++j) {
-      __builtin_amdgcn_global_load_lds((gbl_void*)pa[j], (lds_void*)(At + (wave * ACH + j) * 1024), 16, 0, 0);
-      pa[j] += sa[j];
-    }
-#pragma unroll
-    for (int j = 0; j < BCH; ++j) {
-      __builtin_amdgcn_global_load_lds((gbl_void*)pb[j], (lds_void*)(Bt + (wave * BCH + j) * 1024), 16, 0, 0);
-      pb[j] += sb[j];
-    }
-  };
-
-  // FAST path, interleaved form: DMA piece `pc` (A chunks first, then B chunks) of the step being staged into ring
-  // slot `buf`; `live` = false re-targets the load at the zero vector (branch-free tail).  One piece is issued
-  // after every group of 4 MFMAs so its ~60-180 cycle issue cost hides under the matrix pipe instead of in front of it.
+  // FAST: DMA piece `pc` (A chunks first, then B chunks) of the step being staged into ring slot `buf`;
+  // live = false re-targets the load at the zero vector (branch-free tail).
   auto issue_piece = [&](int pc, int buf, bool live) {
     char* At = smem + buf * STAGE_BYTES;
     char* Bt = At + A_TILE_BYTES;
 #pragma unroll
     for (int j = 0; j < ACH; ++j)
       if (pc == j) {
+        const int c = wave + j * NW;
         const bf16* src = live ? pa[j] : zsrc;
-        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(At + (wave * ACH + j) * 1024), 16, 0, 0);
+        char* dst = (NCA % NW == 0 || c < NCA) ? At + c * 1024 : pad_dst;
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
         pa[j] += sa[j];
       }
 #pragma unroll
     for (int j = 0; j < BCH; ++j)
       if (pc == ACH + j) {
+        const int c = wave + j * NW;
         const bf16* src = live ? pb[j] : zsrc;
-        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(Bt + (wave * BCH + j) * 1024), 16, 0, 0);
+        char* dst = (NCB % NW == 0 || c < NCB) ? Bt + c * 1024 : pad_dst;
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
         pb[j] += sb[j];
       }
   };
 
+  // general path: addresses recomputed per K-step (tap arithmetic, border / tail predicates)
   auto stage_gen = [&](int kt, int buf) {
     int tap = 0, c0;
     if (FORM == GEMM_TN) {
@@ -283,40 +280,40 @@ __global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_k
     const int dy = tap / 3, dx = tap - dy * 3;
     char* At = smem + buf * STAGE_BYTES;
     char* Bt = At + A_TILE_BYTES;
-    // ---------------- A : ACH chunks per wave ----------------
 #pragma unroll
     for (int j = 0; j < ACH; ++j) {
-      const int c = wave * ACH + j;
+      const int c = wave + j * NW;
+      const bool cok = NCA % NW == 0 || c < NCA;
       const bf16* src;
       if (FORM == GEMM_TN) {
         const int krow = c * 4 + (lane >> 4);
         const int kk = c0 + krow;
         const int m = m0 + (nc_logical<128>(krow, lane & 15) << 3);
-        src = (kk < p.K && m < p.M) ? p.A + (long)kk * p.lda + m : zsrc;
+        src = (cok && kk < p.K && m < p.M) ? p.A + (long)kk * p.lda + m : zsrc;
       } else {
         const int row = c * KC_ROWS + kc_rowl;
         const int kofs = c0 + ((kc_pv ^ kc_swz<BK>(row)) << 3);
         if (CONV) {
           long s = gather_src(arow[j], dy, dx, p);
-          src = (s >= 0 && kofs < p.K) ? p.A + s * p.lda + kofs : zsrc;
+          src = (cok && s >= 0 && kofs < p.K) ? p.A + s * p.lda + kofs : zsrc;
         } else {
           const int m = m0 + row;
-          src = (m < p.M && kofs < p.K) ? p.A + (long)m * p.lda + kofs : zsrc;
+          src = (cok && m < p.M && kofs < p.K) ? p.A + (long)m * p.lda + kofs : zsrc;
         }
       }
-      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(At + c * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(cok ? At + c * 1024 : pad_dst), 16, 0, 0);
     }
-    // ---------------- B : BCH chunks per wave ----------------
 #pragma unroll
     for (int j = 0; j < BCH; ++j) {
-      const int c = wave * BCH + j;
+      const int c = wave + j * NW;
+      const bool cok = NCB % NW == 0 || c < NCB;
       const bf16* src;
       if (FORM == GEMM_NT) {
         const int wtap = p.flip ? (p.taps - 1 - tap) : tap;
         const int row = c * KC_ROWS + kc_rowl;
         const int n = n0 + row;
         const int kofs = c0 + ((kc_pv ^ kc_swz<BK>(row)) << 3);
-        src = (n < p.N && kofs < p.K) ? p.B + (long)n * p.ldb + (long)wtap * p.b_tap_stride + kofs : zsrc;
+        src = (cok && n < p.N && kofs < p.K) ? p.B + (long)n * p.ldb + (long)wtap * p.b_tap_stride + kofs : zsrc;
       } else {
         constexpr int V = BN / 8;
         const int q = c * 64 + lane;
@@ -325,7 +322,7 @@ __global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_k
         const int n = n0 + (nc_logical<BN>(krow, pv) << 3);
         if (FORM == GEMM_NN) {
           const int wtap = p.flip ? (p.taps - 1 - tap) : tap;
-          src = (kk < p.K && n < p.N) ? p.B + (long)kk * p.ldb + (long)wtap * p.b_tap_stride + n : zsrc;
+          src = (cok && kk < p.K && n < p.N) ? p.B + (long)kk * p.ldb + (long)wtap * p.b_tap_stride + n : zsrc;
         } else {
           long s;
           if (CONV) {
@@ -334,42 +331,52 @@ __global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_k
           } else {
             s = kk < p.K ? kk : -1;
           }
-          src = (s >= 0 && n < p.N) ? p.B + s * p.ldb + n : zsrc;
+          src = (cok && s >= 0 && n < p.N) ? p.B + s * p.ldb + n : zsrc;
         }
       }
-      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(Bt + c * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(cok ? Bt + c * 1024 : pad_dst), 16, 0, 0);
+    }
+  };
+  auto stage = [&](int kt, int buf) {
+    if (FAST) {
+#pragma unroll
+      for (int pc = 0; pc < NL; ++pc) issue_piece(pc, buf, true);   // steps are staged in increasing order
+    } else {
+      stage_gen(kt, buf);
     }
   };
 
-  f32x4 acc[4][NJ];
+  f32x4 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // bias gradient (TN): column sums of the A operand = A^T . ones, on the matrix pipe, by one wave column of the
   // workgroups that own n-tile 0 (and tap 0)
   const bool do_bias = FORM == GEMM_TN && p.bias_grad != nullptr && bx == 0 && tap_fixed == 0 && wn == 0;
-  f32x4 accb[4];
+  f32x4 accb[MI];
   bf16x8 ones;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < MI; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
-
-  auto stage = [&](int kt, int buf) {
-    if (FAST) stage_fast(buf); else stage_gen(kt, buf);   // FAST: steps are always staged in increasing order
-  };
-  (void)stage_fast;
 
   // ---- S-deep ring: K-steps t+1 .. t+S-1 are in flight (LDS-DMA) while step t is multiplied ----
   const int T = kt_end - kt_begin;
 #pragma unroll
-  for (int d = 0; d < S - 1; ++d)
+  for (int d = 0; d < S - 1; ++d) {
     if (d < T) stage(kt_begin + d, d);
+    else if (FAST) {                       // keep the vmcnt arithmetic uniform: same number of loads every step
+#pragma unroll
+      for (int pc = 0; pc < NL; ++pc) issue_piece(pc, d, false);
+    }
+  }
   int rd = 0, wr = S - 1;  // ring slots: read slot of step t, write slot of step t+S-1
   for (int t = 0; t < T; ++t) {
-    // step t has landed once at most the later steps' DMAs of this wave are still outstanding ...
-    if (S == 3 && t + 1 < T) wait_vmcnt<NL>(); else wait_vmcnt<0>();
+    // step t has landed once at most the S-2 later steps' DMAs of this wave are still outstanding ...
+    if (FAST) wait_vmcnt<(S - 2) * NL>();                           // FAST issues NL loads for every step, live or not
+    else if (S >= 3 && t + S - 2 < T) wait_vmcnt<(S - 2) * NL>();
+    else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave has finished reading slot `wr` (step t-1)
     const bool live = t + S - 1 < T;
     if (!FAST && live) stage(kt_begin + t + S - 1, wr);
@@ -377,13 +384,13 @@ __global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_k
     const char* Bt = At + A_TILE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8 af[4], bfr[NJ];
+      bf16x8 af[MI], bfr[NJ];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < MI; ++i) {
         if (FORM == GEMM_TN)
-          af[i] = frag_nc<128>(At, ks * 32 + g * 8, wm * 64 + i * 16, l16);
+          af[i] = frag_nc<128>(At, ks * 32 + g * 8, wm * (MI * 16) + i * 16, l16);
         else
-          af[i] = frag_kc<BK>(At, wm * 64 + i * 16 + l16, ks * 4 + g);
+          af[i] = frag_kc<BK>(At, wm * (MI * 16) + i * 16 + l16, ks * 4 + g);
       }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
@@ -394,17 +401,17 @@ __global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_k
       }
       if (FORM == GEMM_TN && do_bias) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+        for (int i = 0; i < MI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
       }
       if (!FAST) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        if (FAST) {
-          constexpr int NSLOT = (BK / 32) * 4;
-          const int slot = ks * 4 + i;
+        if (FAST) {  // one DMA piece per MFMA group
+          constexpr int NSLOT = (BK / 32) * MI;
+          const int slot = ks * MI + i;
 #pragma unroll
           for (int pc = 0; pc < NL; ++pc)
             if (pc % NSLOT == slot) issue_piece(pc, wr, live);
@@ -415,81 +422,83 @@ __global__ __launch_bounds__(256, (S == 2 ? (BK == 32 ? 3 : 2) : 1)) void gemm_k
     rd = rd + 1 == S ? 0 : rd + 1;
     wr = wr + 1 == S ? 0 : wr + 1;
   }
-  __syncthreads();  // all fragment reads done before the ring is reused as the fp32 staging tile
+  wait_vmcnt<0>();
+  __syncthreads();  // all fragment reads (and padding DMA) done before the ring is reused as the fp32 staging tile
   if (FORM == GEMM_TN && do_bias && l16 == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 64 + i * 16 + g * 4 + r;
+        const int m = m0 + wm * (MI * 16) + i * 16 + g * 4 + r;
         if (m < p.M) atomicAdd(p.bias_grad + m, accb[i][r]);
       }
   }
 
-  // ---- epilogue: stage the fp32 tile in LDS 64 rows at a time (34 KiB), then row-contiguous 16-byte stores ----
+  // ---- epilogue: stage the fp32 tile in LDS 64 rows at a time (34-42 KiB), then row-contiguous 16-byte stores ----
   float* Cs = (float*)smem;
-  constexpr int VPR = BN / 8;                 // 8-column vectors per tile row
+  constexpr int VPR = BN / 8;  // 8-column vectors per tile row
 #pragma unroll 1
   for (int half = 0; half < 2; ++half) {
-    if (wm == half) {
+    const int wrow = wm * (MI * 16);           // this wave's first row in the tile
+    if (wrow / 64 == half) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            Cs[(i * 16 + g * 4 + r) * LDC + wn * (BN / 2) + j * 16 + l16] = acc[i][j][r];
+            Cs[(wrow - half * 64 + i * 16 + g * 4 + r) * LDC + wn * (BN / 2) + j * 16 + l16] = acc[i][j][r];
     }
     __syncthreads();
-  for (int id = tid; id < 64 * VPR; id += 256) {
-    int row = id / VPR, col = (id - row * VPR) * 8;
-    int m = m0 + half * 64 + row, n = n0 + col;
-    if (m >= p.M || n >= p.N) continue;
-    float x[8];
-    {
-      f32x4 a = *(const f32x4*)(Cs + row * LDC + col);
-      f32x4 b = *(const f32x4*)(Cs + row * LDC + col + 4);
-      x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3];
-      x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
-    }
-    if (p.out_f32) {
-      float* c = (float*)p.C + (long)m * p.ldc + (long)tap_fixed * p.c_tap_stride + n;
-      if (p.splitk > 1) {  // deterministic split-K: partial tile to this split's slab, summed by splitk_reduce_kernel
-        float* sl = p.slab + ((long)split * p.M + m) * p.slab_ld + (long)tap_fixed * p.c_tap_stride + n;
-        *(f32x4*)sl = (f32x4){x[0], x[1], x[2], x[3]};
-        *(f32x4*)(sl + 4) = (f32x4){x[4], x[5], x[6], x[7]};
-      } else if (p.accumulate) {
-        f32x4 a = *(f32x4*)c, b = *(f32x4*)(c + 4);
-        a[0] += x[0]; a[1] += x[1]; a[2] += x[2]; a[3] += x[3];
-        b[0] += x[4]; b[1] += x[5]; b[2] += x[6]; b[3] += x[7];
-        *(f32x4*)c = a;
-        *(f32x4*)(c + 4) = b;
+    for (int id = tid; id < 64 * VPR; id += NT) {
+      int row = id / VPR, col = (id - row * VPR) * 8;
+      int m = m0 + half * 64 + row, n = n0 + col;
+      if (m >= p.M || n >= p.N) continue;
+      float x[8];
+      {
+        f32x4 a = *(const f32x4*)(Cs + row * LDC + col);
+        f32x4 b = *(const f32x4*)(Cs + row * LDC + col + 4);
+        x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3];
+        x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
+      }
+      if (p.out_f32) {
+        float* c = (float*)p.C + (long)m * p.ldc + (long)tap_fixed * p.c_tap_stride + n;
+        if (p.splitk > 1) {  // deterministic split-K: partial tile to this split's slab, summed by splitk_reduce_kernel
+          float* sl = p.slab + ((long)split * p.M + m) * p.slab_ld + (long)tap_fixed * p.c_tap_stride + n;
+          *(f32x4*)sl = (f32x4){x[0], x[1], x[2], x[3]};
+          *(f32x4*)(sl + 4) = (f32x4){x[4], x[5], x[6], x[7]};
+        } else if (p.accumulate) {
+          f32x4 a = *(f32x4*)c, b = *(f32x4*)(c + 4);
+          a[0] += x[0]; a[1] += x[1]; a[2] += x[2]; a[3] += x[3];
+          b[0] += x[4]; b[1] += x[5]; b[2] += x[6]; b[3] += x[7];
+          *(f32x4*)c = a;
+          *(f32x4*)(c + 4) = b;
+        } else {
+          *(f32x4*)c = (f32x4){x[0], x[1], x[2], x[3]};
+          *(f32x4*)(c + 4) = (f32x4){x[4], x[5], x[6], x[7]};
+        }
       } else {
-        *(f32x4*)c = (f32x4){x[0], x[1], x[2], x[3]};
-        *(f32x4*)(c + 4) = (f32x4){x[4], x[5], x[6], x[7]};
-      }
-    } else {
-      if (p.bias) {
-        bf16x8 bv = *(const bf16x8*)(p.bias + n);
+        if (p.bias) {
+          bf16x8 bv = *(const bf16x8*)(p.bias + n);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] += (float)bv[e];
-      }
-      if (p.rowvec) {
-        bf16x8 tv = *(const bf16x8*)(p.rowvec + (long)(m / p.rows_per_batch) * p.ldv + n);
+          for (int e = 0; e < 8; ++e) x[e] += (float)bv[e];
+        }
+        if (p.rowvec) {
+          bf16x8 tv = *(const bf16x8*)(p.rowvec + (long)(m / p.rows_per_batch) * p.ldv + n);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] += (float)tv[e];
-      }
-      if (p.resid) {
-        bf16x8 rv = *(const bf16x8*)(p.resid + (long)m * p.ldr + n);
+          for (int e = 0; e < 8; ++e) x[e] += (float)tv[e];
+        }
+        if (p.resid) {
+          bf16x8 rv = *(const bf16x8*)(p.resid + (long)m * p.ldr + n);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] += (float)rv[e];
-      }
-      bf16x8 o;
+          for (int e = 0; e < 8; ++e) x[e] += (float)rv[e];
+        }
+        bf16x8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (bf16)x[e];
-      *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + n) = o;
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)x[e];
+        *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + n) = o;
+      }
     }
-  }
     __syncthreads();
   }
 }
@@ -522,33 +531,38 @@ void gemm_defaults(GemmP* p) {
 }
 
 static constexpr int gemm_smem_bytes(int BN, int S, int BK) {
-  int ring = S * (BM + BN) * BK * 2, stg = 64 * (BN + 4) * 4;
+  int ring = S * (BM + BN) * BK * 2 + 1024, stg = 64 * (BN + 4) * 4;
   return ring > stg ? ring : stg;
 }
 
-template <int FORM, bool CONV, int BN, int S, int BK, bool FAST>
+template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW>
 static int launch_k(const GemmP& p, hipStream_t st) {
   static bool attr_set = false;
   constexpr int smem = gemm_smem_bytes(BN, S, BK);
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<FORM, CONV, BN, S, BK, FAST>,
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
   dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), FORM == GEMM_TN ? p.taps * p.splitk : 1);
-  hipLaunchKernelGGL((gemm_kernel<FORM, CONV, BN, S, BK, FAST>), grid, dim3(256), smem, st, p);
+  hipLaunchKernelGGL((gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW>), grid, dim3(NW * 64), smem, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-template <int FORM, bool CONV, int BN, int S, int BK>
+template <int FORM, bool CONV, int BN, int S, int BK, int NW>
 static int launch_cfg(const GemmP& p, hipStream_t st) {
-  if (!CONV && p.K % BK == 0 && !getenv("SDXL_GEMM_NOFAST")) return launch_k<FORM, false, BN, S, BK, true>(p, st);
-  return launch_k<FORM, CONV, BN, S, BK, false>(p, st);
+  static int nofast = -1;
+  if (nofast < 0) nofast = getenv("SDXL_GEMM_NOFAST") ? 1 : 0;
+  if (!CONV && p.K % BK == 0 && !nofast) return launch_k<FORM, false, BN, S, BK, true, NW>(p, st);
+  return launch_k<FORM, CONV, BN, S, BK, false, NW>(p, st);
 }
 
-// tile / pipeline selection.  BN = 160 when it divides N (1280, 640, 320, 3840, 5120, 10240, 2560, 1920 ... all do):
-// at B=4, 1024^2 every Linear / conv output then tiles into an exact multiple of 256 workgroups (one per CU).
-// SDXL_GEMM_CFG=<bn><s> (e.g. 1282, 1283, 1603) forces a configuration (benchmarking).
+// Tile / pipeline selection.  Configurations (SDXL_GEMM_CFG=<id> forces one, for benchmarking):
+//   1: 128x128, BK 64, 2-deep ring, 4 waves  (65 KiB LDS, 2 workgroups per CU)          -- default
+//   2: 128x128, BK 32, 2-deep ring, 4 waves  (34 KiB LDS, 3-4 per CU)                   -- large-grid dgrad / wgrad
+//   3: 128x160, BK 64, 4-deep ring, 8 waves  (145 KiB LDS, 1 per CU, 3 K-steps of DMA in flight)
+//   4: 128x128, BK 64, 4-deep ring, 8 waves  (129 KiB LDS, 1 per CU)
+//   5: 128x128, BK 64, 3-deep ring, 4 waves  (97 KiB LDS, 1 per CU)
 static int g_force_cfg = -1;
 template <int FORM, bool CONV>
 static int launch_one(const GemmP& p, hipStream_t st) {
@@ -556,26 +570,36 @@ static int launch_one(const GemmP& p, hipStream_t st) {
     const char* e = getenv("SDXL_GEMM_CFG");
     g_force_cfg = e ? atoi(e) : 0;
   }
-  // measured on MI355X (round 1): two co-resident 128x128 workgroups per CU (S = 2, 68 KiB LDS each) beat the
-  // one-per-CU 3-deep rings (128x128 or 128x160, ~100 KiB LDS) on every shape but the K >= 2560 ones in isolation, and
-  // on the whole step even there: a one-per-CU kernel leaves no LDS for the side stream's wgrad workgroups to co-run.
-  int bn = 128, s = 2;
+  int cfg = 1;
   // the transpose-read forms (dgrad / wgrad) spend twice the LDS-read issue slots per K-step: when the grid is large
-  // enough to actually keep 3-4 workgroups resident per CU, the BK = 32 variant (34 KiB LDS) hides that better
+  // enough to actually keep 3-4 workgroups resident per CU, the BK = 32 variant hides that better
   // (measured +13..30 % on those shapes, -15..25 % on grids of <= 320 workgroups).
   {
     const long blocks = (long)cdiv(p.M, BM) * cdiv(p.N, 128) * (FORM == GEMM_TN ? p.taps * p.splitk : 1);
-    if (FORM != GEMM_NT && blocks >= 700) bn = 32;
+    if (FORM != GEMM_NT && blocks >= 700) cfg = 2;
   }
-  if (g_force_cfg) { bn = g_force_cfg / 10; s = g_force_cfg % 10; if (bn == 160 && p.N % 8) bn = 128; }
-  if (bn == 160) return launch_cfg<FORM, CONV, 160, 3, 64>(p, st);
-  if (bn == 32) return launch_cfg<FORM, CONV, 128, 2, 32>(p, st);   // SDXL_GEMM_CFG=322: BK = 32, 3-4 workgroups per CU
-  if (s == 2) return launch_cfg<FORM, CONV, 128, 2, 64>(p, st);
-  return launch_cfg<FORM, CONV, 128, 3, 64>(p, st);
+  // problems that tile into at most two rounds of one 128x160 workgroup per CU (N = 1280 / 640 wide outputs at
+  // M <= 16K rows, the 640- and 1280-channel convs): the 8-wave, 4-deep-ring configuration keeps 3 K-steps of DMA in
+  // flight and wins +15..30 % there (it loses on wider outputs, where two co-resident 128x128 workgroups balance better)
+  {
+    static int c3 = -1;
+    if (c3 < 0) { const char* e = getenv("SDXL_GEMM_C3"); c3 = e ? atoi(e) : 1; }   // bit 0: forward (NT), bit 1: NN / TN (off: a one-per-CU dgrad starves the side stream's wgrad of LDS: 168 vs 152 ms/step)
+    const long t160 = (long)cdiv(p.M, BM) * (p.N / 160) * (FORM == GEMM_TN ? p.taps * p.splitk : 1);
+    const bool en = FORM == GEMM_NT ? (c3 & 1) : (c3 & 2);
+    if (en && p.N % 160 == 0 && t160 <= 512) cfg = 3;
+  }
+  if (g_force_cfg) cfg = g_force_cfg;
+  if (cfg == 3 && p.N % 160 != 0) cfg = 4;
+  switch (cfg) {
+    case 2: return launch_cfg<FORM, CONV, 128, 2, 32, 4>(p, st);
+    case 3: return launch_cfg<FORM, CONV, 160, 4, 64, 8>(p, st);
+    case 4: return launch_cfg<FORM, CONV, 128, 4, 64, 8>(p, st);
+    case 5: return launch_cfg<FORM, CONV, 128, 3, 64, 4>(p, st);
+    default: return launch_cfg<FORM, CONV, 128, 2, 64, 4>(p, st);
+  }
 }
 
 // ---- optional per-launch timing (bench.py roofline): HIP events on the launch stream around every GEMM launch ----
-#include <vector>
 struct GemmProf {
   bool on = false;
   std::vector<hipEvent_t> ev;
