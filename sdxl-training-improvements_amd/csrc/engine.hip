@@ -4,6 +4,7 @@
 #include "engine.h"
 
 #include <stdarg.h>
+#include <stdlib.h>
 
 static thread_local char g_err[1024] = "";
 void sdxl_set_error(const char* fmt, ...) {
@@ -81,7 +82,9 @@ bool Plan::grad_alias(Act* x, Act* y) {
 static int pick_splitk(long out_rows, long out_cols, int taps, long red) {
   long tiles = (long)cdiv(out_rows, 128) * cdiv(out_cols, 128) * taps;
   long ktiles = cdiv(red, 64);
-  long s = 512 / tiles;
+  static long target = -1;
+  if (target < 0) { const char* e = getenv("SDXL_SPLITK_TARGET"); target = e ? atol(e) : 512; }
+  long s = target / tiles;
   if (s < 1) s = 1;
   long maxs = ktiles / 8;
   if (maxs < 1) maxs = 1;

@@ -587,6 +587,10 @@ static int launch_one(const GemmP& p, hipStream_t st) {
     const long t160 = (long)cdiv(p.M, BM) * (p.N / 160) * (FORM == GEMM_TN ? p.taps * p.splitk : 1);
     const bool en = FORM == GEMM_NT ? (c3 & 1) : (c3 & 2);
     if (en && p.N % 160 == 0 && t160 <= 512) cfg = 3;
+    // experimental backward scheme (bit 2): dgrad in a 3-deep 128x160 8-wave ring (109 KiB) that leaves room for one
+    // BK = 32 wgrad workgroup (34 KiB) of the side stream on the same CU
+    if ((c3 & 4) && FORM == GEMM_NN && p.N % 160 == 0 && t160 <= 512) cfg = 6;
+    if ((c3 & 4) && FORM == GEMM_TN) cfg = 2;
   }
   if (g_force_cfg) cfg = g_force_cfg;
   if (cfg == 3 && p.N % 160 != 0) cfg = 4;
@@ -595,6 +599,7 @@ static int launch_one(const GemmP& p, hipStream_t st) {
     case 3: return launch_cfg<FORM, CONV, 160, 4, 64, 8>(p, st);
     case 4: return launch_cfg<FORM, CONV, 128, 4, 64, 8>(p, st);
     case 5: return launch_cfg<FORM, CONV, 128, 3, 64, 4>(p, st);
+    case 6: return launch_cfg<FORM, CONV, 160, 3, 64, 8>(p, st);
     default: return launch_cfg<FORM, CONV, 128, 2, 64, 4>(p, st);
   }
 }
