@@ -62,7 +62,14 @@ int sdxl_create(const sdxl_unet_config* cfg, int device, sdxl_handle** out) {
   const char* ns = getenv("SDXL_NO_SIDE_STREAM");
   h->e.use_side = !(ns && ns[0] == '1');
   if (h->e.use_side) {
-    HIP_CHECK_RET(hipStreamCreateWithFlags(&h->e.side, hipStreamNonBlocking));
+    {  // the side stream carries work that is off the critical path: lowest priority unless SDXL_SIDE_PRIO says otherwise
+      int lo = 0, hi = 0;
+      HIP_CHECK_RET(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      const char* sp = getenv("SDXL_SIDE_PRIO");
+      int mode = sp ? atoi(sp) : 0;     // 0 default priority, 1 lowest, 2 highest
+      int prio = mode == 1 ? lo : (mode == 2 ? hi : 0);
+      HIP_CHECK_RET(hipStreamCreateWithPriority(&h->e.side, hipStreamNonBlocking, prio));
+    }
     HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_join, hipEventDisableTiming));
     HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_hoist, hipEventDisableTiming));
   }

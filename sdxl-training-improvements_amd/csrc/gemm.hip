@@ -583,7 +583,7 @@ static int launch_one(const GemmP& p, hipStream_t st) {
   // flight and wins +15..30 % there (it loses on wider outputs, where two co-resident 128x128 workgroups balance better)
   {
     static int c3 = -1;
-    if (c3 < 0) { const char* e = getenv("SDXL_GEMM_C3"); c3 = e ? atoi(e) : 1; }   // bit 0: forward (NT), bit 1: NN / TN (off: a one-per-CU dgrad starves the side stream's wgrad of LDS: 168 vs 152 ms/step)
+    if (c3 < 0) { const char* e = getenv("SDXL_GEMM_C3"); c3 = e ? atoi(e) : 9; }   // bit 0: forward (NT), bit 1: NN / TN (off: a one-per-CU dgrad starves the side stream's wgrad of LDS: 168 vs 152 ms/step)
     const long t160 = (long)cdiv(p.M, BM) * (p.N / 160) * (FORM == GEMM_TN ? p.taps * p.splitk : 1);
     const bool en = FORM == GEMM_NT ? (c3 & 1) : (c3 & 2);
     if (en && p.N % 160 == 0 && t160 <= 512) cfg = 3;
@@ -591,6 +591,7 @@ static int launch_one(const GemmP& p, hipStream_t st) {
     // BK = 32 wgrad workgroup (34 KiB) of the side stream on the same CU
     if ((c3 & 4) && FORM == GEMM_NN && p.N % 160 == 0 && t160 <= 512) cfg = 6;
     if ((c3 & 4) && FORM == GEMM_TN) cfg = 2;
+    if ((c3 & 8) && FORM == GEMM_TN) cfg = 2;   // experiment: every wgrad in the 34 KiB BK = 32 configuration
   }
   if (g_force_cfg) cfg = g_force_cfg;
   if (cfg == 3 && p.N % 160 != 0) cfg = 4;
