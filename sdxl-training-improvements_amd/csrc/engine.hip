@@ -56,7 +56,9 @@ hipEvent_t Engine::next_event() {
   }
   return ev_pool[ev_used++];
 }
-// run `fn(stream)` for the weight-gradient work of one op: on the side stream once `main` has reached this point
+// run `fn(stream)` for the weight-gradient work of one op: on the side stream once `main` has reached this point.
+// (Batching several ops behind one event record was measured: every step of delay for the side stream lengthens the
+// segment-end join -- 152 / 155 / 158 / 163 / 171 ms per step for batches of 1 / 2 / 4 / 8 / 16 -- so each op gets its own.)
 template <class F>
 static int on_side(Plan& p, hipStream_t main, F&& fn) {
   Engine& e = *p.eng;
@@ -285,8 +287,15 @@ struct LayerNormOp : Op {
   }
   void plan_bwd(Plan& p) override { dy_off = y->goff; dx = p.grad_dst(x); }
   int bwd(Plan& p, hipStream_t st, bool) override {
-    return launch_layernorm_bwd(p.P(x), p.GP(dy_off), p.eng->Wp(gm), p.F(stats_off), p.GP(dx.out), p.GP(dx.addend),
-                                p.eng->Gp(gm), p.eng->Gp(bt), (int)x->rows, C, st);
+    // dgamma / dbeta are leaves: they go to the side stream with the weight gradients
+    static int ln_side = -1;
+    if (ln_side < 0) { const char* e = getenv("SDXL_LN_SIDE"); ln_side = e ? atoi(e) : 0; }   // measured: no gain from moving them off the main stream
+    if (!ln_side) CHK(launch_layernorm_bwd_params(p.P(x), p.GP(dy_off), p.F(stats_off), p.eng->Gp(gm), p.eng->Gp(bt), (int)x->rows, C, st));
+    else CHK(on_side(p, st, [&](hipStream_t s2) -> int {
+      return launch_layernorm_bwd_params(p.P(x), p.GP(dy_off), p.F(stats_off), p.eng->Gp(gm), p.eng->Gp(bt), (int)x->rows, C, s2);
+    }));
+    return launch_layernorm_bwd_dx(p.P(x), p.GP(dy_off), p.eng->Wp(gm), p.F(stats_off), p.GP(dx.out), p.GP(dx.addend),
+                                   (int)x->rows, C, st);
   }
 };
 

@@ -15,11 +15,15 @@
 // (b128 / transpose) agree by construction.  C/D layout: col = l & 15, row = 4*(l>>4) + reg.
 #include "kernels.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <vector>
 
 #define BM 128
+#ifndef GEMM_DIRECT_EPILOGUE
+#define GEMM_DIRECT_EPILOGUE 1   // applies to the fp32 (wgrad) form only: 8-byte bf16 stores measured 4 % slower than staged rows
+#endif
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef __attribute__((address_space(3))) void lds_void;
@@ -110,6 +114,15 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 static constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
+static constexpr int gemm_smem_bytes(int BN, int S, int BK) {
+  int ring = S * (BM + BN) * BK * 2 + 1024, stg = 64 * (BN + 4) * 4;
+  return ring > stg ? ring : stg;
+}
+// workgroups per CU the register budget is sized for: what the 160 KiB of LDS admits, at most 3 (4-wave) / 1 (8-wave)
+static constexpr int gemm_occupancy(int BN, int S, int BK, int NW) {
+  int byl = (160 * 1024) / gemm_smem_bytes(BN, S, BK);
+  return NW == 8 ? 1 : (byl > 3 ? 3 : (byl < 1 ? 1 : byl));
+}
 
 // FORM : GEMM_NT / NN / TN        CONV : implicit-GEMM 3x3 gather
 // BN   : 128 or 160 output columns per workgroup          S : LDS ring depth (S-1 K-steps of DMA in flight)
@@ -118,7 +131,7 @@ static constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
 //        per-lane constant each K-step (0 for out-of-range rows, which keep pointing at the zero vector), and the DMA
 //        pieces are issued between groups of MFMAs so their issue cost hides under the matrix pipe.
 template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (S == 2 ? (BK == 32 ? 3 : 2) : 1))) void gemm_kernel(const GemmP p) {
+__global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_kernel(const GemmP p) {
   constexpr int A_TILE_BYTES = BM * BK * 2;       // [128][BK] or [BK][128] bf16
   constexpr int B_TILE_BYTES = BN * BK * 2;       // [BN][BK] or [BK][BN] bf16
   constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
@@ -135,6 +148,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (S == 2 ? (BK == 32 ? 3 : 2
   constexpr int KC_ROWS = 64 / VR;                // rows of a K-contiguous tile per 1 KiB chunk
   constexpr int LDC = BN + 4;
   constexpr int NT = NW * 64;
+  constexpr bool PIPE = true;
+  constexpr bool DIRECT = GEMM_DIRECT_EPILOGUE && FORM == GEMM_TN;   // operand-swapped products + register -> global epilogue
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -169,6 +184,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (S == 2 ? (BK == 32 ? 3 : 2
   }
   const int n0 = bx * BN;
   const int m0 = by * BM;
+#ifdef SDXL_GEMM_DIAG   // scratch diagnostics only (never defined in the product build): knock out one pipeline component
+  constexpr int dbg = SDXL_GEMM_DIAG;       // bit 0: no MFMA, bit 1: no DMA in the main loop, bit 2: no fragment reads
+#else
+  constexpr int dbg = 0;
+#endif
 
   // reduction schedule
   int tap_fixed = 0, split = 0;
@@ -244,7 +264,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (S == 2 ? (BK == 32 ? 3 : 2
   }
   // FAST: DMA piece `pc` (A chunks first, then B chunks) of the step being staged into ring slot `buf`;
   // live = false re-targets the load at the zero vector (branch-free tail).
+  bool dma_on = true;
   auto issue_piece = [&](int pc, int buf, bool live) {
+    if (dbg && !dma_on) return;
     char* At = smem + buf * STAGE_BYTES;
     char* Bt = At + A_TILE_BYTES;
 #pragma unroll
@@ -372,6 +394,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (S == 2 ? (BK == 32 ? 3 : 2
     }
   }
   int rd = 0, wr = S - 1;  // ring slots: read slot of step t, write slot of step t+S-1
+  if (dbg & 2) dma_on = false;
   for (int t = 0; t < T; ++t) {
     // step t has landed once at most the S-2 later steps' DMAs of this wave are still outstanding ...
     if (FAST) wait_vmcnt<(S - 2) * NL>();                           // FAST issues NL loads for every step, live or not
@@ -382,35 +405,56 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (S == 2 ? (BK == 32 ? 3 : 2
     if (!FAST && live) stage(kt_begin + t + S - 1, wr);
     const char* At = smem + rd * STAGE_BYTES;
     const char* Bt = At + A_TILE_BYTES;
+    // every fragment read of the K-step is issued before its first MFMA (the compiler's counted lgkmcnt waits then
+    // let the ks = 0 products start as soon as their operands land while the ks = 1 reads are still in flight)
+    constexpr int KS = BK / 32;
+    bf16x8 af[KS][MI], bfr[KS][NJ];
+    if (dbg & 4) {
 #pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8 af[MI], bfr[NJ];
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[ks][i] = ones;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bfr[ks][j] = ones;
+      }
+    } else
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         if (FORM == GEMM_TN)
-          af[i] = frag_nc<128>(At, ks * 32 + g * 8, wm * (MI * 16) + i * 16, l16);
+          af[ks][i] = frag_nc<128>(At, ks * 32 + g * 8, wm * (MI * 16) + i * 16, l16);
         else
-          af[i] = frag_kc<BK>(At, wm * (MI * 16) + i * 16 + l16, ks * 4 + g);
-      }
+          af[ks][i] = frag_kc<BK>(At, wm * (MI * 16) + i * 16 + l16, ks * 4 + g);
+        if (i == 0) {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        if (FORM == GEMM_NT)
-          bfr[j] = frag_kc<BK>(Bt, wn * (BN / 2) + j * 16 + l16, ks * 4 + g);
-        else
-          bfr[j] = frag_nc<BN>(Bt, ks * 32 + g * 8, wn * (BN / 2) + j * 16, l16);
+          for (int j = 0; j < NJ; ++j) {
+            if (FORM == GEMM_NT)
+              bfr[ks][j] = frag_kc<BK>(Bt, wn * (BN / 2) + j * 16 + l16, ks * 4 + g);
+            else
+              bfr[ks][j] = frag_nc<BN>(Bt, ks * 32 + g * 8, wn * (BN / 2) + j * 16, l16);
+          }
+        }
       }
+    }
+    if (PIPE) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
       if (FORM == GEMM_TN && do_bias) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+        for (int i = 0; i < MI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], ones, accb[i], 0, 0, 0);
       }
       if (!FAST) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) {
+          if (dbg & 1) acc[i][j][0] += (float)af[ks][i][0] + (float)bfr[ks][j][0];
+          else if (DIRECT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+        }
         if (FAST) {  // one DMA piece per MFMA group
-          constexpr int NSLOT = (BK / 32) * MI;
+          constexpr int NSLOT = KS * MI;
           const int slot = ks * MI + i;
 #pragma unroll
           for (int pc = 0; pc < NL; ++pc)
@@ -422,8 +466,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (S == 2 ? (BK == 32 ? 3 : 2
     rd = rd + 1 == S ? 0 : rd + 1;
     wr = wr + 1 == S ? 0 : wr + 1;
   }
-  wait_vmcnt<0>();
-  __syncthreads();  // all fragment reads (and padding DMA) done before the ring is reused as the fp32 staging tile
+  wait_vmcnt<0>();   // padding / tail DMA pieces must not outlive the workgroup's LDS allocation
   if (FORM == GEMM_TN && do_bias && l16 == 0) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -433,7 +476,56 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (S == 2 ? (BK == 32 ? 3 : 2
         if (m < p.M) atomicAdd(p.bias_grad + m, accb[i][r]);
       }
   }
-
+  if (DIRECT) {
+    // ---- epilogue, registers -> global: the products were issued with the operands swapped (D^T layout), so lane
+    // (l16, g) holds C[m = 16 i + l16][n = 16 j + 4 g .. + 3]: 4 contiguous columns = one 8-byte (bf16) or 16-byte
+    // (fp32) store per fragment, no LDS staging and no workgroup barrier
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wm * (MI * 16) + i * 16 + l16;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 16 + g * 4;
+        if (n >= p.N) continue;
+        f32x4 x = acc[i][j];
+        if (p.out_f32) {
+          float* c = (float*)p.C + (long)m * p.ldc + (long)tap_fixed * p.c_tap_stride + n;
+          if (p.splitk > 1) {
+            *(f32x4*)(p.slab + ((long)split * p.M + m) * p.slab_ld + (long)tap_fixed * p.c_tap_stride + n) = x;
+          } else if (p.accumulate) {
+            f32x4 a = *(f32x4*)c;
+            a[0] += x[0]; a[1] += x[1]; a[2] += x[2]; a[3] += x[3];
+            *(f32x4*)c = a;
+          } else {
+            *(f32x4*)c = x;
+          }
+        } else {
+          if (p.bias) {
+            bf16x4 bv = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] += (float)bv[e];
+          }
+          if (p.rowvec) {
+            bf16x4 tv = *(const bf16x4*)(p.rowvec + (long)(m / p.rows_per_batch) * p.ldv + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] += (float)tv[e];
+          }
+          if (p.resid) {
+            bf16x4 rv = *(const bf16x4*)(p.resid + (long)m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] += (float)rv[e];
+          }
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (bf16)x[e];
+          *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) = o;
+        }
+      }
+    }
+    return;
+  }
+  __syncthreads();  // all fragment reads (and padding DMA) done before the ring is reused as the fp32 staging tile
   // ---- epilogue: stage the fp32 tile in LDS 64 rows at a time (34-42 KiB), then row-contiguous 16-byte stores ----
   float* Cs = (float*)smem;
   constexpr int VPR = BN / 8;  // 8-column vectors per tile row
@@ -530,11 +622,6 @@ void gemm_defaults(GemmP* p) {
   p->rows_per_batch = 1;
 }
 
-static constexpr int gemm_smem_bytes(int BN, int S, int BK) {
-  int ring = S * (BM + BN) * BK * 2 + 1024, stg = 64 * (BN + 4) * 4;
-  return ring > stg ? ring : stg;
-}
-
 template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW>
 static int launch_k(const GemmP& p, hipStream_t st) {
   static bool attr_set = false;
@@ -571,27 +658,27 @@ static int launch_one(const GemmP& p, hipStream_t st) {
     g_force_cfg = e ? atoi(e) : 0;
   }
   int cfg = 1;
-  // the transpose-read forms (dgrad / wgrad) spend twice the LDS-read issue slots per K-step: when the grid is large
-  // enough to actually keep 3-4 workgroups resident per CU, the BK = 32 variant hides that better
-  // (measured +13..30 % on those shapes, -15..25 % on grids of <= 320 workgroups).
-  {
-    const long blocks = (long)cdiv(p.M, BM) * cdiv(p.N, 128) * (FORM == GEMM_TN ? p.taps * p.splitk : 1);
-    if (FORM != GEMM_NT && blocks >= 700) cfg = 2;
+  static int c3 = -1, tn_cfg = 2, nn_small = 1, nn_big = 2;
+  if (c3 < 0) {
+    const char* e = getenv("SDXL_GEMM_C3");
+    c3 = e ? atoi(e) : 1;
+    if ((e = getenv("SDXL_GEMM_TN_CFG"))) tn_cfg = atoi(e);
+    if ((e = getenv("SDXL_GEMM_NN_SMALL"))) nn_small = atoi(e);
+    if ((e = getenv("SDXL_GEMM_NN_BIG"))) nn_big = atoi(e);
   }
-  // problems that tile into at most two rounds of one 128x160 workgroup per CU (N = 1280 / 640 wide outputs at
-  // M <= 16K rows, the 640- and 1280-channel convs): the 8-wave, 4-deep-ring configuration keeps 3 K-steps of DMA in
-  // flight and wins +15..30 % there (it loses on wider outputs, where two co-resident 128x128 workgroups balance better)
+  const long blocks = (long)cdiv(p.M, BM) * cdiv(p.N, 128) * (FORM == GEMM_TN ? p.taps * p.splitk : 1);
+  // the transpose-read forms (dgrad / wgrad) spend twice the LDS-read issue slots per K-step: BK = 32 variants with
+  // 3-4 workgroups per CU hide that better on large grids; wgrad runs beside dgrad on the side stream and is kept in
+  // a small-LDS configuration so that both co-reside on a CU
+  if (FORM == GEMM_NN) cfg = blocks >= 700 ? nn_big : nn_small;
+  if (FORM == GEMM_TN) cfg = tn_cfg;
+  // forward problems that tile into at most two rounds of one 128x160 workgroup per CU (N = 1280 / 640 wide outputs
+  // at M <= 16K rows, the 640- and 1280-channel convs): the 8-wave, 4-deep-ring configuration keeps 3 K-steps of DMA
+  // in flight and wins +15..30 % there.  Not for dgrad / wgrad: a one-per-CU workgroup on one stream starves the
+  // other stream's kernels of LDS (168 vs 152 ms/step).
   {
-    static int c3 = -1;
-    if (c3 < 0) { const char* e = getenv("SDXL_GEMM_C3"); c3 = e ? atoi(e) : 9; }   // bit 0: forward (NT), bit 1: NN / TN (off: a one-per-CU dgrad starves the side stream's wgrad of LDS: 168 vs 152 ms/step)
-    const long t160 = (long)cdiv(p.M, BM) * (p.N / 160) * (FORM == GEMM_TN ? p.taps * p.splitk : 1);
-    const bool en = FORM == GEMM_NT ? (c3 & 1) : (c3 & 2);
-    if (en && p.N % 160 == 0 && t160 <= 512) cfg = 3;
-    // experimental backward scheme (bit 2): dgrad in a 3-deep 128x160 8-wave ring (109 KiB) that leaves room for one
-    // BK = 32 wgrad workgroup (34 KiB) of the side stream on the same CU
-    if ((c3 & 4) && FORM == GEMM_NN && p.N % 160 == 0 && t160 <= 512) cfg = 6;
-    if ((c3 & 4) && FORM == GEMM_TN) cfg = 2;
-    if ((c3 & 8) && FORM == GEMM_TN) cfg = 2;   // experiment: every wgrad in the 34 KiB BK = 32 configuration
+    const long t160 = (long)cdiv(p.M, BM) * (p.N / 160);
+    if (FORM == GEMM_NT && (c3 & 1) && p.N % 160 == 0 && t160 <= 512) cfg = 3;
   }
   if (g_force_cfg) cfg = g_force_cfg;
   if (cfg == 3 && p.N % 160 != 0) cfg = 4;
@@ -601,6 +688,9 @@ static int launch_one(const GemmP& p, hipStream_t st) {
     case 4: return launch_cfg<FORM, CONV, 128, 4, 64, 8>(p, st);
     case 5: return launch_cfg<FORM, CONV, 128, 3, 64, 4>(p, st);
     case 6: return launch_cfg<FORM, CONV, 160, 3, 64, 8>(p, st);
+    case 7: return launch_cfg<FORM, CONV, 128, 4, 32, 4>(p, st);
+    case 8: return launch_cfg<FORM, CONV, 128, 3, 32, 4>(p, st);
+    case 9: return launch_cfg<FORM, CONV, 128, 6, 32, 8>(p, st);
     default: return launch_cfg<FORM, CONV, 128, 2, 64, 4>(p, st);
   }
 }
@@ -611,6 +701,8 @@ struct GemmProf {
   std::vector<hipEvent_t> ev;
   size_t used = 0;
   std::vector<double> flops;
+  struct Rec { int form, taps, M, N, K, splitk; };
+  std::vector<Rec> recs;
 };
 static GemmProf g_prof;
 bool gemm_profiling() { return g_prof.on; }
@@ -618,18 +710,26 @@ int gemm_profile_begin() {
   g_prof.on = true;
   g_prof.used = 0;
   g_prof.flops.clear();
+  g_prof.recs.clear();
   return 0;
 }
 int gemm_profile_end(double* flops, double* ms, int* launches) {
   g_prof.on = false;
   double f = 0, t = 0;
   HIP_CHECK_RET(hipDeviceSynchronize());
+  FILE* dump = nullptr;   // SDXL_GEMM_PROF_DUMP=<path>: per-launch records (appended), for shape-level analysis
+  if (const char* dp = getenv("SDXL_GEMM_PROF_DUMP")) dump = fopen(dp, "a");
   for (size_t i = 0; i < g_prof.flops.size(); ++i) {
     float e = 0.f;
     HIP_CHECK_RET(hipEventElapsedTime(&e, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
     t += e;
     f += g_prof.flops[i];
+    if (dump) {
+      const GemmProf::Rec& r = g_prof.recs[i];
+      fprintf(dump, "%d,%d,%d,%d,%d,%d,%.4f\n", r.form, r.taps, r.M, r.N, r.K, r.splitk, e);
+    }
   }
+  if (dump) fclose(dump);
   if (flops) *flops = f;
   if (ms) *ms = t;
   if (launches) *launches = (int)g_prof.flops.size();
@@ -648,6 +748,7 @@ int launch_gemm(const GemmP& p, hipStream_t st) {
   HIP_CHECK_RET(hipEventRecord(g_prof.ev[g_prof.used + 1], st));
   g_prof.used += 2;
   g_prof.flops.push_back(2.0 * (double)p.M * (double)p.N * (double)p.K * (double)p.taps);
+  g_prof.recs.push_back({p.form, p.taps, p.M, p.N, p.K, p.splitk});
   return rc;
 }
 

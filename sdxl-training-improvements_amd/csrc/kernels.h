@@ -101,6 +101,11 @@ int launch_layernorm_fwd(const bf16* x, bf16* y, const bf16* gamma, const bf16* 
                          int C, float eps, hipStream_t st);
 int launch_layernorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const float* stats, bf16* dx,
                          const bf16* addend, float* dgamma, float* dbeta, int M, int C, hipStream_t st);
+// the two halves of the above: dx on the critical path, the parameter gradients (a leaf) wherever there is room
+int launch_layernorm_bwd_dx(const bf16* x, const bf16* dy, const bf16* gamma, const float* stats, bf16* dx,
+                            const bf16* addend, int M, int C, hipStream_t st);
+int launch_layernorm_bwd_params(const bf16* x, const bf16* dy, const float* stats, float* dgamma, float* dbeta, int M,
+                                int C, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
 // elementwise / small (elementwise.hip)

@@ -518,6 +518,19 @@ static void col_reduce_geom(int M, int C, dim3* grid, int* rows_per_chunk) {
 
 int launch_layernorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const float* stats, bf16* dx,
                          const bf16* addend, float* dgamma, float* dbeta, int M, int C, hipStream_t st) {
+  int rc = launch_layernorm_bwd_dx(x, dy, gamma, stats, dx, addend, M, C, st);
+  return rc ? rc : launch_layernorm_bwd_params(x, dy, stats, dgamma, dbeta, M, C, st);
+}
+int launch_layernorm_bwd_params(const bf16* x, const bf16* dy, const float* stats, float* dgamma, float* dbeta, int M,
+                                int C, hipStream_t st) {
+  dim3 g2; int rpc;
+  col_reduce_geom(M, C, &g2, &rpc);
+  hipLaunchKernelGGL(col_reduce_kernel, g2, dim3(256), 0, st, x, dy, (long)C, stats, dgamma, dbeta, M, C, rpc);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int launch_layernorm_bwd_dx(const bf16* x, const bf16* dy, const bf16* gamma, const float* stats, bf16* dx,
+                            const bf16* addend, int M, int C, hipStream_t st) {
   ARG_CHECK(C % 128 == 0, "layernorm bwd: C=%d must be a multiple of 128", C);
   const int accumulate = addend != nullptr;
   dim3 grid(cdiv(M, 16)), blk(256);
@@ -531,9 +544,6 @@ int launch_layernorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const
 #undef LN_CASE
     default: ARG_CHECK(false, "layernorm bwd: C=%d not instantiated", C);
   }
-  dim3 g2; int rpc;
-  col_reduce_geom(M, C, &g2, &rpc);
-  hipLaunchKernelGGL(col_reduce_kernel, g2, dim3(256), 0, st, x, dy, (long)C, stats, dgamma, dbeta, M, C, rpc);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
