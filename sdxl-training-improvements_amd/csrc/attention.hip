@@ -11,7 +11,7 @@
 //   slot (g, j<4)  <-> row 32t + 4g + j         slot (g, j>=4) <-> row 32t + 16 + 4g + (j-4)
 // used identically by the register operand (packed scores) and the transpose-read operand.
 //
-// Kernels: attn_fwd (O, LSE) ; attn_delta (rowsum dO*O) ; attn_bwd_dq ; attn_bwd_dkv.
+// Kernels: attn_fwd (O, LSE) ; attn_bwd_dq (also Delta = rowsum dO*O) ; attn_bwd_dkv (+ its split-query reduce).
 #include "kernels.h"
 
 #define HD 64
@@ -202,28 +202,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Delta[bh][q] = sum_d dO[q][d] * O[q][d]   (one 16-lane group per row: 4 elements per lane)
-// ------------------------------------------------------------------------------------------------
-__global__ void attn_delta_kernel(const AttnP p) {
-  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);  // over B*H*Nq
-  const int sub = threadIdx.x & 15;
-  const long total = (long)p.B * p.H * p.Nq;
-  float s = 0.f;
-  long bh = 0; int q = 0;
-  if (row < total) {
-    bh = row / p.Nq; q = row - bh * p.Nq;
-    int b = bh / p.H, h = bh - b * p.H;
-    bf16x4 o = *(const bf16x4*)(p.O + ((long)b * p.Nq + q) * p.ldo + h * HD + sub * 4);
-    bf16x4 d = *(const bf16x4*)(p.dO + ((long)b * p.Nq + q) * p.lddo + h * HD + sub * 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) s += (float)o[e] * (float)d[e];
-  }
-  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
-  if (row < total && sub == 0) p.Delta[row] = s;
-}
-
-// ------------------------------------------------------------------------------------------------
 // dQ: same orientation as forward.  dQ^T[d][q] = scale * K^T . dS^T,  dS^T = P^T o (dP^T - Delta)
+// Delta[bh][q] = sum_d dO[q][d] * O[q][d] is computed here from the dO fragments the kernel holds anyway (each lane
+// has 16 of the row's 64 d; two cross-lane steps finish the sum) and stored for the dK/dV kernel that follows.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE_ELEMS];
@@ -232,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   const int q0 = blockIdx.x * 128 + wave * 32;
   const bf16* Qb = p.Q + (long)b * p.Nq * p.ldq + h * HD;
   const bf16* dOb = p.dO + (long)b * p.Nq * p.lddo + h * HD;
+  const bf16* Ob = p.O + (long)b * p.Nq * p.ldo + h * HD;
   const bf16* Kb = p.K + (long)b * p.Nk * p.ldk + h * HD;
   const bf16* Vb = p.V + (long)b * p.Nk * p.ldv + h * HD;
 
@@ -241,13 +223,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   for (int qb = 0; qb < 2; ++qb) {
     int q = q0 + qb * 16 + l16;
     bool ok = q < p.Nq;
+    float dl = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       qf[qb][ks] = ok ? *(const bf16x8*)(Qb + (long)q * p.ldq + ks * 32 + g * 8) : z8();
       df[qb][ks] = ok ? *(const bf16x8*)(dOb + (long)q * p.lddo + ks * 32 + g * 8) : z8();
+      bf16x8 of = ok ? *(const bf16x8*)(Ob + (long)q * p.ldo + ks * 32 + g * 8) : z8();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += (float)df[qb][ks][e] * (float)of[e];
     }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
     lse2[qb] = ok ? p.LSE[(long)bh * p.Nq + q] * LOG2E : 0.f;
-    delta[qb] = ok ? p.Delta[(long)bh * p.Nq + q] : 0.f;
+    delta[qb] = dl;
+    if (ok && g == 0) p.Delta[(long)bh * p.Nq + q] = dl;
   }
   f32x4 dq[4][2];
 #pragma unroll
@@ -497,10 +486,8 @@ int launch_attn_fwd(const AttnP& p, hipStream_t st) {
 
 int launch_attn_bwd(const AttnP& p, hipStream_t st) {
   if (int e = check_attn(p)) return e;
-  ARG_CHECK(p.dO && p.dQ && p.dK && p.dV && p.LSE && p.Delta, "attention bwd: missing buffers");
+  ARG_CHECK(p.O && p.dO && p.dQ && p.dK && p.dV && p.LSE && p.Delta, "attention bwd: missing buffers");
   ARG_CHECK(!p.accumulate, "attention bwd: accumulate not implemented");
-  long rows = (long)p.B * p.H * p.Nq;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(rows, 16)), dim3(256), 0, st, p);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(cdiv(p.Nq, 128), p.B * p.H), dim3(256), 0, st, p);
   AttnP q = p;
   if (q.qsplit < 1 || !q.part) q.qsplit = 1;

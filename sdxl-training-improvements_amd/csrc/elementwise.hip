@@ -10,55 +10,6 @@ static inline int ew_grid(long nvec) {
 }
 #define VEC_LOOP(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
 
-// ------------------------------------------------------------------ GEGLU
-__global__ void geglu_fwd_kernel(const bf16* __restrict__ u, bf16* __restrict__ g, long M, int C4) {
-  const int vpr = C4 / 8;
-  VEC_LOOP(i, M * vpr) {
-    long r = i / vpr;
-    int c = (int)(i - r * vpr) * 8;
-    bf16x8 a = *(const bf16x8*)(u + r * 2 * C4 + c);
-    bf16x8 t = *(const bf16x8*)(u + r * 2 * C4 + C4 + c);
-    bf16x8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)a[e] * gelu_f((float)t[e]));
-    *(bf16x8*)(g + r * C4 + c) = o;
-  }
-}
-__global__ void geglu_bwd_kernel(const bf16* __restrict__ u, const bf16* __restrict__ dg, bf16* __restrict__ du,
-                                 long M, int C4) {
-  const int vpr = C4 / 8;
-  VEC_LOOP(i, M * vpr) {
-    long r = i / vpr;
-    int c = (int)(i - r * vpr) * 8;
-    bf16x8 a = *(const bf16x8*)(u + r * 2 * C4 + c);
-    bf16x8 t = *(const bf16x8*)(u + r * 2 * C4 + C4 + c);
-    bf16x8 d = *(const bf16x8*)(dg + r * C4 + c);
-    bf16x8 oa, ot;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float tv = (float)t[e], dv = (float)d[e];
-      oa[e] = (bf16)(dv * gelu_f(tv));
-      ot[e] = (bf16)(dv * (float)a[e] * gelu_grad_f(tv));
-    }
-    *(bf16x8*)(du + r * 2 * C4 + c) = oa;
-    *(bf16x8*)(du + r * 2 * C4 + C4 + c) = ot;
-  }
-}
-int launch_geglu_fwd(const bf16* u, bf16* g, int M, int C4, hipStream_t st) {
-  ARG_CHECK(C4 % 8 == 0, "geglu: C4=%d", C4);
-  long nv = (long)M * (C4 / 8);
-  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, u, g, (long)M, C4);
-  HIP_CHECK_RET(hipGetLastError());
-  return 0;
-}
-int launch_geglu_bwd(const bf16* u, const bf16* dg, bf16* du, int M, int C4, hipStream_t st) {
-  ARG_CHECK(C4 % 8 == 0, "geglu: C4=%d", C4);
-  long nv = (long)M * (C4 / 8);
-  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, u, dg, du, (long)M, C4);
-  HIP_CHECK_RET(hipGetLastError());
-  return 0;
-}
-
 // ------------------------------------------------------------------ SiLU / add (flat, n % 8 == 0)
 __global__ void silu_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, long nvec) {
   VEC_LOOP(i, nvec) {

@@ -106,6 +106,10 @@ struct LinearOp : Op {
   int resid_alias = 0, splitk = 1;
   size_t dy_off = NONE;
   Plan::GradDst dx, dres;
+  // GEGLU feed-forward pair (GemmP::geglu): the first projection (y = u, interleaved value | gate columns) also
+  // writes gact = value * gelu(gate); the second projection (x = gact) turns its input gradient straight into dU
+  Act* gact = nullptr;   // first projection: fused activation output [rows][N/2]
+  Act* gu = nullptr;     // second projection: the first projection's pre-activation u [rows][2K]
   LinearOp(Act* x_, Act* y_, PRef w_, PRef b_, int K_, int N_, Act* resid_) : x(x_), y(y_), resid(resid_), w(w_), b(b_), K(K_), N(N_) {}
   int fwd(Plan& p, hipStream_t st) override {
     GemmP g;
@@ -116,6 +120,7 @@ struct LinearOp : Op {
     g.lda = K; g.ldb = K; g.ldc = N;
     g.bias = b.off == NONE ? nullptr : p.eng->Wp(b);
     if (resid) { g.resid = p.P(resid); g.ldr = N; }
+    if (gact) { g.geglu = 1; g.aux = p.P(gact); g.ldaux = N / 2; }
     return launch_gemm(g, st);
   }
   void plan_bwd(Plan& p) override {
@@ -124,13 +129,15 @@ struct LinearOp : Op {
       resid_alias = p.grad_alias(resid, y) ? 1 : 0;
       if (!resid_alias) dres = p.grad_dst(resid);
     }
-    if (x->need_grad) dx = p.grad_dst(x);
+    if (gu) dx = p.grad_dst(gu);           // the activation itself gets no gradient buffer: dgrad emits dU
+    else if (x->need_grad) dx = p.grad_dst(x);
     splitk = pick_splitk(N, K, 1, x->rows);
     want_slab(p, N, K, 1, splitk);
   }
   int bwd(Plan& p, hipStream_t st, bool first) override {
     const bf16* dy = p.GP(dy_off);
     const int M = (int)x->rows;
+    if (gu && dx.addend != NONE) { sdxl_set_error("geglu: pre-activation gradient has another writer"); return 3; }
     if (resid && !resid_alias) CHK(launch_add(p.GP(dres.addend), dy, p.GP(dres.out), (long)M * N, st));
     CHK(on_side(p, st, [&](hipStream_t s2) -> int {
       GemmP g;
@@ -154,7 +161,8 @@ struct LinearOp : Op {
       g.A = dy; g.B = p.eng->Wp(w); g.C = p.GP(dx.out);
       g.M = M; g.N = K; g.K = N;
       g.lda = N; g.ldb = K; g.ldc = K;
-      if (dx.addend != NONE) { g.resid = p.GP(dx.addend); g.ldr = K; }
+      if (gu) { g.geglu = 2; g.aux = p.P(gu); g.ldaux = 2L * K; g.ldc = 2L * K; }
+      else if (dx.addend != NONE) { g.resid = p.GP(dx.addend); g.ldr = K; }
       CHK(launch_gemm(g, st));
     }
     return 0;
@@ -362,21 +370,6 @@ struct AttnOp : Op {
   }
 };
 
-struct GegluOp : Op {
-  Act *u, *g;
-  int C4;
-  bool bad = false;
-  size_t dg_off = NONE;
-  Plan::GradDst du;
-  GegluOp(Act* u_, Act* g_, int C4_) : u(u_), g(g_), C4(C4_) {}
-  int fwd(Plan& p, hipStream_t st) override { return launch_geglu_fwd(p.P(u), p.P(g), (int)u->rows, C4, st); }
-  void plan_bwd(Plan& p) override { dg_off = g->goff; du = p.grad_dst(u); if (du.addend != NONE) bad = true; }
-  int bwd(Plan& p, hipStream_t st, bool) override {
-    if (bad) { sdxl_set_error("geglu: operand gradient has another writer"); return 3; }
-    return launch_geglu_bwd(p.P(u), p.GP(dg_off), p.GP(du.out), (int)u->rows, C4, st);
-  }
-};
-
 struct SiluOp : Op {
   Act *x, *y;
   size_t dy_off = NONE;
@@ -491,15 +484,18 @@ struct Builder {
     return op;
   }
   // ---- layers ----
-  Act* linear(const std::string& name, Act* x, int K, int N, bool bias, Act* resid, bool conv1x1 = false) {
+  // kind 2: GEGLU first projection, rows (and bias) packed value | gate interleaved in groups of 64 (repack_kernel)
+  Act* linear(const std::string& name, Act* x, int K, int N, bool bias, Act* resid, bool conv1x1 = false, int kind = 0,
+              LinearOp** op_out = nullptr) {
     PRef w = e.param((size_t)N * K);
     if (conv1x1) e.map_src(name + ".weight", {N, K, 1, 1}, w, 0, 0, 0);
-    else e.map_src(name + ".weight", {N, K}, w, 0, 0, 0);
+    else e.map_src(name + ".weight", {N, K}, w, kind, 0, 0);
     PRef b;
-    if (bias) { b = e.param(N, true); e.map_src(name + ".bias", {N}, b, 0, 0, 0); }
+    if (bias) { b = e.param(N, true); e.map_src(name + ".bias", {N}, b, kind, 0, 0); }
     if (!pl) return nullptr;
     Act* y = pl->new_act(x->rows, N);
-    tagseg(pl->add<LinearOp>(x, y, w, b, K, N, resid), w);
+    LinearOp* op = tagseg(pl->add<LinearOp>(x, y, w, b, K, N, resid), w);
+    if (op_out) *op_out = op;
     return y;
   }
   // fused projection of several [Ni, K] source matrices into one [sum Ni, K] native matrix (no bias)
@@ -584,13 +580,15 @@ struct Builder {
     }
     Act* x2 = linear(b + ".attn2.to_out.0", a2, C, C, true, x1);
     Act* l3 = layernorm(b + ".norm3", x2, C);
-    Act* u = linear(b + ".ff.net.0.proj", l3, C, 8 * C, true, nullptr);
-    Act* g = nullptr;
-    if (pl) {
-      g = pl->new_act(x->rows, 4 * C);
-      tagseg(pl->add<GegluOp>(u, g, 4 * C), PRef());
-    }
-    return linear(b + ".ff.net.2", g, 4 * C, C, true, x2);
+    // feed-forward: GEGLU lives in the epilogues of the two projections (forward: value * gelu(gate) next to u;
+    // backward: the second projection's dgrad writes dU directly), no separate activation pass
+    LinearOp *ff1 = nullptr, *ff2 = nullptr;
+    Act* u = linear(b + ".ff.net.0.proj", l3, C, 8 * C, true, nullptr, false, 2, &ff1);
+    Act* g = pl ? pl->new_act(x->rows, 4 * C) : nullptr;
+    if (ff1) ff1->gact = g;
+    Act* y = linear(b + ".ff.net.2", g, 4 * C, C, true, x2, false, 0, &ff2);
+    if (ff2) ff2->gu = u;
+    return y;
   }
   Act* transformer(const std::string& p, Act* x, Act* ehs, int h, int w_, int C, int depth) {
     Act* n = groupnorm(p + ".norm", x, h * w_, C, e.cfg.tf_gn_eps, 0);
@@ -726,6 +724,8 @@ template <typename TS, typename TD>
 __global__ void repack_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long n, int kind, int co, int ci,
                               int ci_pad, int to_native) {
   // kind 0: flat copy.  kind 1: src [co][ci][3][3] <-> native [co][9][ci_pad]
+  // kind 2: GEGLU projection, src rows [value 0..C4) | gate 0..C4)] <-> native rows interleaved in groups of 64:
+  //         channel c -> value row (c/64)*128 + c%64, gate row +64   (co = 2*C4 rows of ci elements; bias: ci = 1)
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     long s = i, d = i;
     if (kind == 1) {
@@ -733,6 +733,11 @@ __global__ void repack_kernel(const TS* __restrict__ src, TD* __restrict__ dst, 
       long rem = i - o * (long)ci * 9;
       int c = (int)(rem / 9), tap = (int)(rem - (long)c * 9);
       long nat = (o * 9 + tap) * ci_pad + c;
+      if (to_native) { s = i; d = nat; } else { s = nat; d = i; }
+    } else if (kind == 2) {
+      const long r = i / ci, k = i - r * ci;
+      const int c4 = co / 2, half = (int)(r / c4), c = (int)(r - (long)half * c4);
+      const long nat = ((long)(c >> 6) * 128 + half * 64 + (c & 63)) * ci + k;
       if (to_native) { s = i; d = nat; } else { s = nat; d = i; }
     }
     dst[d] = (TD)(float)src[s];

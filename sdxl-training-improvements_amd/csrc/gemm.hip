@@ -542,6 +542,51 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
             Cs[(wrow - half * 64 + i * 16 + g * 4 + r) * LDC + wn * (BN / 2) + j * 16 + l16] = acc[i][j][r];
     }
     __syncthreads();
+    if (FORM != GEMM_TN && BN == 128 && p.geglu) {
+      // GEGLU fused epilogues (see GemmP): both operate on the bf16-rounded values, exactly like a separate pass would
+      for (int id = tid; id < 64 * VPR; id += NT) {
+        const int row = id / VPR, col = (id - row * VPR) * 8;
+        const int m = m0 + half * 64 + row;
+        if (m >= p.M) continue;
+        if (FORM == GEMM_NT) {          // forward: this tile = value | gate halves of 64 channels
+          if (col >= 64 || n0 + col >= p.N) continue;
+          const int na = n0 + col, nt = na + 64;
+          float xa[8], xt[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { xa[e] = Cs[row * LDC + col + e]; xt[e] = Cs[row * LDC + 64 + col + e]; }
+          if (p.bias) {
+            bf16x8 ba = *(const bf16x8*)(p.bias + na), bt = *(const bf16x8*)(p.bias + nt);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xa[e] += (float)ba[e]; xt[e] += (float)bt[e]; }
+          }
+          bf16x8 oa, ot, og;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            oa[e] = (bf16)xa[e];
+            ot[e] = (bf16)xt[e];
+            og[e] = (bf16)((float)oa[e] * gelu_f((float)ot[e]));
+          }
+          *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + na) = oa;
+          *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + nt) = ot;
+          *(bf16x8*)(p.aux + (long)m * p.ldaux + (n0 >> 1) + col) = og;
+        } else {                        // dgrad of the second projection: dG tile -> dU (value and gate halves)
+          const int n = n0 + col;
+          if (n >= p.N) continue;
+          const long cu = (long)(n >> 6) * 128 + (n & 63);
+          bf16x8 ua = *(const bf16x8*)(p.aux + (long)m * p.ldaux + cu);
+          bf16x8 ut = *(const bf16x8*)(p.aux + (long)m * p.ldaux + cu + 64);
+          bf16x8 oa, ot;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float dv = (float)(bf16)Cs[row * LDC + col + e], tv = (float)ut[e];
+            oa[e] = (bf16)(dv * gelu_f(tv));
+            ot[e] = (bf16)(dv * (float)ua[e] * gelu_grad_f(tv));
+          }
+          *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + cu) = oa;
+          *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + cu + 64) = ot;
+        }
+      }
+    } else
     for (int id = tid; id < 64 * VPR; id += NT) {
       int row = id / VPR, col = (id - row * VPR) * 8;
       int m = m0 + half * 64 + row, n = n0 + col;
@@ -681,6 +726,7 @@ static int launch_one(const GemmP& p, hipStream_t st) {
     if (FORM == GEMM_NT && (c3 & 1) && p.N % 160 == 0 && t160 <= 512) cfg = 3;
   }
   if (g_force_cfg) cfg = g_force_cfg;
+  if (p.geglu && (cfg == 3 || cfg == 6)) cfg = 1;   // the fused GEGLU epilogues need 128-column tiles
   if (cfg == 3 && p.N % 160 != 0) cfg = 4;
   switch (cfg) {
     case 2: return launch_cfg<FORM, CONV, 128, 2, 32, 4>(p, st);
@@ -769,6 +815,15 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
     ARG_CHECK(!p.out_f32 && p.splitk == 1, "gemm NT/NN: bf16 output, no split-K");
     ARG_CHECK(p.ldc % 8 == 0, "gemm: ldc=%ld must be a multiple of 8", p.ldc);
     if (p.accumulate) { p.resid = (const bf16*)p.C; p.ldr = p.ldc; }
+    if (p.geglu) {
+      ARG_CHECK((p.geglu == 1 && p.form == GEMM_NT && p.N % 128 == 0) || (p.geglu == 2 && p.form == GEMM_NN && p.N % 64 == 0),
+                "gemm: geglu mode %d does not fit form %d / N=%d", p.geglu, p.form, p.N);
+      ARG_CHECK(p.aux && p.ldaux % 8 == 0 && ((uintptr_t)p.aux & 15) == 0 && p.taps == 1, "gemm: geglu needs an aligned aux matrix");
+      ARG_CHECK(!p.resid && !p.rowvec && (p.geglu == 1 || !p.bias), "gemm: geglu epilogue takes no residual / row vector");
+    }
+  }
+  if (p.form == GEMM_TN) {
+    ARG_CHECK(!p.geglu, "gemm TN: no geglu epilogue");
   }
   if (p.splitk < 1) p.splitk = 1;
   {

@@ -35,6 +35,15 @@ struct GemmP {
   const bf16* rowvec;
   long ldv;
   int rows_per_batch;
+  // GEGLU fused into the feed-forward GEMMs (bf16 output forms, 128-column tiles).  The 2*C4 columns of the first
+  // projection are stored interleaved in groups of 64: column (c/64)*128 + c%64 is the value half of channel c,
+  // +64 its gate half (the weight rows are packed in the same order), so one tile holds both halves of 64 channels.
+  //   geglu == 1 (NT, N = 2*C4):  C = u (pre-activation, kept for the backward), aux[m][c] = value * gelu(gate)
+  //   geglu == 2 (NN, N = C4):    acc = dG;  C[m][2*C4] = dU from aux = u:  d value = dG * gelu(gate),
+  //                                                                        d gate  = dG * value * gelu'(gate)
+  int geglu;
+  bf16* aux;
+  long ldaux;
   // fp32 output (wgrad): C_f32 (+)= acc.  splitk > 1: each split writes its partial [M][N*taps] tile set to
   // slab[split] (plain stores) and a reduce kernel sums the slabs in a fixed order (deterministic, no atomics);
   // the conv form requires C to be the dense [M][taps*N] weight-gradient matrix (ldc == N*taps).
@@ -110,8 +119,6 @@ int launch_layernorm_bwd_params(const bf16* x, const bf16* dy, const float* stat
 // ------------------------------------------------------------------------------------------------
 // elementwise / small (elementwise.hip)
 // ------------------------------------------------------------------------------------------------
-int launch_geglu_fwd(const bf16* u, bf16* g, int M, int C4, hipStream_t st);            // u [M][2*C4]
-int launch_geglu_bwd(const bf16* u, const bf16* dg, bf16* du, int M, int C4, hipStream_t st);
 int launch_silu_fwd(const bf16* x, bf16* y, long n, hipStream_t st);
 int launch_silu_bwd(const bf16* x, const bf16* dy, bf16* dx, const bf16* addend, long n, hipStream_t st);
 int launch_add(const bf16* a, const bf16* b, bf16* o, long n, hipStream_t st);           // o = a + b

@@ -72,8 +72,8 @@ SIGNATURES = {
     "sdxl_op_groupnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "sdxl_op_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "sdxl_op_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "sdxl_op_geglu_fwd": [_vp, _vp, _i, _i, _vp],
-    "sdxl_op_geglu_bwd": [_vp, _vp, _vp, _i, _i, _vp],
+    "sdxl_op_ff_geglu_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "sdxl_op_ff_geglu_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sdxl_op_loss": [_P(LossConfig), _P(Batch), _vp, _vp, _vp, _f, _vp, _i, _vp],
     "sdxl_probe_layout": [_vp, _vp],
     "sdxl_profile_gemm_begin": [],

@@ -273,20 +273,42 @@ def test_layernorm_fwd_bwd(L, M, Cc):
     report("layernorm dbeta", db, br.grad, 2e-3)
 
 
-@pytest.mark.parametrize("M,C4", [(64, 256), (308, 2560)])
-def test_geglu_fwd_bwd(L, M, C4):
-    u = rnd(M, 2 * C4, seed=60)
+def geglu_pack_rows(t, C4):
+    """[2*C4, ...] source order (value rows | gate rows) -> the library's packed order (groups of 64 interleaved)."""
+    a, g = t[:C4], t[C4:]
+    shp = t.shape[1:]
+    return torch.stack([a.reshape(C4 // 64, 64, *shp), g.reshape(C4 // 64, 64, *shp)], 1).reshape(2 * C4, *shp).contiguous()
+
+
+def geglu_unpack_cols(u, C4):
+    """[M, 2*C4] packed columns -> source order (value | gate)."""
+    M = u.shape[0]
+    v = u.reshape(M, C4 // 64, 2, 64)
+    return torch.cat([v[:, :, 0].reshape(M, C4), v[:, :, 1].reshape(M, C4)], 1)
+
+
+@pytest.mark.parametrize("M,K,C4", [(64, 128, 256), (308, 320, 1280), (4096, 1280, 5120)])
+def test_ff_geglu_fused_fwd_bwd(L, M, K, C4):
+    """GEGLU fused into the two feed-forward projections (reference: diffusers GEGLU, ff.net.0.proj -> ff.net.2)."""
+    x = rnd(M, K, seed=60)
+    w1, b1 = rnd(2 * C4, K, seed=61, scale=K ** -0.5), rnd(2 * C4, seed=62, scale=0.1)
+    w2 = rnd(K, C4, seed=63, scale=C4 ** -0.5)
+    dy = rnd(M, K, seed=64)
+    u = torch.empty(M, 2 * C4, dtype=torch.bfloat16, device=dev())
     g = torch.empty(M, C4, dtype=torch.bfloat16, device=dev())
-    lib.check(L.sdxl_op_geglu_fwd(ptr(u), ptr(g), M, C4, stream()))
-    ur = u.float().requires_grad_(True)
-    a, t = ur.chunk(2, -1)
-    ref = a * torch.nn.functional.gelu(t)
-    report("geglu fwd", g, ref.detach(), 6e-3)
-    dg = rnd(M, C4, seed=61)
-    ref.backward(dg.float())
+    w1p, b1p = geglu_pack_rows(w1, C4), geglu_pack_rows(b1, C4)     # keep alive until the launch has been enqueued
+    lib.check(L.sdxl_op_ff_geglu_fwd(ptr(x), ptr(w1p), ptr(b1p), ptr(u), ptr(g), M, K, C4, stream()))
+    ur = (x.float() @ w1.float().t() + b1.float())
+    report("ff geglu: u", geglu_unpack_cols(u, C4), ur, 6e-3)
+    ub = geglu_unpack_cols(u, C4).float().requires_grad_(True)      # backward reference from the stored bf16 u
+    a, t = ub.chunk(2, -1)
+    gr = a * torch.nn.functional.gelu(t)
+    report("ff geglu: g", g, gr.detach(), 6e-3)
+    dg = dy.float() @ w2.float()
+    gr.backward(dg)
     du = torch.empty_like(u)
-    lib.check(L.sdxl_op_geglu_bwd(ptr(u), ptr(dg), ptr(du), M, C4, stream()))
-    report("geglu bwd", du, ur.grad, 8e-3)
+    lib.check(L.sdxl_op_ff_geglu_bwd(ptr(dy), ptr(w2), ptr(u), ptr(du), M, K, C4, stream()))
+    report("ff geglu: du", geglu_unpack_cols(du, C4), ub.grad, 1e-2)
 
 
 @pytest.mark.parametrize("method", [0, 1])
