@@ -55,10 +55,28 @@ __device__ __forceinline__ float silu_grad_f(float x) {
   float s = 1.f / (1.f + __expf(-x));
   return s * (1.f + x * (1.f - s));
 }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// exact (erf) GELU pieces in ~14 instructions: Phi(x) and phi(x) share one exponential.
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7, far below bf16 resolution): with z = |x| / sqrt(2),
+//   erf(z) = 1 - (a1 k + a2 k^2 + a3 k^3 + a4 k^4 + a5 k^5) exp(-z^2),  k = 1 / (1 + 0.3275911 z)
+__device__ __forceinline__ void gelu_cdf_pdf(float x, float* cdf, float* pdf) {
+  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);      // exp(-x^2 / 2)
+  const float k = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.23164189f, 1.f));    // 0.3275911 / sqrt(2)
+  float q = fmaf(k, 1.061405429f, -1.453152027f);
+  q = fmaf(k, q, 1.421413741f);
+  q = fmaf(k, q, -0.284496736f);
+  q = fmaf(k, q, 0.254829592f);
+  const float h = 0.5f - 0.5f * (q * k * e);                                    // erf(|x|/sqrt2) / 2
+  *cdf = 0.5f + copysignf(h, x);
+  *pdf = 0.39894228040143268f * e;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float c, d;
+  gelu_cdf_pdf(x, &c, &d);
+  return x * c;
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
-  float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float c, d;
+  gelu_cdf_pdf(x, &c, &d);
+  return c + x * d;
 }
 #endif

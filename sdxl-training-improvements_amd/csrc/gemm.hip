@@ -579,8 +579,10 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float dv = (float)(bf16)Cs[row * LDC + col + e], tv = (float)ut[e];
-            oa[e] = (bf16)(dv * gelu_f(tv));
-            ot[e] = (bf16)(dv * (float)ua[e] * gelu_grad_f(tv));
+            float cdf, pdf;
+            gelu_cdf_pdf(tv, &cdf, &pdf);
+            oa[e] = (bf16)(dv * tv * cdf);
+            ot[e] = (bf16)(dv * (float)ua[e] * fmaf(tv, pdf, cdf));
           }
           *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + cu) = oa;
           *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + cu + 64) = ot;
