@@ -127,7 +127,8 @@ static constexpr int gemm_occupancy(int BN, int S, int BK, int NW) {
 // FORM : GEMM_NT / NN / TN        CONV : implicit-GEMM 3x3 gather
 // BN   : 128 or 160 output columns per workgroup          S : LDS ring depth (S-1 K-steps of DMA in flight)
 // BK   : 64 or 32 reduction elements per K-step           NW: waves per workgroup (4: 2x2, 8: 4x2)
-// FAST : non-conv, reduction length a multiple of BK: every lane's DMA source is a running pointer advanced by a
+// FAST : reduction length a multiple of BK and either no gather or a same-size stride-1 3x3 gather: every lane's DMA
+//        source is a running pointer (conv: fixed base + uniform offset + border predicate) advanced by a
 //        per-lane constant each K-step (0 for out-of-range rows, which keep pointing at the zero vector), and the DMA
 //        pieces are issued between groups of MFMAs so their issue cost hides under the matrix pipe.
 template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW>
@@ -211,18 +212,29 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
   // N-contiguous tile of width Wd: chunk c = vectors 64c..64c+63 of the [BK][Wd/8] vector grid
   const int kc_rowl = lane / VR, kc_pv = lane % VR;
   PixRow arow[ACH];
-  if (CONV && FORM != GEMM_TN) {
+  if (CONV && !FAST && FORM != GEMM_TN) {
 #pragma unroll
     for (int j = 0; j < ACH; ++j) arow[j] = decode_pix(m0 + (wave + j * NW) * KC_ROWS + kc_rowl, p.M, p.Hm, p.Wm);
   }
   const bf16* zsrc = (const bf16*)g_zero16;
   char* const pad_dst = smem + RING_BYTES;   // 1 KiB: destination of the padding pieces
 
-  // FAST path state: running source pointers + per-lane step (elements) for this wave's chunks
+  // FAST path state.  Linear: running source pointers + per-lane step (elements) for this wave's chunks.
+  // Conv (same-size stride-1 3x3, Cin a multiple of BK): fixed per-lane base pointers + a wave-uniform offset that
+  // follows (tap, channel step) [NT / NN] or the pixel step [TN]; the border zero-fill is a per-lane 9-bit tap mask
+  // [NT / NN: the gathered rows are this workgroup's fixed output pixels] or an incrementally tracked (y, x) of the
+  // gathered pixel [TN: the reduction runs over pixels, the tap is fixed per workgroup].
+  constexpr bool CF = FAST && CONV;
   const bf16* pa[ACH];
   const bf16* pb[BCH];
   long sa[ACH], sb[BCH];
-  if (FAST) {
+  int amask[ACH];            // CF: NT / NN tap-validity mask of the A rows; TN: static validity of the dY columns
+  int bok[BCH];              // CF: static validity of the B lanes (column in range)
+  int by_[BCH], bx_[BCH];    // CF, TN: (y, x) of the pixel this lane gathers at the step being staged
+  long ua = 0, ub = 0;       // CF: uniform element offsets of the step being staged
+  int s_tap = 0, s_c = 0;    // CF, NT / NN: (tap, channel step) of the step being staged
+  const int tdy = tap_fixed / 3 - 1, tdx = tap_fixed - (tap_fixed / 3) * 3 - 1;   // CF, TN: this workgroup's tap
+  if (FAST && !CONV) {
 #pragma unroll
     for (int j = 0; j < ACH; ++j) {
       const int c = wave + j * NW;
@@ -262,6 +274,84 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
       }
     }
   }
+  if (CF) {
+#pragma unroll
+    for (int j = 0; j < ACH; ++j) {
+      const int c = wave + j * NW;
+      if (FORM == GEMM_TN) {
+        const int krow = c * 4 + (lane >> 4);
+        const int m = m0 + (nc_logical<128>(krow, lane & 15) << 3);
+        amask[j] = (c < NCA && m < p.M) ? 1 : 0;
+        pa[j] = p.A + ((long)kt_begin * BK + krow) * p.lda + m;
+      } else {
+        const int row = c * KC_ROWS + kc_rowl;
+        const int m = m0 + row;
+        const PixRow r = decode_pix(m, p.M, p.Hm, p.Wm);
+        int mask = 0;
+        if (c < NCA && r.ok) {
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const int ys = r.y + t / 3 - 1, xs = r.x + t % 3 - 1;
+            if (ys >= 0 && ys < p.Hm && xs >= 0 && xs < p.Wm) mask |= 1 << t;
+          }
+        }
+        amask[j] = mask;
+        pa[j] = p.A + (long)m * p.lda + ((kc_pv ^ kc_swz<BK>(row)) << 3);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BCH; ++j) {
+      const int c = wave + j * NW;
+      if (FORM == GEMM_NT) {
+        const int row = c * KC_ROWS + kc_rowl;
+        const int n = n0 + row;
+        bok[j] = (c < NCB && n < p.N) ? 1 : 0;
+        pb[j] = p.B + (long)n * p.ldb + ((kc_pv ^ kc_swz<BK>(row)) << 3);
+      } else {
+        constexpr int V = BN / 8;
+        const int q = c * 64 + lane;
+        const int krow = q / V, pv = q - krow * V;
+        const int n = n0 + (nc_logical<BN>(krow, pv) << 3);
+        bok[j] = (c < NCB && n < p.N) ? 1 : 0;
+        if (FORM == GEMM_NN) {
+          pb[j] = p.B + (long)krow * p.ldb + n;
+        } else {
+          const long kk0 = (long)kt_begin * BK + krow;           // first gathered pixel of this lane
+          const PixRow r = decode_pix((int)kk0, p.K, p.Hm, p.Wm);
+          by_[j] = r.y;
+          bx_[j] = r.x;
+          pb[j] = p.B + (kk0 + tdy * p.Wm + tdx) * p.ldb + n;    // only dereferenced where the tap is in bounds
+        }
+      }
+    }
+    if (FORM != GEMM_TN) {
+      ua = -(long)(p.Wm + 1) * p.lda;                            // tap 0 = (-1, -1)
+      ub = (long)(p.flip ? p.taps - 1 : 0) * p.b_tap_stride;
+    }
+  }
+  // CF: move the uniform state to the next K-step (called once all pieces of a step have been issued)
+  auto advance = [&]() {
+    if (!CF) return;
+    if (FORM == GEMM_TN) {
+      ua += (long)BK * p.lda;
+      ub += (long)BK * p.ldb;
+      const int dxs = BK % p.Wm, dys = BK / p.Wm;
+#pragma unroll
+      for (int j = 0; j < BCH; ++j) {
+        bx_[j] += dxs;
+        if (bx_[j] >= p.Wm) { bx_[j] -= p.Wm; by_[j] += 1; }
+        by_[j] += dys;
+        if (by_[j] >= p.Hm) by_[j] -= p.Hm;
+      }
+    } else {
+      if (++s_c == ktiles_per_tap) { s_c = 0; ++s_tap; }
+      const int dy = s_tap / 3 - 1, dx = s_tap - (s_tap / 3) * 3 - 1;
+      const int wtap = p.flip ? p.taps - 1 - s_tap : s_tap;
+      ua = (long)(dy * p.Wm + dx) * p.lda + (long)s_c * BK;
+      if (FORM == GEMM_NT) ub = (long)wtap * p.b_tap_stride + (long)s_c * BK;
+      else ub = (long)wtap * p.b_tap_stride + (long)s_c * BK * p.ldb;
+    }
+  };
   // FAST: DMA piece `pc` (A chunks first, then B chunks) of the step being staged into ring slot `buf`;
   // live = false re-targets the load at the zero vector (branch-free tail).
   bool dma_on = true;
@@ -273,19 +363,35 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
     for (int j = 0; j < ACH; ++j)
       if (pc == j) {
         const int c = wave + j * NW;
-        const bf16* src = live ? pa[j] : zsrc;
+        const bf16* src;
+        if (CF) {
+          const bool v = live && (FORM == GEMM_TN ? amask[j] != 0 : ((amask[j] >> s_tap) & 1) != 0);
+          src = v ? pa[j] + ua : zsrc;
+        } else {
+          src = live ? pa[j] : zsrc;
+        }
         char* dst = (NCA % NW == 0 || c < NCA) ? At + c * 1024 : pad_dst;
         __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
-        pa[j] += sa[j];
+        if (!CF) pa[j] += sa[j];
       }
 #pragma unroll
     for (int j = 0; j < BCH; ++j)
       if (pc == ACH + j) {
         const int c = wave + j * NW;
-        const bf16* src = live ? pb[j] : zsrc;
+        const bf16* src;
+        if (CF) {
+          bool v = live && bok[j] != 0;
+          if (FORM == GEMM_TN) {
+            const int ys = by_[j] + tdy, xs = bx_[j] + tdx;
+            v = v && ys >= 0 && ys < p.Hm && xs >= 0 && xs < p.Wm;
+          }
+          src = v ? pb[j] + ub : zsrc;
+        } else {
+          src = live ? pb[j] : zsrc;
+        }
         char* dst = (NCB % NW == 0 || c < NCB) ? Bt + c * 1024 : pad_dst;
         __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
-        pb[j] += sb[j];
+        if (!CF) pb[j] += sb[j];
       }
   };
 
@@ -363,6 +469,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
     if (FAST) {
 #pragma unroll
       for (int pc = 0; pc < NL; ++pc) issue_piece(pc, buf, true);   // steps are staged in increasing order
+      advance();
     } else {
       stage_gen(kt, buf);
     }
@@ -391,6 +498,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
     else if (FAST) {                       // keep the vmcnt arithmetic uniform: same number of loads every step
 #pragma unroll
       for (int pc = 0; pc < NL; ++pc) issue_piece(pc, d, false);
+      advance();
     }
   }
   int rd = 0, wr = S - 1;  // ring slots: read slot of step t, write slot of step t+S-1
@@ -463,6 +571,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
       }
       if (!FAST) __builtin_amdgcn_s_setprio(0);
     }
+    if (FAST) advance();   // every piece of step t + S - 1 has been issued
     rd = rd + 1 == S ? 0 : rd + 1;
     wr = wr + 1 == S ? 0 : wr + 1;
   }
@@ -686,8 +795,12 @@ static int launch_k(const GemmP& p, hipStream_t st) {
 template <int FORM, bool CONV, int BN, int S, int BK, int NW>
 static int launch_cfg(const GemmP& p, hipStream_t st) {
   static int nofast = -1;
-  if (nofast < 0) nofast = getenv("SDXL_GEMM_NOFAST") ? 1 : 0;
-  if (!CONV && p.K % BK == 0 && !nofast) return launch_k<FORM, false, BN, S, BK, true, NW>(p, st);
+  if (nofast < 0) { const char* e = getenv("SDXL_GEMM_NOFAST"); nofast = e ? atoi(e) : 0; }   // 1: all, 2: conv only
+  if (!CONV && p.K % BK == 0 && nofast != 1) return launch_k<FORM, false, BN, S, BK, true, NW>(p, st);
+  // same-size stride-1 3x3 convolutions (all but the two downsamplers, their transposed dgrads and conv_in)
+  if (CONV && nofast == 0 && p.taps == 9 && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws && p.K % BK == 0 &&
+      true)
+    return launch_k<FORM, true, BN, S, BK, true, NW>(p, st);
   return launch_k<FORM, CONV, BN, S, BK, false, NW>(p, st);
 }
 
@@ -705,11 +818,12 @@ static int launch_one(const GemmP& p, hipStream_t st) {
     g_force_cfg = e ? atoi(e) : 0;
   }
   int cfg = 1;
-  static int c3 = -1, tn_cfg = 2, nn_small = 1, nn_big = 2;
+  static int c3 = -1, tn_cfg = 2, tnc_cfg = 2, nn_small = 1, nn_big = 2;
   if (c3 < 0) {
     const char* e = getenv("SDXL_GEMM_C3");
     c3 = e ? atoi(e) : 1;
     if ((e = getenv("SDXL_GEMM_TN_CFG"))) tn_cfg = atoi(e);
+    if ((e = getenv("SDXL_GEMM_TNC_CFG"))) tnc_cfg = atoi(e);
     if ((e = getenv("SDXL_GEMM_NN_SMALL"))) nn_small = atoi(e);
     if ((e = getenv("SDXL_GEMM_NN_BIG"))) nn_big = atoi(e);
   }
@@ -718,7 +832,7 @@ static int launch_one(const GemmP& p, hipStream_t st) {
   // 3-4 workgroups per CU hide that better on large grids; wgrad runs beside dgrad on the side stream and is kept in
   // a small-LDS configuration so that both co-reside on a CU
   if (FORM == GEMM_NN) cfg = blocks >= 700 ? nn_big : nn_small;
-  if (FORM == GEMM_TN) cfg = tn_cfg;
+  if (FORM == GEMM_TN) cfg = CONV ? tnc_cfg : tn_cfg;
   // forward problems that tile into at most two rounds of one 128x160 workgroup per CU (N = 1280 / 640 wide outputs
   // at M <= 16K rows, the 640- and 1280-channel convs): the 8-wave, 4-deep-ring configuration keeps 3 K-steps of DMA
   // in flight and wins +15..30 % there.  Not for dgrad / wgrad: a one-per-CU workgroup on one stream starves the
