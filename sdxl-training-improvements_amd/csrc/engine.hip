@@ -85,7 +85,7 @@ static int pick_splitk(long out_rows, long out_cols, int taps, long red) {
   long tiles = (long)cdiv(out_rows, 128) * cdiv(out_cols, 128) * taps;
   long ktiles = cdiv(red, 64);
   static long target = -1;
-  if (target < 0) { const char* e = getenv("SDXL_SPLITK_TARGET"); target = e ? atol(e) : 512; }
+  if (target < 0) { const char* e = getenv("SDXL_SPLITK_TARGET"); target = e ? atol(e) : 384; }
   long s = target / tiles;
   if (s < 1) s = 1;
   long maxs = ktiles / 8;

@@ -818,7 +818,7 @@ static int launch_one(const GemmP& p, hipStream_t st) {
     g_force_cfg = e ? atoi(e) : 0;
   }
   int cfg = 1;
-  static int c3 = -1, tn_cfg = 2, tnc_cfg = 2, nn_small = 1, nn_big = 2;
+  static int c3 = -1, tn_cfg = 1, tnc_cfg = 1, nn_small = 1, nn_big = 2;
   if (c3 < 0) {
     const char* e = getenv("SDXL_GEMM_C3");
     c3 = e ? atoi(e) : 1;
