@@ -503,6 +503,73 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
   }
   int rd = 0, wr = S - 1;  // ring slots: read slot of step t, write slot of step t+S-1
   if (dbg & 2) dma_on = false;
+  constexpr int KS = BK / 32;
+  struct Frags { bf16x8 a[KS][MI], b[KS][NJ]; };
+  // every fragment read of a K-step is issued in one go (the compiler's counted lgkmcnt waits then let the ks = 0
+  // products start as soon as their operands land while the ks = 1 reads are still in flight)
+  auto read_frags = [&](int slot, Frags& f) {
+    const char* At = smem + slot * STAGE_BYTES;
+    const char* Bt = At + A_TILE_BYTES;
+    if (dbg & 4) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) f.a[ks][i] = ones;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) f.b[ks][j] = ones;
+      }
+      return;
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        if (FORM == GEMM_TN)
+          f.a[ks][i] = frag_nc<128>(At, ks * 32 + g * 8, wm * (MI * 16) + i * 16, l16);
+        else
+          f.a[ks][i] = frag_kc<BK>(At, wm * (MI * 16) + i * 16 + l16, ks * 4 + g);
+        if (i == 0) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            if (FORM == GEMM_NT)
+              f.b[ks][j] = frag_kc<BK>(Bt, wn * (BN / 2) + j * 16 + l16, ks * 4 + g);
+            else
+              f.b[ks][j] = frag_nc<BN>(Bt, ks * 32 + g * 8, wn * (BN / 2) + j * 16, l16);
+          }
+        }
+      }
+    }
+  };
+  // the K-step's products; FAST: the DMA pieces of step t + S - 1 (ring slot `wslot`) ride between the MFMA groups
+  auto mfma_step = [&](const Frags& f, int wslot, bool live) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (FORM == GEMM_TN && do_bias) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[ks][i], ones, accb[i], 0, 0, 0);
+      }
+      if (!FAST) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (dbg & 1) acc[i][j][0] += (float)f.a[ks][i][0] + (float)f.b[ks][j][0];
+          else if (DIRECT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b[ks][j], f.a[ks][i], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[ks][i], f.b[ks][j], acc[i][j], 0, 0, 0);
+        }
+        if (FAST) {  // one DMA piece per MFMA group
+          constexpr int NSLOT = KS * MI;
+          const int slot = ks * MI + i;
+#pragma unroll
+          for (int pc = 0; pc < NL; ++pc)
+            if (pc % NSLOT == slot) issue_piece(pc, wslot, live);
+        }
+      }
+      if (!FAST) __builtin_amdgcn_s_setprio(0);
+    }
+  };
+  // (A register-prefetch variant -- fragments of step t + 1 read while the products of step t run, one ring slot
+  // fewer in flight -- was measured on the S >= 3 configurations: 5-20 % slower, so the loop stays as it is.)
   for (int t = 0; t < T; ++t) {
     // step t has landed once at most the S-2 later steps' DMAs of this wave are still outstanding ...
     if (FAST) wait_vmcnt<(S - 2) * NL>();                           // FAST issues NL loads for every step, live or not
@@ -511,66 +578,10 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
     __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave has finished reading slot `wr` (step t-1)
     const bool live = t + S - 1 < T;
     if (!FAST && live) stage(kt_begin + t + S - 1, wr);
-    const char* At = smem + rd * STAGE_BYTES;
-    const char* Bt = At + A_TILE_BYTES;
-    // every fragment read of the K-step is issued before its first MFMA (the compiler's counted lgkmcnt waits then
-    // let the ks = 0 products start as soon as their operands land while the ks = 1 reads are still in flight)
-    constexpr int KS = BK / 32;
-    bf16x8 af[KS][MI], bfr[KS][NJ];
-    if (dbg & 4) {
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) af[ks][i] = ones;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) bfr[ks][j] = ones;
-      }
-    } else
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        if (FORM == GEMM_TN)
-          af[ks][i] = frag_nc<128>(At, ks * 32 + g * 8, wm * (MI * 16) + i * 16, l16);
-        else
-          af[ks][i] = frag_kc<BK>(At, wm * (MI * 16) + i * 16 + l16, ks * 4 + g);
-        if (i == 0) {
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            if (FORM == GEMM_NT)
-              bfr[ks][j] = frag_kc<BK>(Bt, wn * (BN / 2) + j * 16 + l16, ks * 4 + g);
-            else
-              bfr[ks][j] = frag_nc<BN>(Bt, ks * 32 + g * 8, wn * (BN / 2) + j * 16, l16);
-          }
-        }
-      }
-    }
+    Frags f;
+    read_frags(rd, f);
     if (PIPE) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (FORM == GEMM_TN && do_bias) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], ones, accb[i], 0, 0, 0);
-      }
-      if (!FAST) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          if (dbg & 1) acc[i][j][0] += (float)af[ks][i][0] + (float)bfr[ks][j][0];
-          else if (DIRECT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
-          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
-        }
-        if (FAST) {  // one DMA piece per MFMA group
-          constexpr int NSLOT = KS * MI;
-          const int slot = ks * MI + i;
-#pragma unroll
-          for (int pc = 0; pc < NL; ++pc)
-            if (pc % NSLOT == slot) issue_piece(pc, wr, live);
-        }
-      }
-      if (!FAST) __builtin_amdgcn_s_setprio(0);
-    }
+    mfma_step(f, wr, live);
     if (FAST) advance();   // every piece of step t + S - 1 has been issued
     rd = rd + 1 == S ? 0 : rd + 1;
     wr = wr + 1 == S ? 0 : wr + 1;
