@@ -319,27 +319,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 // S[q][key] = Q . K^T so that each lane owns one key column; P / dS feed dV^T = dO^T . P and
 // dK^T = Q^T . dS as B operands, dO^T / Q^T come from transpose reads of the row-major tiles.
 // ------------------------------------------------------------------------------------------------
+// KB = 16-key column blocks per wave: 2 for self attention (block = 128 keys; every Q / dO fragment read from LDS
+// feeds two key blocks, halving the LDS traffic per MFMA), 1 for the split-query cross-attention form.
+template <int KB>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
   // ONE LDS object (a second one makes hipcc drain the LDS-DMA before every ds_read): Q0 dO0 Q1 dO1 | stats
   __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE_ELEMS + 512];
   float (*sstat)[2][64] = (float (*)[2][64])(sm + 4 * TILE_ELEMS);                                   // [buf][lse2|delta][q]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l16 = lane & 15, g = lane >> 4;
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
-  const int key = blockIdx.x * 64 + wave * 16 + l16;  // this lane's key column
+  const int key0 = blockIdx.x * (64 * KB) + wave * (16 * KB) + l16;  // this lane's key column of block kb: key0 + 16 kb
   const bf16* Qb = p.Q + (long)b * p.Nq * p.ldq + h * HD;
   const bf16* dOb = p.dO + (long)b * p.Nq * p.lddo + h * HD;
   const bf16* Kb = p.K + (long)b * p.Nk * p.ldk + h * HD;
   const bf16* Vb = p.V + (long)b * p.Nk * p.ldv + h * HD;
-  const bool kok = key < p.Nk;
-  bf16x8 kf[2], vf[2];  // B operands: [k=d][col=key]
+  bool kok[KB];
+  bf16x8 kf[KB][2], vf[KB][2];  // B operands: [k=d][col=key]
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    kf[ks] = kok ? *(const bf16x8*)(Kb + (long)key * p.ldk + ks * 32 + g * 8) : z8();
-    vf[ks] = kok ? *(const bf16x8*)(Vb + (long)key * p.ldv + ks * 32 + g * 8) : z8();
+  for (int kb = 0; kb < KB; ++kb) {
+    const int key = key0 + kb * 16;
+    kok[kb] = key < p.Nk;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kf[kb][ks] = kok[kb] ? *(const bf16x8*)(Kb + (long)key * p.ldk + ks * 32 + g * 8) : z8();
+      vf[kb][ks] = kok[kb] ? *(const bf16x8*)(Vb + (long)key * p.ldv + ks * 32 + g * 8) : z8();
+    }
   }
-  f32x4 dk[4], dv[4];
+  f32x4 dk[KB][4], dv[KB][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dk[kb][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[kb][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   const float c = SCALE * LOG2E;
 
   const int ntiles_all = (p.Nq + 63) / 64;
@@ -370,65 +380,81 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     }
     const bf16* Qt = sm + (buf * 2) * TILE_ELEMS;
     const bf16* Dt = Qt + TILE_ELEMS;
-    f32x4 s[4], dp[4];
+    f32x4 s[KB][4], dp[KB][4];
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) {
       bf16x8 a0 = ld_frag(Qt, qb * 16 + l16, g * 8), a1 = ld_frag(Qt, qb * 16 + l16, 32 + g * 8);
       bf16x8 d0 = ld_frag(Dt, qb * 16 + l16, g * 8), d1 = ld_frag(Dt, qb * 16 + l16, 32 + g * 8);
-      f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, kf[0], a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, kf[1], a, 0, 0, 0);
-      s[qb] = a;
-      f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
-      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, vf[0], d, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, vf[1], d, 0, 0, 0);
-      dp[qb] = d;
-    }
-    f32x4 pr[4];
 #pragma unroll
-    for (int qb = 0; qb < 4; ++qb) {
-      f32x4 l2 = *(const f32x4*)&sstat[buf][0][qb * 16 + g * 4];
-      f32x4 dl = *(const f32x4*)&sstat[buf][1][qb * 16 + g * 4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int q = t * 64 + qb * 16 + g * 4 + r;
-        float e = (q < p.Nq && kok) ? __builtin_amdgcn_exp2f(s[qb][r] * c - l2[r]) : 0.f;
-        pr[qb][r] = e;
-        s[qb][r] = e * (dp[qb][r] - dl[r]) * SCALE;
+      for (int kb = 0; kb < KB; ++kb) {
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, kf[kb][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, kf[kb][1], a, 0, 0, 0);
+        s[kb][qb] = a;
+        f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, vf[kb][0], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, vf[kb][1], d, 0, 0, 0);
+        dp[kb][qb] = d;
       }
     }
-    bf16x8 pf[2] = {pack8(pr[0], pr[1]), pack8(pr[2], pr[3])};
-    bf16x8 dsf[2] = {pack8(s[0], s[1]), pack8(s[2], s[3])};
+    bf16x8 pf[KB][2], dsf[KB][2];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      f32x4 pr[4];
+#pragma unroll
+      for (int qb = 0; qb < 4; ++qb) {
+        f32x4 l2 = *(const f32x4*)&sstat[buf][0][qb * 16 + g * 4];
+        f32x4 dl = *(const f32x4*)&sstat[buf][1][qb * 16 + g * 4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int q = t * 64 + qb * 16 + g * 4 + r;
+          float e = (q < p.Nq && kok[kb]) ? __builtin_amdgcn_exp2f(s[kb][qb][r] * c - l2[r]) : 0.f;
+          pr[qb][r] = e;
+          s[kb][qb][r] = e * (dp[kb][qb][r] - dl[r]) * SCALE;
+        }
+      }
+      pf[kb][0] = pack8(pr[0], pr[1]);
+      pf[kb][1] = pack8(pr[2], pr[3]);
+      dsf[kb][0] = pack8(s[kb][0], s[kb][1]);
+      dsf[kb][1] = pack8(s[kb][2], s[kb][3]);
+    }
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
         bf16x8 dot = tr_frag(Dt, t2, db * 16, l16, g);
-        dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf[t2], dv[db], 0, 0, 0);
         bf16x8 qt = tr_frag(Qt, t2, db * 16, l16, g);
-        dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf[t2], dk[db], 0, 0, 0);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          dv[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf[kb][t2], dv[kb][db], 0, 0, 0);
+          dk[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf[kb][t2], dk[kb][db], 0, 0, 0);
+        }
       }
     if (more && tid < 128) sstat[buf ^ 1][tid >> 6][tid & 63] = rs;
     buf ^= 1;
   }
-  if (p.qsplit > 1) {   // fp32 partials: part[z][bh][key_local][2][64]
-    const int kvt = (p.Nk + 63) / 64;
-    float* base = p.part + ((((long)blockIdx.z * gridDim.y + bh) * kvt * 64 + (blockIdx.x * 64 + wave * 16 + l16)) * 2) * 64;
 #pragma unroll
-    for (int db = 0; db < 4; ++db) {
-      *(f32x4*)(base + db * 16 + g * 4) = dk[db];
-      *(f32x4*)(base + 64 + db * 16 + g * 4) = dv[db];
-    }
-  } else if (kok) {
-    bf16* kr = p.dK + ((long)b * p.Nk + key) * p.lddk + h * HD;
-    bf16* vr = p.dV + ((long)b * p.Nk + key) * p.lddv + h * HD;
+  for (int kb = 0; kb < KB; ++kb) {
+    const int key = key0 + kb * 16;
+    if (p.qsplit > 1) {   // fp32 partials: part[z][bh][key][2][64]
+      const int kvt = (p.Nk + 63) / 64;
+      float* base = p.part + ((((long)blockIdx.z * gridDim.y + bh) * kvt * 64 + key) * 2) * 64;
 #pragma unroll
-    for (int db = 0; db < 4; ++db) {
-      bf16x4 a, c2;
+      for (int db = 0; db < 4; ++db) {
+        *(f32x4*)(base + db * 16 + g * 4) = dk[kb][db];
+        *(f32x4*)(base + 64 + db * 16 + g * 4) = dv[kb][db];
+      }
+    } else if (kok[kb]) {
+      bf16* kr = p.dK + ((long)b * p.Nk + key) * p.lddk + h * HD;
+      bf16* vr = p.dV + ((long)b * p.Nk + key) * p.lddv + h * HD;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { a[r] = (bf16)dk[db][r]; c2[r] = (bf16)dv[db][r]; }
-      *(bf16x4*)(kr + db * 16 + g * 4) = a;
-      *(bf16x4*)(vr + db * 16 + g * 4) = c2;
+      for (int db = 0; db < 4; ++db) {
+        bf16x4 a, c2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a[r] = (bf16)dk[kb][db][r]; c2[r] = (bf16)dv[kb][db][r]; }
+        *(bf16x4*)(kr + db * 16 + g * 4) = a;
+        *(bf16x4*)(vr + db * 16 + g * 4) = c2;
+      }
     }
   }
 }
@@ -491,7 +517,11 @@ int launch_attn_bwd(const AttnP& p, hipStream_t st) {
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(cdiv(p.Nq, 128), p.B * p.H), dim3(256), 0, st, p);
   AttnP q = p;
   if (q.qsplit < 1 || !q.part) q.qsplit = 1;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(cdiv(p.Nk, 64), p.B * p.H, q.qsplit), dim3(256), 0, st, q);
+  // two key blocks per wave when the 128-key workgroups still fill the chip twice over
+  if (q.qsplit == 1 && (long)cdiv(p.Nk, 128) * p.B * p.H >= 512)
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, dim3(cdiv(p.Nk, 128), p.B * p.H, 1), dim3(256), 0, st, q);
+  else
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, dim3(cdiv(p.Nk, 64), p.B * p.H, q.qsplit), dim3(256), 0, st, q);
   if (q.qsplit > 1) {
     long total = (long)p.B * p.H * p.Nk * 32;
     hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, q);
