@@ -22,7 +22,7 @@
 
 #define BM 128
 #ifndef GEMM_DIRECT_EPILOGUE
-#define GEMM_DIRECT_EPILOGUE 1   // applies to the fp32 (wgrad) form only: 8-byte bf16 stores measured 4 % slower than staged rows
+#define GEMM_DIRECT_EPILOGUE 1
 #endif
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
   constexpr int LDC = BN + 4;
   constexpr int NT = NW * 64;
   constexpr bool PIPE = true;
-  constexpr bool DIRECT = GEMM_DIRECT_EPILOGUE && FORM == GEMM_TN;   // operand-swapped products + register -> global epilogue
+  constexpr bool DIRECT = GEMM_DIRECT_EPILOGUE;   // operand-swapped products (D^T layout) + register -> global epilogue
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -596,22 +596,71 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
         if (m < p.M) atomicAdd(p.bias_grad + m, accb[i][r]);
       }
   }
-  if (DIRECT) {
-    // ---- epilogue, registers -> global: the products were issued with the operands swapped (D^T layout), so lane
-    // (l16, g) holds C[m = 16 i + l16][n = 16 j + 4 g .. + 3]: 4 contiguous columns = one 8-byte (bf16) or 16-byte
-    // (fp32) store per fragment, no LDS staging and no workgroup barrier
+  // ---- epilogue, registers -> global.  The products were issued with the operands swapped (D^T layout), so lane
+  // (l16, g) holds C[m = 16 i + l16][n = 16 j + 4 g .. + 3]: no LDS staging, no workgroup barrier, a wave retires as
+  // soon as its own tile is done.
+  //   fp32 (wgrad): one 16-byte store per fragment.
+  //   bf16: two neighbouring fragments (j, j+1) trade halves with v_permlane16_swap (odd 16-lane rows of one register
+  //   <-> even rows of the other), after which lane g owns 8 contiguous columns of fragment j + (g & 1) at column
+  //   8 (g >> 1): one 16-byte store, 64 contiguous bytes per output row and instruction.
+  auto store_bf16 = [&](int m, int n, float (&x)[8], int cnt) {   // cnt = 8 or 4 columns
+    if (m >= p.M || n >= p.N) return;
+    if (cnt == 8) {
+      if (p.bias) {
+        bf16x8 bv = *(const bf16x8*)(p.bias + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += (float)bv[e];
+      }
+      if (p.rowvec) {
+        bf16x8 tv = *(const bf16x8*)(p.rowvec + (long)(m / p.rows_per_batch) * p.ldv + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += (float)tv[e];
+      }
+      if (p.resid) {
+        bf16x8 rv = *(const bf16x8*)(p.resid + (long)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += (float)rv[e];
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16)x[e];
+      *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + n) = o;
+    } else {
+      if (p.bias) {
+        bf16x4 bv = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] += (float)bv[e];
+      }
+      if (p.rowvec) {
+        bf16x4 tv = *(const bf16x4*)(p.rowvec + (long)(m / p.rows_per_batch) * p.ldv + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] += (float)tv[e];
+      }
+      if (p.resid) {
+        bf16x4 rv = *(const bf16x4*)(p.resid + (long)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] += (float)rv[e];
+      }
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16)x[e];
+      *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) = o;
+    }
+  };
+  if (FORM == GEMM_TN || !p.geglu) {
+    if (FORM != GEMM_TN) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // MFMA results -> inline-asm VALU reads below
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = m0 + wm * (MI * 16) + i * 16 + l16;
-      if (m >= p.M) continue;
+      if (FORM == GEMM_TN) {
+        if (m >= p.M) continue;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 16 + g * 4;
-        if (n >= p.N) continue;
-        f32x4 x = acc[i][j];
-        if (p.out_f32) {
+        for (int j = 0; j < NJ; ++j) {
+          const int n = n0 + wn * (BN / 2) + j * 16 + g * 4;
+          if (n >= p.N) continue;
+          f32x4 x = acc[i][j];
           float* c = (float*)p.C + (long)m * p.ldc + (long)tap_fixed * p.c_tap_stride + n;
-          if (p.splitk > 1) {
+          if (p.splitk > 1) {   // deterministic split-K: partial tile to this split's slab, summed by splitk_reduce_kernel
             *(f32x4*)(p.slab + ((long)split * p.M + m) * p.slab_ld + (long)tap_fixed * p.c_tap_stride + n) = x;
           } else if (p.accumulate) {
             f32x4 a = *(f32x4*)c;
@@ -620,33 +669,35 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
           } else {
             *(f32x4*)c = x;
           }
-        } else {
-          if (p.bias) {
-            bf16x4 bv = *(const bf16x4*)(p.bias + n);
+        }
+      } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] += (float)bv[e];
+        for (int j = 0; j + 1 < NJ; j += 2) {
+          float x[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // (inline asm: hipcc 7.2 folds four __builtin_amdgcn_permlane16_swap calls on the elements of a vector
+            //  into one and reuses its result for all of them)
+            float lo = acc[i][j][r], hi = acc[i][j + 1][r];
+            asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+            x[r] = lo;
+            x[4 + r] = hi;
           }
-          if (p.rowvec) {
-            bf16x4 tv = *(const bf16x4*)(p.rowvec + (long)(m / p.rows_per_batch) * p.ldv + n);
+          store_bf16(m, n0 + wn * (BN / 2) + (j + (g & 1)) * 16 + (g >> 1) * 8, x, 8);
+        }
+        if (NJ & 1) {   // odd fragment count (BN = 160): the last fragment goes out in 8-byte pieces
+          float x[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] += (float)tv[e];
-          }
-          if (p.resid) {
-            bf16x4 rv = *(const bf16x4*)(p.resid + (long)m * p.ldr + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] += (float)rv[e];
-          }
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (bf16)x[e];
-          *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) = o;
+          for (int r = 0; r < 4; ++r) x[r] = acc[i][NJ - 1][r];
+          store_bf16(m, n0 + wn * (BN / 2) + (NJ - 1) * 16 + g * 4, x, 4);
         }
       }
     }
     return;
   }
   __syncthreads();  // all fragment reads (and padding DMA) done before the ring is reused as the fp32 staging tile
-  // ---- epilogue: stage the fp32 tile in LDS 64 rows at a time (34-42 KiB), then row-contiguous 16-byte stores ----
+  // ---- GEGLU epilogues (value and gate of a channel sit in different waves): the fp32 tile is staged in LDS 64 rows
+  // at a time (34 KiB), then each thread handles 8 channels of one row ----
   float* Cs = (float*)smem;
   constexpr int VPR = BN / 8;  // 8-column vectors per tile row
 #pragma unroll 1
@@ -657,12 +708,10 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            Cs[(wrow - half * 64 + i * 16 + g * 4 + r) * LDC + wn * (BN / 2) + j * 16 + l16] = acc[i][j][r];
+          *(f32x4*)(Cs + (wrow - half * 64 + i * 16 + l16) * LDC + wn * (BN / 2) + j * 16 + g * 4) = acc[i][j];
     }
     __syncthreads();
-    if (FORM != GEMM_TN && BN == 128 && p.geglu) {
+    if (FORM != GEMM_TN && BN == 128) {
       // GEGLU fused epilogues (see GemmP): both operate on the bf16-rounded values, exactly like a separate pass would
       for (int id = tid; id < 64 * VPR; id += NT) {
         const int row = id / VPR, col = (id - row * VPR) * 8;
@@ -707,55 +756,6 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
           *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + cu) = oa;
           *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + cu + 64) = ot;
         }
-      }
-    } else
-    for (int id = tid; id < 64 * VPR; id += NT) {
-      int row = id / VPR, col = (id - row * VPR) * 8;
-      int m = m0 + half * 64 + row, n = n0 + col;
-      if (m >= p.M || n >= p.N) continue;
-      float x[8];
-      {
-        f32x4 a = *(const f32x4*)(Cs + row * LDC + col);
-        f32x4 b = *(const f32x4*)(Cs + row * LDC + col + 4);
-        x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3];
-        x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
-      }
-      if (p.out_f32) {
-        float* c = (float*)p.C + (long)m * p.ldc + (long)tap_fixed * p.c_tap_stride + n;
-        if (p.splitk > 1) {  // deterministic split-K: partial tile to this split's slab, summed by splitk_reduce_kernel
-          float* sl = p.slab + ((long)split * p.M + m) * p.slab_ld + (long)tap_fixed * p.c_tap_stride + n;
-          *(f32x4*)sl = (f32x4){x[0], x[1], x[2], x[3]};
-          *(f32x4*)(sl + 4) = (f32x4){x[4], x[5], x[6], x[7]};
-        } else if (p.accumulate) {
-          f32x4 a = *(f32x4*)c, b = *(f32x4*)(c + 4);
-          a[0] += x[0]; a[1] += x[1]; a[2] += x[2]; a[3] += x[3];
-          b[0] += x[4]; b[1] += x[5]; b[2] += x[6]; b[3] += x[7];
-          *(f32x4*)c = a;
-          *(f32x4*)(c + 4) = b;
-        } else {
-          *(f32x4*)c = (f32x4){x[0], x[1], x[2], x[3]};
-          *(f32x4*)(c + 4) = (f32x4){x[4], x[5], x[6], x[7]};
-        }
-      } else {
-        if (p.bias) {
-          bf16x8 bv = *(const bf16x8*)(p.bias + n);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) x[e] += (float)bv[e];
-        }
-        if (p.rowvec) {
-          bf16x8 tv = *(const bf16x8*)(p.rowvec + (long)(m / p.rows_per_batch) * p.ldv + n);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) x[e] += (float)tv[e];
-        }
-        if (p.resid) {
-          bf16x8 rv = *(const bf16x8*)(p.resid + (long)m * p.ldr + n);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) x[e] += (float)rv[e];
-        }
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16)x[e];
-        *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + n) = o;
       }
     }
     __syncthreads();
