@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="ddpm_b4_1024", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true", help="skip the (untimed) fused-optimizer measurement")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--profile-steps", type=int, default=1, help="extra steps with per-launch GEMM event timing")
     args = ap.parse_args()
@@ -186,6 +187,29 @@ def main():
                 "gemm_ms_per_step": round(ms.value / args.profile_steps, 2),
                 "gemm_tflop_per_step": round(fl.value / args.profile_steps / 1e12, 2)}
 
+    # row f1, measured OUTSIDE the timed region (the metric excludes the optimizer): the fused AdamW_BF16 update of all
+    # parameters, HBM-bound: 20 algorithmic bytes per element (p, m, v, shift bf16 in + out, fp32 gradient in)
+    opt_extra = None
+    if rank == 0 and not args.no_optimizer:
+        from sdxl_amd.optimizer import AdamWBF16
+        opt = AdamWBF16(net, lr=4e-7, weight_decay=0.01)
+        for _ in range(2):
+            opt.step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            opt.step()
+        e1.record()
+        torch.cuda.synchronize()
+        oms = e0.elapsed_time(e1) / 5
+        nel = net.weights.numel()
+        opt_extra = {"kernel": "adamw_bf16_kernel (fused AdamW_BF16 step, all parameters in one launch)",
+                     "ms_per_update": round(oms, 2), "params": nel,
+                     "roofline": {"bound": "hbm", "achieved": round(20.0 * nel / oms / 1e6, 1), "peak": 8000.0,
+                                  "unit": "GB/s", "frac": round(20.0 * nel / oms / 1e6 / 8000.0, 4), "traffic": None},
+                     "note": "not part of `value`; one update per gradient_accumulation_steps micro-steps"}
+        del opt
     if rank == 0:
         step_tflops = value / world * wl["flop_per_image"] / 1e12
         out = {"metric": "images/sec/node SDXL-base 1024^2 bf16 fwd+bwd", "value": round(value, 3), "unit": "images/sec",
@@ -195,7 +219,7 @@ def main():
                           "weights": "synthetic (counter-hash init of the 2,567,463,684-parameter SDXL-base UNet)"},
                "step_tflops_per_gpu": round(step_tflops, 1),
                "step_mfma_frac": round(step_tflops / PEAK_BF16_TFLOPS, 4),
-               "loss": loss, "roofline": roof}
+               "loss": loss, "roofline": roof, "optimizer": opt_extra}
         if world == 1 and not args.no_cpu_baseline:
             del net, sync
             torch.cuda.empty_cache()

@@ -74,6 +74,9 @@ int sdxl_param_bytes(sdxl_handle* h, size_t* weight_bytes, size_t* grad_bytes);
 int sdxl_bind_params(sdxl_handle* h, void* weights_dev, void* grads_dev);
 int sdxl_num_params(sdxl_handle* h);                            /* diffusers state-dict tensors */
 int sdxl_param_info(sdxl_handle* h, int i, char* name, int name_cap, int* ndim, long shape[4]);
+/* the contiguous element range tensor i occupies in the packed weight / gradient arenas (per-tensor optimizer
+ * bookkeeping such as AdamWBF16's lazy decay) */
+int sdxl_param_range(sdxl_handle* h, int i, size_t* elem_off, size_t* elems);
 /* copy one tensor in PyTorch layout ([out,in] / [cout,cin,kh,kw]) from device memory into the packed arena
  * (dtype: 0 = fp32, 1 = bf16).  Caller keeps ownership of src. */
 int sdxl_load_weight(sdxl_handle* h, const char* name, const void* src_dev, int dtype, void* stream);
@@ -149,6 +152,31 @@ int sdxl_op_ff_geglu_fwd(const void* x, const void* w1, const void* b1, void* u,
 int sdxl_op_ff_geglu_bwd(const void* dy, const void* w2, const void* u, void* du, int M, int C, int C4, void* stream);
 int sdxl_op_loss(const sdxl_loss_config* lc, const sdxl_batch* b, void* unet_in, const void* pred, void* dpred,
                  float grad_scale, float* out8_dev, int phase /*0 prepare,1 loss,2 dpred*/, void* stream);
+/* ---- row f1: fused AdamW_BF16 step (replaces AdamWBF16.step / _make_step,
+ * reference src/training/optimizers/adamw_bfloat16/__init__.py:87-197 and stochastic/__init__.py:46-124).
+ * One launch over flat arrays (the packed weight / gradient arenas, or any 16-byte aligned slice of them):
+ * p, m (exp_avg), v (exp_avg_sq), shift are bf16 and updated in place; grad is fp32 (grad_dtype 0, the native arena) or
+ * bf16 (1).  n must be a multiple of 8.  grad_scale_dev: optional device float multiplied into the gradient
+ * (1/accumulation, clip coefficient).  rand_inject: optional uint16 [4][n] table of the random integers of the four
+ * stochastic roundings in the reference's draw order (exp_avg, shift, p, shift) -- parity tests; NULL = Philox keyed
+ * by (seed, step, element).  Weight decay is lazy in the reference (per tensor, paid when wd*lr accumulates past
+ * 5e-3): decay_this_iteration applies to the whole launch; sdxl_adamw_decay pays it for one tensor's range. */
+typedef struct {
+  double lr, beta1, beta2, eps; /* doubles: the reference derives 1-beta, -lr*sqrt(1-beta2^t) in python floats */
+  double step;                 /* t >= 1 of this update (denominator correction sqrt(1 - beta2^t)) */
+  double decay_this_iteration; /* 0 = none */
+  int reference_ema;           /* 1: the reference's arithmetic exactly, m <- SR(g + (1-beta1)*(beta1*m))  [its
+                                  add_stochastic_ applies alpha to the wrong operand, stochastic/__init__.py:96];
+                                  0: the documented EMA m <- SR(beta1*m + (1-beta1)*g) */
+  int grad_round_bf16;         /* 1: round the scaled gradient to bf16 first (the reference's gradients are bf16) */
+  unsigned long long seed;
+} sdxl_adamw_config;
+int sdxl_adamw_default_config(sdxl_adamw_config* c);   /* lr 1e-4, betas (0.9, 0.999), eps 1e-8, reference_ema 1 */
+int sdxl_adamw_bf16_step(void* p, const void* grad, int grad_dtype, void* m, void* v, void* shift, size_t n,
+                         const sdxl_adamw_config* c, const float* grad_scale_dev, const unsigned short* rand_inject,
+                         void* stream);
+int sdxl_adamw_decay(void* shift, const void* p, size_t n, float decay, void* stream);
+
 /* debug: run ds_read_b64_tr_b16 / MFMA layout probes (used by tests/test_gpu_layout.py) */
 int sdxl_probe_layout(void* out_dev, void* stream);
 /* measurement: between begin and end every launch of the bf16 MFMA GEMM family (Linear / conv fwd, dgrad, wgrad) is

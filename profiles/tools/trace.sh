@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/trace
-rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/trace -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 0 2>&1 | tail -1 | cut -c1-200
+rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/trace -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-optimizer --profile-steps 0 2>&1 | tail -1 | cut -c1-200
 ls -la $GRAFT_REPO_ROOT/gpurun_out/trace/*
 cd $GRAFT_REPO_ROOT/gpurun_out/trace && python - <<'PY'
 import csv,glob

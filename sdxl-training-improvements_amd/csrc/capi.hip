@@ -1,4 +1,5 @@
 // extern "C" surface of libsdxlstep (see include/sdxlstep.h for the contract of every entry point).
+#include <math.h>
 #include "engine.h"
 
 #include <stdlib.h>
@@ -126,6 +127,18 @@ int sdxl_param_info(sdxl_handle* h, int i, char* name, int cap, int* ndim, long 
   if (name && cap > 0) snprintf(name, cap, "%s", s.name.c_str());
   if (ndim) *ndim = s.ndim;
   if (shape) for (int k = 0; k < 4; ++k) shape[k] = s.shape[k];
+  return 0;
+}
+
+int sdxl_param_range(sdxl_handle* h, int i, size_t* elem_off, size_t* elems) {
+  H_CHECK(h);
+  ARG_CHECK(i >= 0 && i < (int)h->e.src.size(), "parameter index %d out of range", i);
+  const SrcParam& s = h->e.src[i];
+  size_t n = 1;
+  for (int k = 0; k < s.ndim; ++k) n *= (size_t)s.shape[k];
+  if (s.kind == 1) n = (size_t)s.shape[0] * 9 * (size_t)s.ci_pad;   // conv: [cout][tap][cin padded]
+  if (elem_off) *elem_off = s.native.off + s.elem_off;
+  if (elems) *elems = n;
   return 0;
 }
 
@@ -542,6 +555,56 @@ int sdxl_op_loss(const sdxl_loss_config* lc, const sdxl_batch* b, void* unet_in,
   if (phase == 1) return launch_loss_fwd(L, (hipStream_t)st);
   if (phase == 2) return launch_loss_bwd(L, (hipStream_t)st);
   ARG_CHECK(false, "phase %d", phase);
+}
+
+// ---- row f1: fused AdamW_BF16 ----
+static float bf16_round_host(float x) {
+  unsigned u;
+  memcpy(&u, &x, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  u &= 0xFFFF0000u;
+  memcpy(&x, &u, 4);
+  return x;
+}
+int sdxl_adamw_default_config(sdxl_adamw_config* c) {
+  ARG_CHECK(c, "null config");
+  memset(c, 0, sizeof(*c));
+  c->lr = 1e-4; c->beta1 = 0.9; c->beta2 = 0.999; c->eps = 1e-8;   // AdamWBF16.__init__ defaults (:31-36)
+  c->step = 1.0;
+  c->reference_ema = 1;
+  return 0;
+}
+int sdxl_adamw_bf16_step(void* p, const void* grad, int grad_dtype, void* m, void* v, void* shift, size_t n,
+                         const sdxl_adamw_config* c, const float* grad_scale_dev, const unsigned short* rand_inject,
+                         void* st) {
+  ARG_CHECK(c, "null config");
+  ARG_CHECK(grad_dtype == 0 || grad_dtype == 1, "adamw: grad_dtype %d (0 = fp32, 1 = bf16)", grad_dtype);
+  ARG_CHECK(c->step >= 1.0 && c->beta1 >= 0.0 && c->beta1 < 1.0 && c->beta2 >= 0.0 && c->beta2 < 1.0 && c->eps >= 0.0,
+            "adamw: invalid hyper-parameters");
+  AdamWP q;
+  memset(&q, 0, sizeof(q));
+  q.p = (bf16*)p; q.m = (bf16*)m; q.v = (bf16*)v; q.shift = (bf16*)shift; q.n = n;
+  if (grad_dtype == 0) q.grad_f32 = (const float*)grad; else q.grad_bf16 = (const bf16*)grad;
+  // scalars exactly as the reference's python floats reach the torch kernels: double arithmetic, then float32
+  const double b1 = c->beta1, b2 = c->beta2;
+  q.beta1 = (float)b1; q.beta2 = (float)b2;
+  q.one_minus_beta1 = (float)(1.0 - b1);
+  q.one_minus_beta2 = (float)(1.0 - b2);
+  q.eps_bf16 = bf16_round_host((float)c->eps);
+  q.value = (float)(-c->lr * sqrt(1.0 - pow(b2, c->step)));
+  q.decay_alpha_bf16 = c->decay_this_iteration > 0.0 ? bf16_round_host((float)-c->decay_this_iteration) : 0.f;
+  q.reference_ema = c->reference_ema;
+  q.grad_round_bf16 = c->grad_round_bf16;
+  q.grad_scale = grad_scale_dev;
+  q.rand = rand_inject;
+  q.seed_lo = (unsigned)c->seed; q.seed_hi = (unsigned)(c->seed >> 32);
+  q.step_counter = (unsigned)c->step;
+  return launch_adamw_bf16(q, (hipStream_t)st);
+}
+int sdxl_adamw_decay(void* shift, const void* p, size_t n, float decay, void* st) {
+  ARG_CHECK(shift && p, "adamw decay: missing buffers");
+  if (decay <= 0.f) return 0;
+  return launch_adamw_decay((bf16*)shift, (const bf16*)p, n, bf16_round_host(-decay), (hipStream_t)st);
 }
 
 int sdxl_probe_layout(void* out, void* st) { return probe_layout(out, (hipStream_t)st); }

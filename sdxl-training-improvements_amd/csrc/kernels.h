@@ -160,3 +160,25 @@ struct LossP {
 int launch_loss_prepare(const LossP& p, hipStream_t st);
 int launch_loss_fwd(const LossP& p, hipStream_t st);
 int launch_loss_bwd(const LossP& p, hipStream_t st);
+
+// ---- fused AdamW_BF16 step (optimizer.hip; reference adamw_bfloat16/__init__.py:146-197) ----
+struct AdamWP {
+  bf16* p;
+  const float* grad_f32;       // native fp32 gradient arena, or
+  const bf16* grad_bf16;       //   bf16 gradients (exactly one of the two)
+  bf16 *m, *v, *shift;
+  size_t n;                    // elements, multiple of 8
+  float beta1, beta2, one_minus_beta1, one_minus_beta2;
+  float eps_bf16;              // eps rounded to bf16 (torch casts the scalar it adds to a bf16 tensor)
+  float value;                 // -lr * sqrt(1 - beta2^step)
+  float decay_alpha_bf16;      // -decay_this_iteration rounded to bf16, 0 = no decay in this launch
+  int reference_ema;           // 1: the reference's actual first-moment update  m <- SR(g + (1-b1) * b1*m)   (quirk D17)
+                               // 0: the documented EMA                          m <- SR(b1*m + (1-b1) * g)
+  int grad_round_bf16;         // round the (scaled) gradient to bf16 first, as the reference's bf16 autograd does
+  const float* grad_scale;     // device scalar multiplied into the gradient (unscale / clip), or nullptr
+  const unsigned short* rand;  // [4][n] injected random 16-bit integers (parity tests), or nullptr = Philox
+  unsigned seed_lo, seed_hi, step_counter;
+};
+int launch_adamw_bf16(const AdamWP& q, hipStream_t st);
+int launch_adamw_decay(bf16* shift, const bf16* p, size_t n, float alpha_bf16, hipStream_t st);
+

@@ -33,6 +33,12 @@ class Batch(C.Structure):
                 ("time_ids", C.c_void_p), ("tag_weights", C.c_void_p)]
 
 
+class AdamWConfig(C.Structure):
+    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("step", C.c_double), ("decay_this_iteration", C.c_double), ("reference_ema", C.c_int),
+                ("grad_round_bf16", C.c_int), ("seed", C.c_ulonglong)]
+
+
 _vp, _i, _f, _l, _sz = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
 _P = C.POINTER
 
@@ -72,6 +78,10 @@ SIGNATURES = {
     "sdxl_op_groupnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "sdxl_op_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "sdxl_op_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "sdxl_param_range": [_vp, _i, _P(_sz), _P(_sz)],
+    "sdxl_adamw_default_config": [C.POINTER(AdamWConfig)],
+    "sdxl_adamw_bf16_step": [_vp, _vp, _i, _vp, _vp, _vp, _sz, C.POINTER(AdamWConfig), _vp, _vp, _vp],
+    "sdxl_adamw_decay": [_vp, _vp, _sz, _f, _vp],
     "sdxl_op_ff_geglu_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sdxl_op_ff_geglu_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sdxl_op_loss": [_P(LossConfig), _P(Batch), _vp, _vp, _vp, _f, _vp, _i, _vp],

@@ -31,6 +31,7 @@ import torch
 from . import distributed as D
 from . import lib
 from .config import Config
+from .optimizer import AdamWBF16
 from .scheduler import NoiseScheduler
 from .unet import NativeUNet
 
@@ -49,35 +50,6 @@ class _NativeLoss(torch.autograd.Function):
     def backward(ctx, grad_out):
         ctx.trainer._native_backward(float(grad_out))
         return None, None, None
-
-
-class FlatAdamW:
-    """Plain AdamW over the packed arenas (bf16 weights, fp32 grads, fp32 moments), torch elementwise ops.
-    Functional stand-in so the loop is usable; NOT the reference's AdamWBF16 arithmetic (row f1 of SURVEY 8(f):
-    stochastic-rounded bf16 moments + error feedback, to be a fused HIP kernel)."""
-
-    def __init__(self, net: NativeUNet, lr=1e-6, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
-        self.net = net
-        self.param_groups = [{"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay}]
-        self.m = torch.zeros_like(net.grads)
-        self.v = torch.zeros_like(net.grads)
-        self.t = 0
-
-    def zero_grad(self, set_to_none: bool = False):
-        self.net.zero_grads()
-
-    @torch.no_grad()
-    def step(self, grads: Optional[torch.Tensor] = None):
-        g = self.net.grads if grads is None else grads.float()
-        p = self.param_groups[0]
-        b1, b2 = p["betas"]
-        self.t += 1
-        self.m.mul_(b1).add_(g, alpha=1 - b1)
-        self.v.mul_(b2).addcmul_(g, g, value=1 - b2)
-        denom = (self.v / (1 - b2 ** self.t)).sqrt_().add_(p["eps"])
-        w = self.net.weights.float()
-        w.mul_(1 - p["lr"] * p["weight_decay"]).addcdiv_(self.m, denom, value=-p["lr"] / (1 - b1 ** self.t))
-        self.net.weights.copy_(w)
 
 
 class NativeSDXLTrainer:
@@ -103,9 +75,10 @@ class NativeSDXLTrainer:
                 raise TypeError("model.unet must be a NativeUNet (use NativeUNet.load_state_dict to import a torch "
                                 f"UNet); missing `{attr}`")
         self.noise_scheduler = NoiseScheduler(self.config, "cpu")
-        self.optimizer = optimizer if optimizer is not None else FlatAdamW(
-            self.net, self.config.optimizer.learning_rate, (self.config.optimizer.beta1, self.config.optimizer.beta2),
-            self.config.optimizer.epsilon, self.config.optimizer.weight_decay)
+        self.optimizer = optimizer if optimizer is not None else AdamWBF16(       # main.py:73-86 (optimizer_type adamw_bf16)
+            self.net, lr=self.config.optimizer.learning_rate, betas=(self.config.optimizer.beta1, self.config.optimizer.beta2),
+            eps=self.config.optimizer.epsilon, weight_decay=self.config.optimizer.weight_decay)
+        self._clip_coef = None
         self.sync = D.GradSync(self.net.param_elems, self._cast, torch.bfloat16, getattr(self.net, "device", "cpu"))
         self._micro = 0                      # micro-step index inside the accumulation cycle
         self._anchor = torch.zeros((), requires_grad=True)
@@ -188,15 +161,18 @@ class NativeSDXLTrainer:
 
     def clip_grad_norm_(self, max_norm: float) -> float:
         """torch.nn.utils.clip_grad_norm_ over the flat arena (flow_matching_trainer.py:181-186)."""
+        fused = isinstance(self.optimizer, AdamWBF16)        # the coefficient rides into the fused optimizer kernel
         if self.sync.world > 1:
             g = self.sync.reduced()
             norm = float(g.float().norm())
-            if norm > max_norm:
-                g.mul_(max_norm / (norm + 1e-6))
-            return norm
-        norm = self.net.grad_norm()
-        if norm > max_norm:
-            self.net.grads.mul_(max_norm / (norm + 1e-6))
+        else:
+            g = self.net.grads
+            norm = self.net.grad_norm()
+        coef = max_norm / (norm + 1e-6) if norm > max_norm else 1.0
+        if fused:
+            self._clip_coef = torch.tensor([coef], dtype=torch.float32, device=g.device) if coef != 1.0 else None
+        elif coef != 1.0:
+            g.mul_(coef)
         return norm
 
     def optimizer_step(self) -> Optional[float]:
@@ -204,8 +180,9 @@ class NativeSDXLTrainer:
         if self.config.training.clip_grad_norm and self.config.training.clip_grad_norm > 0:
             gn = self.clip_grad_norm_(float(self.config.training.clip_grad_norm))
         if self.optimizer is not None:
-            if isinstance(self.optimizer, FlatAdamW):
-                self.optimizer.step(self.sync.reduced() if self.sync.world > 1 else None)
+            if isinstance(self.optimizer, AdamWBF16):
+                self.optimizer.step(self.sync.reduced() if self.sync.world > 1 else None, grad_scale=self._clip_coef)
+                self._clip_coef = None
             else:
                 self.optimizer.step()
         return gn

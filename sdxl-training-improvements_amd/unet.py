@@ -86,6 +86,15 @@ class NativeUNet:
             out[buf.value.decode()] = tuple(int(shp[k]) for k in range(nd.value))
         return out
 
+    def param_ranges(self) -> Dict[str, Tuple[int, int]]:
+        """{diffusers key: (element offset, element count)} of every tensor inside the packed weight / gradient arenas."""
+        out = {}
+        off, cnt = C.c_size_t(), C.c_size_t()
+        for i, name in enumerate(self.param_table):
+            lib.check(self.L.sdxl_param_range(self.h, i, C.byref(off), C.byref(cnt)))
+            out[name] = (int(off.value), int(cnt.value))
+        return out
+
     def param_shapes(self) -> Dict[str, Tuple[int, ...]]:
         """{diffusers state-dict key: shape} -- same keys/shapes as unet.state_dict() in the reference."""
         return dict(self.param_table)

@@ -76,8 +76,11 @@ def test_train_loop_runs_and_updates_weights(setup):
     tr = T.NativeSDXLTrainer(M(), train_dataloader=[_batch(cfg, 2, s) for s in range(4)], config=c)
     before = net.weights.clone()
     tr.train(1)
-    assert tr.optimizer.t == 2                       # 4 micro-steps / accumulation 2
-    assert not torch.equal(before, net.weights) and torch.isfinite(net.weights.float()).all()
+    assert tr.optimizer.step_count == 2              # 4 micro-steps / accumulation 2
+    # AdamWBF16 keeps the true value in p + shift: after two steps at lr 1e-4 the update shows in one of the two
+    moved = (net.weights.float() + tr.optimizer.shift.float() - before.float()).abs().max().item()
+    assert moved > 0 and torch.isfinite(net.weights.float()).all() and torch.isfinite(tr.optimizer.shift.float()).all()
+    assert tr.optimizer.exp_avg.float().abs().max().item() > 0 and tr.optimizer.exp_avg_sq.float().max().item() > 0
     net.load_state_dict(w)                           # restore for other tests
 
 
