@@ -11,24 +11,29 @@
 // oracle/adamw_ref.py, pinned bit-for-bit to fixtures produced by the reference itself): fused multiply-add where
 // torch's kernels fuse, bf16-rounded scalars where torch casts them, IEEE divide / sqrt.  `#pragma clang fp
 // contract(off)` keeps the compiler from fusing anything else.  Stochastic rounding: r in [0, 2^16) is added to the
-// fp32 bit pattern and the low half dropped; r comes from a counter-based generator (Philox-2x32-10 keyed by the
-// seed, counter = (element index, step)) or, for the parity tests, from a caller-supplied table.
+// fp32 bit pattern and the low half dropped; r comes from a counter-based generator (Philox-4x32-7 keyed by the
+// seed, counter = (element-pair index, step)) or, for the parity tests, from a caller-supplied table.
 #include "kernels.h"
 
 #pragma clang fp contract(off)
 
 __device__ __forceinline__ unsigned mulhi32(unsigned a, unsigned b) { return __umulhi(a, b); }
-// Philox-2x32-10 (Salmon et al. 2011): 64 random bits per (counter, key)
-__device__ __forceinline__ void philox2x32(unsigned c0, unsigned c1, unsigned key, unsigned* o0, unsigned* o1) {
+// Philox-4x32-7 (Salmon et al. 2011; 7 rounds is the variant that passes BigCrush with margin): 128 random bits per
+// (counter, key) = the 8 sixteen-bit integers of two elements
+__device__ __forceinline__ void philox4x32_7(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                             unsigned out[4]) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const unsigned hi = mulhi32(0xD256D193u, c0), lo = 0xD256D193u * c0;
-    c0 = hi ^ key ^ c1;
-    c1 = lo;
-    key += 0x9E3779B9u;
+  for (int r = 0; r < 7; ++r) {
+    const unsigned h0 = mulhi32(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    const unsigned h1 = mulhi32(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    c0 = h1 ^ c1 ^ k0;
+    c1 = l1;
+    c2 = h0 ^ c3 ^ k1;
+    c3 = l0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
   }
-  *o0 = c0;
-  *o1 = c1;
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 __device__ __forceinline__ float bf(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 rn(float x) { return (bf16)x; }                       // round-to-nearest-even
@@ -54,15 +59,21 @@ __global__ __launch_bounds__(256) void adamw_bf16_kernel(const AdamWP q) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) g[e] = bf(gv[e]);
     }
+    unsigned rnd[4][4];     // [element pair][word]: counter = (pair index, step), key = seed
+    if (!INJECT) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const size_t pair = i * 4 + k;
+        philox4x32_7((unsigned)pair, (unsigned)(pair >> 32), q.step_counter, 0x5D71A3B1u, q.seed_lo, q.seed_hi, rnd[k]);
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       unsigned r0, r1, r2, r3;
       if (INJECT) {
         r0 = q.rand[e0 + e]; r1 = q.rand[q.n + e0 + e]; r2 = q.rand[2 * q.n + e0 + e]; r3 = q.rand[3 * q.n + e0 + e];
       } else {
-        unsigned a, b;
-        const size_t idx = e0 + e;
-        philox2x32((unsigned)idx, (unsigned)(idx >> 32) ^ q.step_counter, q.seed_lo ^ (q.seed_hi * 0x85EBCA6Bu), &a, &b);
+        const unsigned a = rnd[e >> 1][(e & 1) * 2], b = rnd[e >> 1][(e & 1) * 2 + 1];
         r0 = a & 0xFFFFu; r1 = a >> 16; r2 = b & 0xFFFFu; r3 = b >> 16;
       }
       float gr = g[e] * gscale;                                  // fused unscale / clip coefficient
