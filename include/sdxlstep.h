@@ -116,6 +116,12 @@ int sdxl_unet_backward(sdxl_handle* h, const void* dpred_nhwc8, int first_micro,
 /* fp32 grads -> bf16 (scaled) for the gradient exchange; global L2 norm of the fp32 grads */
 int sdxl_grads_to_bf16(sdxl_handle* h, size_t elem_offset, size_t elems, void* dst_bf16, float scale, void* stream);
 int sdxl_grad_sumsq(sdxl_handle* h, float* out_dev, void* stream);
+/* row f3 pieces: squared L2 norm of any fp32 (dtype 0) / bf16 (1) device array -- e.g. the all-reduced bf16 gradient
+ * arena -- and torch.nn.utils.clip_grad_norm_'s coefficient min(1, max_norm / (norm + 1e-6)) computed on the device;
+ * the coefficient is consumed by sdxl_adamw_bf16_step's grad_scale_dev, so clipping costs no pass over the gradients
+ * (reference: clip_grad_norm_ then optimizer.step, flow_matching_trainer.py:181-189). */
+int sdxl_sumsq(const void* x_dev, int dtype, size_t n, float* out_dev, void* stream);
+int sdxl_clip_coef(const float* sumsq_dev, float max_norm, float* coef_dev, void* stream);
 
 /* ---- single-kernel entry points (parity tests call these; same kernels the plan launches) --------------------- */
 /* C[M,N] = A.B ; form 0: A[M,K],B[N,K] ; 1: A[M,K],B[K,N] ; 2: A[K,M],B[K,N] -> fp32 C (+= if accumulate) */

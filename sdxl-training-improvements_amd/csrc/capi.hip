@@ -397,6 +397,18 @@ int sdxl_grad_sumsq(sdxl_handle* h, float* out, void* st) {
   return launch_sumsq_f32(h->e.grads, (long)h->e.param_elems, out, (hipStream_t)st);
 }
 
+int sdxl_sumsq(const void* x, int dtype, size_t n, float* out, void* st) {
+  ARG_CHECK(x && out && (dtype == 0 || dtype == 1), "sumsq: bad arguments");
+  ARG_CHECK(((uintptr_t)x & 15) == 0, "sumsq: x must be 16-byte aligned");
+  HIP_CHECK_RET(hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)st));
+  return dtype == 0 ? launch_sumsq_f32((const float*)x, (long)n, out, (hipStream_t)st)
+                    : launch_sumsq_bf16((const bf16*)x, (long)n, out, (hipStream_t)st);
+}
+int sdxl_clip_coef(const float* sumsq_dev, float max_norm, float* coef_dev, void* st) {
+  ARG_CHECK(sumsq_dev && coef_dev && max_norm > 0.f, "clip_coef: bad arguments");
+  return launch_clip_coef(sumsq_dev, max_norm, coef_dev, (hipStream_t)st);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // single-kernel entry points
 // ------------------------------------------------------------------------------------------------------------

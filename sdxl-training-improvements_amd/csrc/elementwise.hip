@@ -216,14 +216,44 @@ int launch_bf16_to_f32(const bf16* x, float* y, long n, hipStream_t st) {
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-__global__ void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+// sum of squares of an fp32 or bf16 array (gradient norm): 16-byte vectors, wave reduction, one atomic per wave
+template <typename T>
+__global__ void sumsq_kernel(const T* __restrict__ x, long n, float* __restrict__ out) {
+  constexpr int V = 16 / sizeof(T);
   float s = 0.f;
-  VEC_LOOP(i, n) s += x[i] * x[i];
+  const long nv = n / V;
+  VEC_LOOP(i, nv) {
+    if (sizeof(T) == 4) {
+      const f32x4 v = *(const f32x4*)((const float*)x + i * 4);
+      s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    } else {
+      const bf16x8 v = *(const bf16x8*)((const bf16*)x + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += (float)v[e] * (float)v[e];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < n - nv * V) { const float t = (float)x[nv * V + threadIdx.x]; s += t * t; }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
 }
 int launch_sumsq_f32(const float* x, long n, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(sumsq_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_BLOCK), 0, st, x, n, out);
+  hipLaunchKernelGGL(sumsq_kernel<float>, dim3(ew_grid(n / 4 + 1)), dim3(EW_BLOCK), 0, st, x, n, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int launch_sumsq_bf16(const bf16* x, long n, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(sumsq_kernel<bf16>, dim3(ew_grid(n / 8 + 1)), dim3(EW_BLOCK), 0, st, x, n, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+// torch.nn.utils.clip_grad_norm_'s coefficient from the squared norm, on the device (no host round trip):
+// coef = min(1, max_norm / (sqrt(sumsq) + 1e-6))
+__global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* coef) {
+  const float c = max_norm / (sqrtf(*sumsq) + 1e-6f);
+  *coef = c < 1.f ? c : 1.f;
+}
+int launch_clip_coef(const float* sumsq, float max_norm, float* coef, hipStream_t st) {
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, st, sumsq, max_norm, coef);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

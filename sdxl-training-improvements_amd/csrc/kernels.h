@@ -134,6 +134,8 @@ int launch_copy_cols(const bf16* src, long lds, bf16* dst, long ldd, int rows, i
 int launch_f32_to_bf16(const float* x, bf16* y, long n, float scale, hipStream_t st);
 int launch_bf16_to_f32(const bf16* x, float* y, long n, hipStream_t st);
 int launch_sumsq_f32(const float* x, long n, float* out /* += */, hipStream_t st);
+int launch_sumsq_bf16(const bf16* x, long n, float* out /* += */, hipStream_t st);
+int launch_clip_coef(const float* sumsq, float max_norm, float* coef, hipStream_t st);
 int launch_scale_f32(float* x, long n, const float* scale_dev, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------

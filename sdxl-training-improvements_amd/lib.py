@@ -78,6 +78,8 @@ SIGNATURES = {
     "sdxl_op_groupnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "sdxl_op_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "sdxl_op_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "sdxl_sumsq": [_vp, _i, _sz, _vp, _vp],
+    "sdxl_clip_coef": [_vp, _f, _vp, _vp],
     "sdxl_param_range": [_vp, _i, _P(_sz), _P(_sz)],
     "sdxl_adamw_default_config": [C.POINTER(AdamWConfig)],
     "sdxl_adamw_bf16_step": [_vp, _vp, _i, _vp, _vp, _vp, _sz, C.POINTER(AdamWConfig), _vp, _vp, _vp],

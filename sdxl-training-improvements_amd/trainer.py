@@ -162,15 +162,23 @@ class NativeSDXLTrainer:
     def clip_grad_norm_(self, max_norm: float) -> float:
         """torch.nn.utils.clip_grad_norm_ over the flat arena (flow_matching_trainer.py:181-186)."""
         fused = isinstance(self.optimizer, AdamWBF16)        # the coefficient rides into the fused optimizer kernel
-        if self.sync.world > 1:
-            g = self.sync.reduced()
-            norm = float(g.float().norm())
-        else:
-            g = self.net.grads
-            norm = self.net.grad_norm()
+        g = self.sync.reduced() if self.sync.world > 1 else self.net.grads
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream) if g.is_cuda else None
+        if g.is_cuda:                                        # squared norm + coefficient on the device (HIP kernels)
+            buf = torch.empty(2, dtype=torch.float32, device=g.device)
+            lib.check(self.net.L.sdxl_sumsq(C.c_void_p(g.data_ptr()), 0 if g.dtype == torch.float32 else 1, g.numel(),
+                                            C.c_void_p(buf.data_ptr()), st), "sdxl_sumsq")
+            lib.check(self.net.L.sdxl_clip_coef(C.c_void_p(buf.data_ptr()), float(max_norm),
+                                                C.c_void_p(buf.data_ptr() + 4), st), "sdxl_clip_coef")
+            if fused:
+                self._clip_coef = buf[1:2]
+            else:
+                g.mul_(buf[1])
+            return float(buf[0].sqrt())                      # the reference logs the norm (one read-back)
+        norm = float(g.float().norm())                       # host-logic tests with a stand-in net (no GPU)
         coef = max_norm / (norm + 1e-6) if norm > max_norm else 1.0
         if fused:
-            self._clip_coef = torch.tensor([coef], dtype=torch.float32, device=g.device) if coef != 1.0 else None
+            self._clip_coef = torch.tensor([coef], dtype=torch.float32) if coef != 1.0 else None
         elif coef != 1.0:
             g.mul_(coef)
         return norm

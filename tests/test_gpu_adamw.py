@@ -133,3 +133,22 @@ def test_decay_range(L):
     al = R._bf16_scalar(-0.0075)
     want[off:off + cnt] = R.f32_to_bf16_rn(R.fma32(R.bf16_to_f32(pb[off:off + cnt]), al, R.bf16_to_f32(sb[off:off + cnt])))
     assert (bits(s) == want).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sumsq_and_clip_coef(L, dtype):
+    """Row f3 pieces: device-side squared norm (fp32 / bf16 arrays, ragged tail) and clip_grad_norm_'s coefficient."""
+    g = torch.Generator().manual_seed(11)
+    n = (1 << 20) + 3
+    x = (torch.randn(n + 8, generator=g) * 0.02).to(dtype).to(dev())[:n]       # 16-byte aligned start, ragged length
+    buf = torch.zeros(2, dtype=torch.float32, device=dev())
+    lib.check(L.sdxl_sumsq(ptr(x), 0 if dtype == torch.float32 else 1, n, ptr(buf), stream()))
+    want = float((x.double() ** 2).sum())
+    torch.cuda.synchronize()
+    assert abs(float(buf[0]) - want) <= 2e-5 * want
+    for max_norm in (1.0, 1e9):
+        lib.check(L.sdxl_clip_coef(ptr(buf), max_norm, C.c_void_p(buf.data_ptr() + 4), stream()))
+        torch.cuda.synchronize()
+        norm = want ** 0.5
+        ref = min(1.0, max_norm / (norm + 1e-6))
+        assert abs(float(buf[1]) - ref) <= 1e-5 * ref
