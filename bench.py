@@ -204,10 +204,17 @@ def main():
         torch.cuda.synchronize()
         oms = e0.elapsed_time(e1) / 5
         nel = net.weights.numel()
+        traffic = None                   # HBM bytes per launch from the committed PMC passes (profiles/r01j_pmc_adamw.json)
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01j_pmc_adamw.json")) as f:
+                pm = json.load(f)
+            traffic = round(pm["hbm_bytes_per_launch"] * nel / pm["elements"])
+        except Exception:
+            pass
         opt_extra = {"kernel": "adamw_bf16_kernel (fused AdamW_BF16 step, all parameters in one launch)",
                      "ms_per_update": round(oms, 2), "params": nel,
                      "roofline": {"bound": "hbm", "achieved": round(20.0 * nel / oms / 1e6, 1), "peak": 8000.0,
-                                  "unit": "GB/s", "frac": round(20.0 * nel / oms / 1e6 / 8000.0, 4), "traffic": None},
+                                  "unit": "GB/s", "frac": round(20.0 * nel / oms / 1e6 / 8000.0, 4), "traffic": traffic},
                      "note": "not part of `value`; one update per gradient_accumulation_steps micro-steps"}
         del opt
     if rank == 0:
