@@ -87,3 +87,36 @@ def test_train_loop_runs_and_updates_weights(setup):
 def test_graft_smoke():
     import __graft_entry__ as G
     G.smoke()
+
+
+def test_train_from_latent_cache_mixed_buckets(setup, tmp_path):
+    """Row f2 in front of the path: cached latents on disk (reference format) -> bucket batches -> pinned prefetch ->
+    NativeSDXLTrainer.train(); two aspect-ratio buckets = two static plans sharing weights and gradients."""
+    import random
+    cfgm, T, cfg, w, net = setup
+    LC = importlib.import_module("sdxl-training-improvements_amd.latent_cache")
+    g = torch.Generator().manual_seed(3)
+    index = None
+    paths = []
+    for i in range(8):
+        h, wd = (16, 16) if i % 2 == 0 else (8, 24)
+        t = {"vae_latents": torch.randn(4, h, wd, generator=g), "time_ids": torch.tensor([[8.0 * h, 8 * wd, 0, 0, 8 * h, 8 * wd]]),
+             "prompt_embeds": torch.randn(77, cfg.cross_attention_dim, generator=g).to(torch.bfloat16),
+             "pooled_prompt_embeds": torch.randn(cfg.pooled_dim, generator=g).to(torch.bfloat16)}
+        bi = {"pixel_dims": [8 * wd, 8 * h], "latent_dims": [wd, h], "bucket_index": i % 2}
+        paths.append(f"/data/img{i}.png")
+        index = LC.write_entry(tmp_path, paths[-1], t, f"caption {i}", bi, index=index)
+    LC.save_index(tmp_path, index)
+    cache = LC.LatentCache(tmp_path)
+    random.seed(0)
+    loader = LC.DevicePrefetcher(LC.CachedLatentLoader(cache, 2, paths), "cuda:0")
+    c = cfgm.Config()
+    c.training.method = "flow_matching"
+    c.training.gradient_accumulation_steps = 2
+    c.optimizer.learning_rate = 1e-4
+    class M: unet = net
+    tr = T.NativeSDXLTrainer(M(), train_dataloader=loader, config=c)
+    tr.train(1)
+    assert tr.optimizer.step_count == 2                   # 4 batches (2 per bucket) / accumulation 2
+    assert torch.isfinite(net.weights.float()).all() and tr.optimizer.exp_avg_sq.float().max().item() > 0
+    net.load_state_dict(w)
