@@ -114,13 +114,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 static constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
-static constexpr int gemm_smem_bytes(int BN, int S, int BK) {
-  int ring = S * (BM + BN) * BK * 2 + 1024, stg = 64 * (BN + 4) * 4;
+static constexpr int gemm_smem_bytes(int BN, int S, int BK, int BMT = BM) {
+  int ring = S * (BMT + BN) * BK * 2 + 1024, stg = 64 * (BN + 4) * 4;
   return ring > stg ? ring : stg;
 }
 // workgroups per CU the register budget is sized for: what the 160 KiB of LDS admits, at most 3 (4-wave) / 1 (8-wave)
-static constexpr int gemm_occupancy(int BN, int S, int BK, int NW) {
-  int byl = (160 * 1024) / gemm_smem_bytes(BN, S, BK);
+static constexpr int gemm_occupancy(int BN, int S, int BK, int NW, int BMT = BM) {
+  int byl = (160 * 1024) / gemm_smem_bytes(BN, S, BK, BMT);
   return NW == 8 ? 1 : (byl > 3 ? 3 : (byl < 1 ? 1 : byl));
 }
 
@@ -131,14 +131,18 @@ static constexpr int gemm_occupancy(int BN, int S, int BK, int NW) {
 //        source is a running pointer (conv: fixed base + uniform offset + border predicate) advanced by a
 //        per-lane constant each K-step (0 for out-of-range rows, which keep pointing at the zero vector), and the DMA
 //        pieces are issued between groups of MFMAs so their issue cost hides under the matrix pipe.
-template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW>
-__global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_kernel(const GemmP p) {
-  constexpr int A_TILE_BYTES = BM * BK * 2;       // [128][BK] or [BK][128] bf16
+// BMT  : output rows per workgroup (128; 256 for the ping-pong configuration)
+// PP   : ping-pong schedule (8 waves = two groups of four, one wave of each group per SIMD): while one group's MFMAs
+//        run, the other group reads its next fragments from LDS and vice versa -- see the main loop
+template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW, int BMT = BM, bool PP = false>
+__global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW, BMT)) void gemm_kernel(const GemmP p) {
+  static_assert(!PP || (FAST && NW == 8 && S >= 3 && FORM != GEMM_TN), "ping-pong: FAST NT / NN, 8 waves, ring >= 3");
+  constexpr int A_TILE_BYTES = BMT * BK * 2;      // [BMT][BK] or [BK][128] bf16
   constexpr int B_TILE_BYTES = BN * BK * 2;       // [BN][BK] or [BK][BN] bf16
   constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
   constexpr int RING_BYTES = S * STAGE_BYTES;     // followed by 1 KiB that absorbs the padding DMA pieces
   constexpr int WGM = NW / 2;                     // wave grid WGM x 2
-  constexpr int MI = BM / (WGM * 16);             // A fragments per wave (4 or 2)
+  constexpr int MI = BMT / (WGM * 16);            // A fragments per wave (4 or 2)
   constexpr int NJ = BN / 32;                     // B fragments per wave (wave tile (16 MI) x BN/2)
   constexpr int NCA = A_TILE_BYTES / 1024;        // 1 KiB DMA chunks of the A tile
   constexpr int NCB = B_TILE_BYTES / 1024;
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
     by = (xcd / px) * tm + lm;
   }
   const int n0 = bx * BN;
-  const int m0 = by * BM;
+  const int m0 = by * BMT;
 #ifdef SDXL_GEMM_DIAG   // scratch diagnostics only (never defined in the product build): knock out one pipeline component
   constexpr int dbg = SDXL_GEMM_DIAG;       // bit 0: no MFMA, bit 1: no DMA in the main loop, bit 2: no fragment reads
 #else
@@ -504,70 +508,93 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
   int rd = 0, wr = S - 1;  // ring slots: read slot of step t, write slot of step t+S-1
   if (dbg & 2) dma_on = false;
   constexpr int KS = BK / 32;
-  struct Frags { bf16x8 a[KS][MI], b[KS][NJ]; };
-  // every fragment read of a K-step is issued in one go (the compiler's counted lgkmcnt waits then let the ks = 0
-  // products start as soon as their operands land while the ks = 1 reads are still in flight)
-  auto read_frags = [&](int slot, Frags& f) {
+  struct FragK { bf16x8 a[MI], b[NJ]; };          // the fragments of one 32-deep half of a K-step
+  // every fragment read of a (K-step, ks) is issued in one go (the compiler's counted lgkmcnt waits then let the
+  // products start as soon as their operands land while later reads are still in flight)
+  auto read_ks = [&](int slot, int ks, FragK& f) {
     const char* At = smem + slot * STAGE_BYTES;
     const char* Bt = At + A_TILE_BYTES;
     if (dbg & 4) {
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
+      for (int i = 0; i < MI; ++i) f.a[i] = ones;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) f.a[ks][i] = ones;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) f.b[ks][j] = ones;
-      }
+      for (int j = 0; j < NJ; ++j) f.b[j] = ones;
       return;
     }
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        if (FORM == GEMM_TN)
-          f.a[ks][i] = frag_nc<128>(At, ks * 32 + g * 8, wm * (MI * 16) + i * 16, l16);
-        else
-          f.a[ks][i] = frag_kc<BK>(At, wm * (MI * 16) + i * 16 + l16, ks * 4 + g);
-        if (i == 0) {
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            if (FORM == GEMM_NT)
-              f.b[ks][j] = frag_kc<BK>(Bt, wn * (BN / 2) + j * 16 + l16, ks * 4 + g);
-            else
-              f.b[ks][j] = frag_nc<BN>(Bt, ks * 32 + g * 8, wn * (BN / 2) + j * 16, l16);
-          }
-        }
-      }
-    }
-  };
-  // the K-step's products; FAST: the DMA pieces of step t + S - 1 (ring slot `wslot`) ride between the MFMA groups
-  auto mfma_step = [&](const Frags& f, int wslot, bool live) {
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (FORM == GEMM_TN && do_bias) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[ks][i], ones, accb[i], 0, 0, 0);
-      }
-      if (!FAST) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
+    for (int i = 0; i < MI; ++i) {
+      if (FORM == GEMM_TN)
+        f.a[i] = frag_nc<128>(At, ks * 32 + g * 8, wm * (MI * 16) + i * 16, l16);
+      else
+        f.a[i] = frag_kc<BK>(At, wm * (MI * 16) + i * 16 + l16, ks * 4 + g);
+      if (i == 0) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          if (dbg & 1) acc[i][j][0] += (float)f.a[ks][i][0] + (float)f.b[ks][j][0];
-          else if (DIRECT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b[ks][j], f.a[ks][i], acc[i][j], 0, 0, 0);
-          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[ks][i], f.b[ks][j], acc[i][j], 0, 0, 0);
-        }
-        if (FAST) {  // one DMA piece per MFMA group
-          constexpr int NSLOT = KS * MI;
-          const int slot = ks * MI + i;
-#pragma unroll
-          for (int pc = 0; pc < NL; ++pc)
-            if (pc % NSLOT == slot) issue_piece(pc, wslot, live);
+          if (FORM == GEMM_NT)
+            f.b[j] = frag_kc<BK>(Bt, wn * (BN / 2) + j * 16 + l16, ks * 4 + g);
+          else
+            f.b[j] = frag_nc<BN>(Bt, ks * 32 + g * 8, wn * (BN / 2) + j * 16, l16);
         }
       }
-      if (!FAST) __builtin_amdgcn_s_setprio(0);
     }
   };
+  // one ks worth of products; FAST: the DMA pieces of step t + S - 1 (ring slot `wslot`) ride between the MFMA groups
+  auto mfma_ks = [&](const FragK& f, int ks, int wslot, bool live) {
+    if (FORM == GEMM_TN && do_bias) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[i], ones, accb[i], 0, 0, 0);
+    }
+    if (!FAST || PP) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if (dbg & 1) acc[i][j][0] += (float)f.a[i][0] + (float)f.b[j][0];
+        else if (DIRECT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b[j], f.a[i], acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+      }
+      if (FAST && !PP) {  // one DMA piece per MFMA group
+        constexpr int NSLOT = KS * MI;
+        const int slot = ks * MI + i;
+#pragma unroll
+        for (int pc = 0; pc < NL; ++pc)
+          if (pc % NSLOT == slot) issue_piece(pc, wslot, live);
+      }
+    }
+    if (!FAST || PP) __builtin_amdgcn_s_setprio(0);
+  };
+  if (PP) {
+    // ---- ping-pong schedule.  Waves 0-3 (group 0, tile rows 0..127) and waves 4-7 (group 1, rows 128..255) share every
+    // barrier but group 1 runs one barrier late, so on each SIMD one wave is in its MFMA phase while the other reads
+    // its next fragments from LDS (and waits for them): the LDS latency chain and the matrix pipe overlap by
+    // construction.  Per wave and K-step u:  B1 | read(u, ks 0) | B2 | mfma(ks 0) + DMA | B3 | read(u, ks 1), vmcnt | B4 |
+    // mfma(ks 1) + DMA.   DMA pieces issued during the products of step u belong to step u + S - 1 and land in the slot of
+    // step u - 1, whose last reader (group 1, ks 1) retired its reads (lgkmcnt 0) before its B4(u - 1), which is group
+    // 0's B1(u) and precedes every product phase of step u.  Step u + 1 is first read by group 0 after its B1(u + 1) =
+    // group 1's B4(u): every wave therefore waits, before its own B4(u), until its pieces of step u + 1 have landed
+    // (outstanding allowed: steps u + 2 .. u + S - 2 and the pieces of step u + S - 1 issued in the ks 0 phase).
+    const int grp = wave >> 2;
+    FragK f[KS];
+    wait_vmcnt<(S - 2) * NL>();                       // step 0 landed (mine)
+    if (grp == 1) __builtin_amdgcn_s_barrier();       // skew
+    for (int t = 0; t < T; ++t) {
+      const bool live = t + S - 1 < T;
+      __builtin_amdgcn_s_barrier();                                   // B1
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) read_ks(rd, ks, f[ks]);
+#pragma unroll
+      for (int pc = 0; pc < NL; ++pc) issue_piece(pc, wr, live);      // DMA of step t + S - 1 -> slot of step t - 1
+      wait_vmcnt<(S - 2) * NL>();                                     // my pieces of step t + 1 have landed
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                   // B2
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) mfma_ks(f[ks], ks, wr, live);
+      advance();
+      rd = rd + 1 == S ? 0 : rd + 1;
+      wr = wr + 1 == S ? 0 : wr + 1;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();       // both groups execute the same number of barriers
+  } else
   // (A register-prefetch variant -- fragments of step t + 1 read while the products of step t run, one ring slot
   // fewer in flight -- was measured on the S >= 3 configurations: 5-20 % slower, so the loop stays as it is.)
   for (int t = 0; t < T; ++t) {
@@ -578,10 +605,12 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
     __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave has finished reading slot `wr` (step t-1)
     const bool live = t + S - 1 < T;
     if (!FAST && live) stage(kt_begin + t + S - 1, wr);
-    Frags f;
-    read_frags(rd, f);
+    FragK f[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) read_ks(rd, ks, f[ks]);
     if (PIPE) __builtin_amdgcn_sched_barrier(0);
-    mfma_step(f, wr, live);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) mfma_ks(f[ks], ks, wr, live);
     if (FAST) advance();   // every piece of step t + S - 1 has been issued
     rd = rd + 1 == S ? 0 : rd + 1;
     wr = wr + 1 == S ? 0 : wr + 1;
@@ -701,7 +730,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
   float* Cs = (float*)smem;
   constexpr int VPR = BN / 8;  // 8-column vectors per tile row
 #pragma unroll 1
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < BMT / 64; ++half) {
     const int wrow = wm * (MI * 16);           // this wave's first row in the tile
     if (wrow / 64 == half) {
 #pragma unroll
@@ -789,17 +818,17 @@ void gemm_defaults(GemmP* p) {
   p->rows_per_batch = 1;
 }
 
-template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW>
+template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW, int BMT = BM, bool PP = false>
 static int launch_k(const GemmP& p, hipStream_t st) {
   static bool attr_set = false;
-  constexpr int smem = gemm_smem_bytes(BN, S, BK);
+  constexpr int smem = gemm_smem_bytes(BN, S, BK, BMT);
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW>,
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW, BMT, PP>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), FORM == GEMM_TN ? p.taps * p.splitk : 1);
-  hipLaunchKernelGGL((gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW>), grid, dim3(NW * 64), smem, st, p);
+  dim3 grid(cdiv(p.N, BN), cdiv(p.M, BMT), FORM == GEMM_TN ? p.taps * p.splitk : 1);
+  hipLaunchKernelGGL((gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW, BMT, PP>), grid, dim3(NW * 64), smem, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -813,6 +842,24 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
       true)
     return launch_k<FORM, true, BN, S, BK, true, NW>(p, st);
   return launch_k<FORM, CONV, BN, S, BK, false, NW>(p, st);
+}
+
+// configurations 10 / 11 (experimental, off by default): 256x128 tile, 8 waves in the ping-pong schedule, BK 64 with a
+// 3-deep ring or BK 32 with a 6-deep ring (145 KiB, 1 workgroup per CU).  FAST staging only (NT / NN); anything else
+// falls back to configuration 1.  Measured: +5..7 % over configuration 1 on large grids (8192^3: 1135 vs 1058 TFLOP/s,
+// 4096x3840x1280: 857 vs 846), equal or slower elsewhere, neutral at step level (SDXL_GEMM_PP_MIN=<tiles> enables it
+// for forward problems with at least that many 256x128 tiles); knock-outs show the read phase (~550 cycles for 4 x 16
+// ds_read_b128 + wait) and the one-step DMA lead of a 3-deep ring, not the MFMA phase (512 cycles), set the pace.
+template <int FORM, bool CONV, int S, int BK>
+static int launch_pp(const GemmP& p, hipStream_t st) {
+  if constexpr (FORM == GEMM_TN) {
+    return launch_cfg<FORM, CONV, 128, 2, 64, 4>(p, st);
+  } else {
+    if (!CONV && p.K % BK == 0) return launch_k<FORM, false, 128, S, BK, true, 8, 256, true>(p, st);
+    if (CONV && p.taps == 9 && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws && p.K % BK == 0)
+      return launch_k<FORM, true, 128, S, BK, true, 8, 256, true>(p, st);
+    return launch_cfg<FORM, CONV, 128, 2, 64, 4>(p, st);
+  }
 }
 
 // Tile / pipeline selection.  Configurations (SDXL_GEMM_CFG=<id> forces one, for benchmarking):
@@ -852,6 +899,13 @@ static int launch_one(const GemmP& p, hipStream_t st) {
     const long t160 = (long)cdiv(p.M, BM) * (p.N / 160);
     if (FORM == GEMM_NT && (c3 & 1) && p.N % 160 == 0 && t160 <= 512) cfg = 3;
   }
+  {   // experiment knob: ping-pong configuration for forward problems with >= pp_min 256x128 tiles
+    static long pp_min = -1;
+    if (pp_min < 0) { const char* e = getenv("SDXL_GEMM_PP_MIN"); pp_min = e ? atol(e) : 0; }
+    static int pp_geglu = -1;
+    if (pp_geglu < 0) { const char* e = getenv("SDXL_GEMM_PP_GEGLU"); pp_geglu = e ? atoi(e) : 0; }
+    if (pp_min > 0 && FORM == GEMM_NT && cfg == 1 && (!p.geglu || pp_geglu) && (long)cdiv(p.M, 256) * cdiv(p.N, 128) >= pp_min) cfg = 10;
+  }
   if (g_force_cfg) cfg = g_force_cfg;
   if (p.geglu && (cfg == 3 || cfg == 6)) cfg = 1;   // the fused GEGLU epilogues need 128-column tiles
   if (cfg == 3 && p.N % 160 != 0) cfg = 4;
@@ -864,6 +918,8 @@ static int launch_one(const GemmP& p, hipStream_t st) {
     case 7: return launch_cfg<FORM, CONV, 128, 4, 32, 4>(p, st);
     case 8: return launch_cfg<FORM, CONV, 128, 3, 32, 4>(p, st);
     case 9: return launch_cfg<FORM, CONV, 128, 6, 32, 8>(p, st);
+    case 10: return launch_pp<FORM, CONV, 3, 64>(p, st);
+    case 11: return launch_pp<FORM, CONV, 6, 32>(p, st);
     default: return launch_cfg<FORM, CONV, 128, 2, 64, 4>(p, st);
   }
 }
