@@ -86,3 +86,36 @@ def test_configs1_shape_step_properties(full):
     assert math.isfinite(n1) and n1 > 0
     assert abs(n2 - n1) <= 2e-3 * n1                       # bf16 d(pred) scaling is the only difference
     assert rel_g <= 5e-3
+
+
+@pytest.mark.parametrize("shape", [(4, 128, 128), (2, 96, 168)], ids=["configs2_1024sq", "configs4_bucket_1344x768"])
+def test_flow_matching_batch_decomposes(full, shape):
+    """BASELINE configs[2] (flow matching, B=4, 1024^2) and the second bucket of configs[4] (1344x768 -> latent 96x168):
+    size-independent property -- the batch loss is the mean of the per-sample losses (every sample has its own t and
+    its rows go through the same kernels), and a batch's gradient is the sum of its samples' gradients."""
+    net = full
+    B, H, W = shape
+    x = _inputs(B, H, W, seed=303 + H)
+    t = torch.sigmoid(torch.randn(B, generator=torch.Generator().manual_seed(9)))
+    probe = "down_blocks.2.attentions.1.transformer_blocks.7.attn2.to_q.weight"
+
+    def run(idx, scale, first):
+        s = slice(idx, idx + 1) if idx is not None else slice(None)
+        net.forward_loss("flow_matching", x["lat"][s], x["noise"][s], t[s], t[s], x["ehs"][s], x["pooled"][s], x["tid"][s])
+        net.backward(scale, first)
+        return net.read_loss()[0]
+
+    net.zero_grads()
+    lb = run(None, 1.0, True)
+    gb = net.export(probe, grad=True).clone()
+    nb = net.grad_norm()
+    net.zero_grads()
+    ls = [run(i, 1.0 / B, i == 0) for i in range(B)]          # per-sample steps accumulated with weight 1/B
+    gs = net.export(probe, grad=True)
+    ns = net.grad_norm()
+    mean = sum(ls) / B
+    rel_g = float((gs - gb).norm() / gb.norm())
+    print(f"[parity] flow matching {B}x{H}x{W}: batch loss {lb:.6f} mean of per-sample {mean:.6f}; |grad| {nb:.4e} vs {ns:.4e}; probe rel {rel_g:.3e}")
+    assert math.isfinite(lb) and 0 < lb < 1000
+    assert abs(lb - mean) <= 1e-3 * abs(lb)
+    assert abs(nb - ns) <= 5e-3 * nb and rel_g <= 1e-2
