@@ -79,60 +79,45 @@ __global__ void gn_stats_kernel(const bf16* __restrict__ x, float* __restrict__ 
   }
 }
 
-// stats[b][g] = (mean, rstd);  coef[b][c] = (a, s) with y = act(a*x + s)
+// stats[b][g] = (mean, rstd).  One 64-lane block per (g, b): lane k sums chunks k, k+64, ... and a fixed-order shuffle
+// tree finishes (order-deterministic, ~2 us instead of a serial walk over up to 256 chunk partials)
 __global__ void gn_finalize_kernel(const bf16* __restrict__ x, const float* __restrict__ part, int chunks,
-                                   const bf16* __restrict__ gamma, const bf16* __restrict__ beta,
-                                   float* __restrict__ stats, float* __restrict__ coef, int HW, int C, int G,
-                                   float eps) {
-  __shared__ float gm[64], gr[64];
-  __shared__ float ps[4][64][2];
-  const int b = blockIdx.x, B = gridDim.x;
+                                   float* __restrict__ stats, int HW, int C, int G, float eps) {
+  const int g = blockIdx.x, b = blockIdx.y, B = gridDim.y;
   const int cpg = C / G;
-  const float n = (float)HW * (float)cpg;
-  {  // fixed-order chunk sum: thread (slice = t/64, g = t%64) adds chunks slice, slice+4, ...
-    const int g = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    float a = 0.f, q = 0.f;
-    if (g < G)
-      for (int k = sl; k < chunks; k += 4) {
-        const float* pp = part + (((long)k * B + b) * G + g) * 2;
-        a += pp[0];
-        q += pp[1];
-      }
-    ps[sl][g][0] = a;
-    ps[sl][g][1] = q;
+  float a = 0.f, q = 0.f;
+  for (int k = threadIdx.x; k < chunks; k += 64) {
+    const float* pp = part + (((long)k * B + b) * G + g) * 2;
+    a += pp[0];
+    q += pp[1];
   }
-  __syncthreads();
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
-    float a = (ps[0][g][0] + ps[1][g][0]) + (ps[2][g][0] + ps[3][g][0]);
-    float q = (ps[0][g][1] + ps[1][g][1]) + (ps[2][g][1] + ps[3][g][1]);
-    float K = (float)x[(long)b * HW * C + g * cpg];
-    float m1 = a / n, m2 = q / n;
-    float var = fmaxf(m2 - m1 * m1, 0.f);
-    float mean = K + m1, rstd = rsqrtf(var + eps);
-    gm[g] = mean;
-    gr[g] = rstd;
-    stats[((long)b * G + g) * 2] = mean;
-    stats[((long)b * G + g) * 2 + 1] = rstd;
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    int g = c / cpg;
-    float a = gr[g] * (float)gamma[c];
-    coef[((long)b * C + c) * 2] = a;
-    coef[((long)b * C + c) * 2 + 1] = (float)beta[c] - gm[g] * a;
+  a = wave_sum(a);
+  q = wave_sum(q);
+  if (threadIdx.x == 0) {
+    const float n = (float)HW * (float)cpg;
+    const float K = (float)x[(long)b * HW * C + g * cpg];
+    const float m1 = a / n, m2 = q / n;
+    const float var = fmaxf(m2 - m1 * m1, 0.f);
+    stats[((long)b * G + g) * 2] = K + m1;
+    stats[((long)b * G + g) * 2 + 1] = rsqrtf(var + eps);
   }
 }
 
+// y = act(a*x + s) with a = rstd*gamma, s = beta - mean*a rebuilt per thread from the 2 statistics of its channels' group
 template <bool SILU>
-__global__ void gn_apply_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, const float* __restrict__ coef,
-                                int HW, int C, int vpr, int rpi, int rows_per_chunk) {
+__global__ void gn_apply_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, const float* __restrict__ stats,
+                                const bf16* __restrict__ gamma, const bf16* __restrict__ beta, int HW, int C, int G,
+                                int vpr, int rpi, int rows_per_chunk) {
   const int b = blockIdx.y;
   const int vec = threadIdx.x % vpr, rsub = threadIdx.x / vpr;
+  const int cpg = C / G;
   float a[8], s[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    a[e] = coef[((long)b * C + vec * 8 + e) * 2];
-    s[e] = coef[((long)b * C + vec * 8 + e) * 2 + 1];
+    const int c = vec * 8 + e, g = c / cpg;
+    const float mean = stats[((long)b * G + g) * 2], rstd = stats[((long)b * G + g) * 2 + 1];
+    a[e] = rstd * (float)gamma[c];
+    s[e] = (float)beta[c] - mean * a[e];
   }
   const bf16* xb = x + (long)b * HW * C;
   bf16* yb = y + (long)b * HW * C;
@@ -156,18 +141,16 @@ int launch_groupnorm_fwd(const bf16* x, bf16* y, const bf16* gamma, const bf16* 
   ARG_CHECK(C / 8 <= 512, "groupnorm: C=%d too wide", C);
   GnGeom g = gn_geom(HW, C);
   float* part = ws;                                      // [chunks][B][G][2]
-  float* coef = ws + (size_t)GN_MAX_CHUNKS * B * G * 2;  // [B][C][2]
   size_t sh = sizeof(float) * 2 * g.rpi * C;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(g.chunks, B), dim3(g.threads), sh, st, x, part, HW, C, G, g.vpr, g.rpi,
                      g.rows_per_chunk);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, x, part, g.chunks, gamma, beta, stats, coef, HW, C,
-                     G, eps);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(64), 0, st, x, part, g.chunks, stats, HW, C, G, eps);
   if (silu)
-    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(g.chunks, B), dim3(g.threads), 0, st, x, y, coef, HW, C, g.vpr,
-                       g.rpi, g.rows_per_chunk);
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(g.chunks, B), dim3(g.threads), 0, st, x, y, stats, gamma, beta, HW, C,
+                       G, g.vpr, g.rpi, g.rows_per_chunk);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(g.chunks, B), dim3(g.threads), 0, st, x, y, coef, HW, C, g.vpr,
-                       g.rpi, g.rows_per_chunk);
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(g.chunks, B), dim3(g.threads), 0, st, x, y, stats, gamma, beta, HW, C,
+                       G, g.vpr, g.rpi, g.rows_per_chunk);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -225,15 +208,16 @@ __global__ void gn_bwd_reduce_kernel(const bf16* __restrict__ x, const bf16* __r
   }
 }
 
-// fixed-order sum over chunks: block = 64 channels x 4 chunk slices -> sums[b][c][2]
-__global__ void gn_bwd_chunksum_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ sums) {
-  __shared__ float ps[4][64][2];
+// fixed-order sum over chunks: block = 64 channels x 16 chunk slices -> sums[b][c][2]
+__global__ __launch_bounds__(1024) void gn_bwd_chunksum_kernel(const float* __restrict__ part, int chunks, int C,
+                                                               float* __restrict__ sums) {
+  __shared__ float ps[16][64][2];
   const int b = blockIdx.y, B = gridDim.y;
   const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   float a = 0.f, q = 0.f;
   if (c < C)
-    for (int k = sl; k < chunks; k += 4) {
+    for (int k = sl; k < chunks; k += 16) {
       const float* pp = part + (((long)k * B + b) * C + c) * 2;
       a += pp[0];
       q += pp[1];
@@ -242,8 +226,11 @@ __global__ void gn_bwd_chunksum_kernel(const float* __restrict__ part, int chunk
   ps[sl][cl][1] = q;
   __syncthreads();
   if (sl == 0 && c < C) {
-    sums[((long)b * C + c) * 2] = (ps[0][cl][0] + ps[1][cl][0]) + (ps[2][cl][0] + ps[3][cl][0]);
-    sums[((long)b * C + c) * 2 + 1] = (ps[0][cl][1] + ps[1][cl][1]) + (ps[2][cl][1] + ps[3][cl][1]);
+    float ta = 0.f, tq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { ta += ps[k][cl][0]; tq += ps[k][cl][1]; }
+    sums[((long)b * C + c) * 2] = ta;
+    sums[((long)b * C + c) * 2 + 1] = tq;
   }
 }
 
@@ -347,7 +334,7 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const
   else
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<false>, dim3(g.chunks, B), dim3(g.threads), sh, st, x, dy, gamma, beta,
                        stats, part, HW, C, G, g.vpr, g.rpi, g.rows_per_chunk);
-  hipLaunchKernelGGL(gn_bwd_chunksum_kernel, dim3(cdiv(C, 64), B), dim3(256), 0, st, part, g.chunks, C, sums);
+  hipLaunchKernelGGL(gn_bwd_chunksum_kernel, dim3(cdiv(C, 64), B), dim3(1024), 0, st, part, g.chunks, C, sums);
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), sizeof(float) * (2 * C + 2 * G), st, sums, g.chunks,
                      gamma, stats, coef, dgamma, dbeta, HW, C, G);
 #define GN_BWD_APPLY(S, A)                                                                                          \
