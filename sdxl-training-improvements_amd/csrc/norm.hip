@@ -351,41 +351,44 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const
 // LayerNorm: 16 lanes per row, NV 16-byte vectors per lane (C = 128*NV), whole row in registers,
 // exact two-pass mean/variance.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float group16_sum(float v) {
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
   v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  if (LPR == 32) v += __shfl_xor(v, 16, 64);
   return v;
 }
 
-template <int NV>
+// LPR lanes per row (16, or 32 for wide rows: twice the waves in flight for the same bytes), NV vectors per lane
+template <int NV, int LPR>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, const bf16* __restrict__ gamma,
                               const bf16* __restrict__ beta, float* __restrict__ stats, int M, float eps) {
-  constexpr int C = NV * 128;
-  const int sub = threadIdx.x & 15;
-  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+  constexpr int C = NV * LPR * 8;
+  const int sub = threadIdx.x & (LPR - 1);
+  const int row = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
   if (row >= M) return;  // whole 16-lane group exits together
   bf16x8 v[NV];
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    v[i] = *(const bf16x8*)(x + (long)row * C + (i * 16 + sub) * 8);
+    v[i] = *(const bf16x8*)(x + (long)row * C + (i * LPR + sub) * 8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) sum += (float)v[i][e];
   }
-  const float mean = group16_sum(sum) * (1.f / C);
+  const float mean = group_sum<LPR>(sum) * (1.f / C);
   float sq = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { float d = (float)v[i][e] - mean; sq += d * d; }
-  const float rstd = rsqrtf(group16_sum(sq) * (1.f / C) + eps);
+  const float rstd = rsqrtf(group_sum<LPR>(sq) * (1.f / C) + eps);
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    bf16x8 gv = *(const bf16x8*)(gamma + (i * 16 + sub) * 8);
-    bf16x8 bv = *(const bf16x8*)(beta + (i * 16 + sub) * 8);
+    bf16x8 gv = *(const bf16x8*)(gamma + (i * LPR + sub) * 8);
+    bf16x8 bv = *(const bf16x8*)(beta + (i * LPR + sub) * 8);
     bf16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (bf16)(((float)v[i][e] - mean) * rstd * (float)gv[e] + (float)bv[e]);
-    *(bf16x8*)(y + (long)row * C + (i * 16 + sub) * 8) = o;
+    *(bf16x8*)(y + (long)row * C + (i * LPR + sub) * 8) = o;
   }
   if (sub == 0) { stats[(long)row * 2] = mean; stats[(long)row * 2 + 1] = rstd; }
 }
@@ -393,34 +396,45 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
 int launch_layernorm_fwd(const bf16* x, bf16* y, const bf16* gamma, const bf16* beta, float* stats, int M, int C,
                          float eps, hipStream_t st) {
   ARG_CHECK(C % 128 == 0, "layernorm: C=%d must be a multiple of 128", C);
-  dim3 grid(cdiv(M, 16)), blk(256);
-  switch (C / 128) {
-#define LN_CASE(NV) case NV: hipLaunchKernelGGL(ln_fwd_kernel<NV>, grid, blk, 0, st, x, y, gamma, beta, stats, M, eps); break;
-    LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(8) LN_CASE(10)
+  dim3 blk(256);
+  if (C % 256 == 0 && C >= 1024) {      // wide rows: 32 lanes per row
+    dim3 grid(cdiv(M, 8));
+    switch (C / 256) {
+#define LN_CASE(NV) case NV: hipLaunchKernelGGL((ln_fwd_kernel<NV, 32>), grid, blk, 0, st, x, y, gamma, beta, stats, M, eps); break;
+      LN_CASE(4) LN_CASE(5) LN_CASE(8) LN_CASE(10)
 #undef LN_CASE
-    default: ARG_CHECK(false, "layernorm: C=%d not instantiated", C);
+      default: ARG_CHECK(false, "layernorm: C=%d not instantiated", C);
+    }
+  } else {
+    dim3 grid(cdiv(M, 16));
+    switch (C / 128) {
+#define LN_CASE(NV) case NV: hipLaunchKernelGGL((ln_fwd_kernel<NV, 16>), grid, blk, 0, st, x, y, gamma, beta, stats, M, eps); break;
+      LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7)
+#undef LN_CASE
+      default: ARG_CHECK(false, "layernorm: C=%d not instantiated", C);
+    }
   }
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
 
 // backward, dx: same geometry as forward (16 lanes per row), nothing carried between rows
-template <int NV, bool ACC>
+template <int NV, int LPR, bool ACC>
 __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                  const bf16* __restrict__ gamma, const float* __restrict__ stats,
                                  bf16* dx, const bf16* addend, int M) {
-  constexpr int C = NV * 128;
-  const int sub = threadIdx.x & 15;
-  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+  constexpr int C = NV * LPR * 8;
+  const int sub = threadIdx.x & (LPR - 1);
+  const int row = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
   if (row >= M) return;
   const float mean = stats[(long)row * 2], rstd = stats[(long)row * 2 + 1];
   bf16x8 v[NV], d[NV];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    v[i] = *(const bf16x8*)(x + (long)row * C + (i * 16 + sub) * 8);
-    d[i] = *(const bf16x8*)(dy + (long)row * C + (i * 16 + sub) * 8);
-    bf16x8 gv = *(const bf16x8*)(gamma + (i * 16 + sub) * 8);
+    v[i] = *(const bf16x8*)(x + (long)row * C + (i * LPR + sub) * 8);
+    d[i] = *(const bf16x8*)(dy + (long)row * C + (i * LPR + sub) * 8);
+    bf16x8 gv = *(const bf16x8*)(gamma + (i * LPR + sub) * 8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float h = ((float)v[i][e] - mean) * rstd;
@@ -429,13 +443,13 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16* __restrict__
       s2 += t * h;
     }
   }
-  s1 = group16_sum(s1) * (1.f / C);
-  s2 = group16_sum(s2) * (1.f / C);
+  s1 = group_sum<LPR>(s1) * (1.f / C);
+  s2 = group_sum<LPR>(s2) * (1.f / C);
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    bf16x8 gv = *(const bf16x8*)(gamma + (i * 16 + sub) * 8);
+    bf16x8 gv = *(const bf16x8*)(gamma + (i * LPR + sub) * 8);
     bf16x8 o;
-    if (ACC) o = *(const bf16x8*)(addend + (long)row * C + (i * 16 + sub) * 8);
+    if (ACC) o = *(const bf16x8*)(addend + (long)row * C + (i * LPR + sub) * 8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float h = ((float)v[i][e] - mean) * rstd;
@@ -444,7 +458,7 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16* __restrict__
       if (ACC) g += (float)o[e];
       o[e] = (bf16)g;
     }
-    *(bf16x8*)(dx + (long)row * C + (i * 16 + sub) * 8) = o;
+    *(bf16x8*)(dx + (long)row * C + (i * LPR + sub) * 8) = o;
   }
 }
 
@@ -520,17 +534,33 @@ int launch_layernorm_bwd_dx(const bf16* x, const bf16* dy, const bf16* gamma, co
                             const bf16* addend, int M, int C, hipStream_t st) {
   ARG_CHECK(C % 128 == 0, "layernorm bwd: C=%d must be a multiple of 128", C);
   const int accumulate = addend != nullptr;
-  dim3 grid(cdiv(M, 16)), blk(256);
-  switch (C / 128) {
-#define LN_CASE(NV)                                                                                            \
-  case NV:                                                                                                     \
-    if (accumulate) hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, true>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, M); \
-    else hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, false>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, M);         \
-    break;
-    LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(8) LN_CASE(10)
-#undef LN_CASE
-    default: ARG_CHECK(false, "layernorm bwd: C=%d not instantiated", C);
+  dim3 blk(256);
+#define LN_LAUNCH(NV, LPR, grid)                                                                                        \
+  if (accumulate) hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, LPR, true>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, M); \
+  else hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, LPR, false>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, M);
+  if (C % 256 == 0 && C >= 1024) {
+    dim3 grid(cdiv(M, 8));
+    switch (C / 256) {
+      case 4: { LN_LAUNCH(4, 32, grid) } break;
+      case 5: { LN_LAUNCH(5, 32, grid) } break;
+      case 8: { LN_LAUNCH(8, 32, grid) } break;
+      case 10: { LN_LAUNCH(10, 32, grid) } break;
+      default: ARG_CHECK(false, "layernorm bwd: C=%d not instantiated", C);
+    }
+  } else {
+    dim3 grid(cdiv(M, 16));
+    switch (C / 128) {
+      case 1: { LN_LAUNCH(1, 16, grid) } break;
+      case 2: { LN_LAUNCH(2, 16, grid) } break;
+      case 3: { LN_LAUNCH(3, 16, grid) } break;
+      case 4: { LN_LAUNCH(4, 16, grid) } break;
+      case 5: { LN_LAUNCH(5, 16, grid) } break;
+      case 6: { LN_LAUNCH(6, 16, grid) } break;
+      case 7: { LN_LAUNCH(7, 16, grid) } break;
+      default: ARG_CHECK(false, "layernorm bwd: C=%d not instantiated", C);
+    }
   }
+#undef LN_LAUNCH
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
