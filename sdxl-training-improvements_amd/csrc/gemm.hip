@@ -832,16 +832,16 @@ static int launch_k(const GemmP& p, hipStream_t st) {
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-template <int FORM, bool CONV, int BN, int S, int BK, int NW>
+template <int FORM, bool CONV, int BN, int S, int BK, int NW, int BMT = BM>
 static int launch_cfg(const GemmP& p, hipStream_t st) {
   static int nofast = -1;
   if (nofast < 0) { const char* e = getenv("SDXL_GEMM_NOFAST"); nofast = e ? atoi(e) : 0; }   // 1: all, 2: conv only
-  if (!CONV && p.K % BK == 0 && nofast != 1) return launch_k<FORM, false, BN, S, BK, true, NW>(p, st);
+  if (!CONV && p.K % BK == 0 && nofast != 1) return launch_k<FORM, false, BN, S, BK, true, NW, BMT>(p, st);
   // same-size stride-1 3x3 convolutions (all but the two downsamplers, their transposed dgrads and conv_in)
   if (CONV && nofast == 0 && p.taps == 9 && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws && p.K % BK == 0 &&
       true)
-    return launch_k<FORM, true, BN, S, BK, true, NW>(p, st);
-  return launch_k<FORM, CONV, BN, S, BK, false, NW>(p, st);
+    return launch_k<FORM, true, BN, S, BK, true, NW, BMT>(p, st);
+  return launch_k<FORM, CONV, BN, S, BK, false, NW, BMT>(p, st);
 }
 
 // configurations 10 / 11 (experimental, off by default): 256x128 tile, 8 waves in the ping-pong schedule, BK 64 with a
@@ -868,6 +868,9 @@ static int launch_pp(const GemmP& p, hipStream_t st) {
 //   3: 128x160, BK 64, 4-deep ring, 8 waves  (145 KiB LDS, 1 per CU, 3 K-steps of DMA in flight)
 //   4: 128x128, BK 64, 4-deep ring, 8 waves  (129 KiB LDS, 1 per CU)
 //   5: 128x128, BK 64, 3-deep ring, 4 waves  (97 KiB LDS, 1 per CU)
+//  13: 128x160, BK 64, 2-deep ring, 4 waves x (64x80)  (73 KiB, 2 per CU)            -- where 160-wide tiles fill the rounds
+//  (a 64x160 variant for the N = 1280 dgrads was +4 % in isolation and -5 % at step level: twice the workgroups crowd
+//   out the side stream's wgrad)
 static int g_force_cfg = -1;
 template <int FORM, bool CONV>
 static int launch_one(const GemmP& p, hipStream_t st) {
@@ -885,20 +888,27 @@ static int launch_one(const GemmP& p, hipStream_t st) {
     if ((e = getenv("SDXL_GEMM_NN_SMALL"))) nn_small = atoi(e);
     if ((e = getenv("SDXL_GEMM_NN_BIG"))) nn_big = atoi(e);
   }
-  const long blocks = (long)cdiv(p.M, BM) * cdiv(p.N, 128) * (FORM == GEMM_TN ? p.taps * p.splitk : 1);
+  // Tile-count quantisation decides most of it on this model's shapes: a launch of t workgroups runs in
+  // ceil(t / 512) rounds of (256 CUs x 2 resident workgroups), so e.g. an N = 640 output at M = 16384 is 640 tiles of
+  // 128x128 (1.25 rounds, 62 % of the slots used) but exactly 512 tiles of 128x160.
+  const long zmul = FORM == GEMM_TN ? p.taps * p.splitk : 1;
+  const long blocks = (long)cdiv(p.M, BM) * cdiv(p.N, 128) * zmul;
+  const bool n160 = p.N % 160 == 0 && !p.geglu;
+  const long t160 = n160 ? (long)cdiv(p.M, BM) * (p.N / 160) * zmul : 0;
+  auto fill = [](long t) { const long cap = 512; return (double)t / (double)(((t + cap - 1) / cap) * cap); };
+  static int sel = -1;
+  if (sel < 0) { const char* e = getenv("SDXL_GEMM_SEL"); sel = e ? atoi(e) : 1; }
   // the transpose-read forms (dgrad / wgrad) spend twice the LDS-read issue slots per K-step: BK = 32 variants with
-  // 3-4 workgroups per CU hide that better on large grids; wgrad runs beside dgrad on the side stream and is kept in
-  // a small-LDS configuration so that both co-reside on a CU
+  // 3-4 workgroups per CU hide that better on large grids
   if (FORM == GEMM_NN) cfg = blocks >= 700 ? nn_big : nn_small;
   if (FORM == GEMM_TN) cfg = CONV ? tnc_cfg : tn_cfg;
-  // forward problems that tile into at most two rounds of one 128x160 workgroup per CU (N = 1280 / 640 wide outputs
-  // at M <= 16K rows, the 640- and 1280-channel convs): the 8-wave, 4-deep-ring configuration keeps 3 K-steps of DMA
-  // in flight and wins +15..30 % there.  Not for dgrad / wgrad: a one-per-CU workgroup on one stream starves the
-  // other stream's kernels of LDS (168 vs 152 ms/step).
-  {
-    const long t160 = (long)cdiv(p.M, BM) * (p.N / 160);
-    if (FORM == GEMM_NT && (c3 & 1) && p.N % 160 == 0 && t160 <= 512) cfg = 3;
-  }
+  // 128x160 tiles, 4 waves x (64x80), 2-deep, 73 KiB (2 per CU): where they fill the rounds at least as well as 128x128
+  // they also move 10 % fewer operand bytes per flop (measured +5..45 %: 16384x640x2560 641 -> 931 TFLOP/s)
+  if (sel && n160 && t160 > 256 && fill(t160) * 1.05 >= fill(blocks)) cfg = 13;
+  // forward problems that fit one round of one 128x160 workgroup per CU (N = 1280 outputs at M = 4096, the 1280-channel
+  // convs): the 8-wave, 4-deep-ring configuration keeps 3 K-steps of DMA in flight and wins +15..30 % there.  Not for
+  // dgrad / wgrad: a one-per-CU workgroup on one stream starves the other stream's kernels of LDS (168 vs 152 ms/step).
+  if (FORM == GEMM_NT && (c3 & 1) && n160 && t160 <= (sel ? 256 : 512)) cfg = 3;
   {   // experiment knob: ping-pong configuration for forward problems with >= pp_min 256x128 tiles
     static long pp_min = -1;
     if (pp_min < 0) { const char* e = getenv("SDXL_GEMM_PP_MIN"); pp_min = e ? atol(e) : 0; }
@@ -907,8 +917,9 @@ static int launch_one(const GemmP& p, hipStream_t st) {
     if (pp_min > 0 && FORM == GEMM_NT && cfg == 1 && (!p.geglu || pp_geglu) && (long)cdiv(p.M, 256) * cdiv(p.N, 128) >= pp_min) cfg = 10;
   }
   if (g_force_cfg) cfg = g_force_cfg;
-  if (p.geglu && (cfg == 3 || cfg == 6)) cfg = 1;   // the fused GEGLU epilogues need 128-column tiles
+  if (p.geglu && (cfg == 3 || cfg == 6 || cfg == 13)) cfg = 1;   // the fused GEGLU epilogues need 128-column tiles
   if (cfg == 3 && p.N % 160 != 0) cfg = 4;
+  if (cfg == 13 && p.N % 160 != 0) cfg = 1;
   switch (cfg) {
     case 2: return launch_cfg<FORM, CONV, 128, 2, 32, 4>(p, st);
     case 3: return launch_cfg<FORM, CONV, 160, 4, 64, 8>(p, st);
@@ -918,6 +929,7 @@ static int launch_one(const GemmP& p, hipStream_t st) {
     case 7: return launch_cfg<FORM, CONV, 128, 4, 32, 4>(p, st);
     case 8: return launch_cfg<FORM, CONV, 128, 3, 32, 4>(p, st);
     case 9: return launch_cfg<FORM, CONV, 128, 6, 32, 8>(p, st);
+    case 13: return launch_cfg<FORM, CONV, 160, 2, 64, 4>(p, st);
     case 10: return launch_pp<FORM, CONV, 3, 64>(p, st);
     case 11: return launch_pp<FORM, CONV, 6, 32>(p, st);
     default: return launch_cfg<FORM, CONV, 128, 2, 64, 4>(p, st);
