@@ -496,8 +496,9 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW, BMT)) void g
 
   // ---- S-deep ring: K-steps t+1 .. t+S-1 are in flight (LDS-DMA) while step t is multiplied ----
   const int T = kt_end - kt_begin;
+  constexpr int U = (PP && BK == 32) ? 2 : 1;   // ping-pong, BK = 32: two K-steps per phase (finer DMA granularity, same phase length)
 #pragma unroll
-  for (int d = 0; d < S - 1; ++d) {
+  for (int d = 0; d < S - U; ++d) {
     if (d < T) stage(kt_begin + d, d);
     else if (FAST) {                       // keep the vmcnt arithmetic uniform: same number of loads every step
 #pragma unroll
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW, BMT)) void g
       advance();
     }
   }
-  int rd = 0, wr = S - 1;  // ring slots: read slot of step t, write slot of step t+S-1
+  int rd = 0, wr = S - U;  // ring slots: read slot of step t, write slot of step t + S - U
   if (dbg & 2) dma_on = false;
   constexpr int KS = BK / 32;
   struct FragK { bf16x8 a[MI], b[NJ]; };          // the fragments of one 32-deep half of a K-step
@@ -574,24 +575,33 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW, BMT)) void g
     // group 1's B4(u): every wave therefore waits, before its own B4(u), until its pieces of step u + 1 have landed
     // (outstanding allowed: steps u + 2 .. u + S - 2 and the pieces of step u + S - 1 issued in the ks 0 phase).
     const int grp = wave >> 2;
-    FragK f[KS];
-    wait_vmcnt<(S - 2) * NL>();                       // step 0 landed (mine)
+    FragK f[KS * U];
+    wait_vmcnt<(S - 2 * U) * NL>();                   // steps 0 .. U-1 landed (mine)
     if (grp == 1) __builtin_amdgcn_s_barrier();       // skew
-    for (int t = 0; t < T; ++t) {
-      const bool live = t + S - 1 < T;
+    for (int t = 0; t < T; t += U) {
       __builtin_amdgcn_s_barrier();                                   // B1
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) read_ks(rd, ks, f[ks]);
+      for (int u = 0; u < U; ++u) {
+        const int slot = rd + u >= S ? rd + u - S : rd + u;
 #pragma unroll
-      for (int pc = 0; pc < NL; ++pc) issue_piece(pc, wr, live);      // DMA of step t + S - 1 -> slot of step t - 1
-      wait_vmcnt<(S - 2) * NL>();                                     // my pieces of step t + 1 have landed
+        for (int ks = 0; ks < KS; ++ks) read_ks(slot, ks, f[u * KS + ks]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {                                   // DMA of steps t + S - U + u -> slots of steps t - U + u
+        const bool live = t + u + S - U < T;
+#pragma unroll
+        for (int pc = 0; pc < NL; ++pc) issue_piece(pc, wr, live);
+        advance();
+        wr = wr + 1 == S ? 0 : wr + 1;
+      }
+      wait_vmcnt<(S - 2 * U) * NL>();                                 // my pieces of the next iteration's steps have landed
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                   // B2
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) mfma_ks(f[ks], ks, wr, live);
-      advance();
-      rd = rd + 1 == S ? 0 : rd + 1;
-      wr = wr + 1 == S ? 0 : wr + 1;
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) mfma_ks(f[u * KS + ks], ks, 0, false);
+      rd = rd + U >= S ? rd + U - S : rd + U;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();       // both groups execute the same number of barriers
   } else
@@ -855,8 +865,8 @@ static int launch_pp(const GemmP& p, hipStream_t st) {
   if constexpr (FORM == GEMM_TN) {
     return launch_cfg<FORM, CONV, 128, 2, 64, 4>(p, st);
   } else {
-    if (!CONV && p.K % BK == 0) return launch_k<FORM, false, 128, S, BK, true, 8, 256, true>(p, st);
-    if (CONV && p.taps == 9 && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws && p.K % BK == 0)
+    if (!CONV && p.K % 64 == 0) return launch_k<FORM, false, 128, S, BK, true, 8, 256, true>(p, st);
+    if (CONV && p.taps == 9 && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws && p.K % 64 == 0)
       return launch_k<FORM, true, 128, S, BK, true, 8, 256, true>(p, st);
     return launch_cfg<FORM, CONV, 128, 2, 64, 4>(p, st);
   }
