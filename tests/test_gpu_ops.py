@@ -124,7 +124,10 @@ def _conv_ref(x_nhwc, w_native, bias, stride):
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(1, 8, 8, 64, 64, 1), (2, 16, 12, 320, 640, 1),
                                                    (2, 16, 16, 64, 128, 2), (1, 12, 20, 8, 320, 1),
-                                                   (2, 8, 8, 192, 8, 1), (1, 32, 32, 960, 320, 1)])
+                                                   (2, 8, 8, 192, 8, 1), (1, 32, 32, 960, 320, 1),
+                                                   # the 1344x768 bucket's level widths (84, 42): the wgrad fast path's
+                                                   # incremental (y, x) tracking wraps rows mid-K-step there
+                                                   (2, 24, 42, 128, 64, 1), (1, 48, 84, 64, 128, 1), (3, 10, 42, 64, 64, 1)])
 def test_conv3x3_fwd_dgrad_wgrad(L, B, H, W, Cin, Cout, stride):
     x = rnd(B, H, W, Cin, seed=10)
     w = rnd(Cout, 9, Cin, seed=11, scale=(9 * Cin) ** -0.5)
