@@ -56,6 +56,42 @@ def test_cfg1_loss_matches_cpu_oracle(full):
     assert abs(pred_scale - ref["metrics"]["pred_scale"]) <= 2e-2 * ref["metrics"]["pred_scale"]
 
 
+PROBES = ["conv_in.weight", "down_blocks.1.attentions.0.transformer_blocks.1.attn1.to_k.weight",
+          "down_blocks.2.attentions.1.transformer_blocks.9.ff.net.0.proj.weight", "mid_block.resnets.0.conv2.weight",
+          "mid_block.attentions.0.transformer_blocks.5.attn2.to_v.weight", "up_blocks.0.attentions.2.transformer_blocks.0.norm2.weight",
+          "up_blocks.1.resnets.1.conv_shortcut.weight", "up_blocks.2.resnets.2.time_emb_proj.bias", "conv_out.weight"]
+
+
+def test_cfg1_gradients_match_cpu_oracle(full):
+    """cfg 1 at full size, backward: gradients of probe parameters spread over the network (first and last layer,
+    self / cross attention projections, the packed GEGLU projection, convs, a shortcut, norm and bias vectors) against
+    autograd through the fp32 CPU oracle on identical inputs (~1 minute of host CPU)."""
+    net = full
+    x = _inputs(1, 64, 64, seed=404)
+    ts = torch.tensor([377])
+    sig = R.karras_sigmas()[ts]
+    net.zero_grads()
+    net.forward_loss("ddpm", x["lat"], x["noise"], sig, ts.float(), x["ehs"], x["pooled"], x["tid"])
+    net.backward(1.0, True)
+    w = U.synth_weights(U.SDXL_BASE, seed=0)
+    for k in PROBES:
+        w[k].requires_grad_(True)
+    ref = R.compute_loss_ddpm(lambda s, t, e, p, ti: U.unet_forward(w, s, t, e, p, ti, U.SDXL_BASE),
+                              {"vae_latents": x["lat"], "prompt_embeds": x["ehs"], "pooled_prompt_embeds": x["pooled"],
+                               "time_ids": x["tid"]}, x["noise"], ts)
+    grads = torch.autograd.grad(ref["loss"], [w[k] for k in PROBES])
+    worst = 1.0
+    for k, gr in zip(PROBES, grads):
+        gh = net.export(k, grad=True).float().cpu().reshape(gr.shape)
+        a, b = gh.double().flatten(), gr.double().flatten()
+        cos = float((a @ b) / (a.norm() * b.norm()))       # (F.cosine_similarity clamps norms at 1e-8: these are ~1e-12)
+        rl2 = float((gh - gr).norm() / gr.norm())
+        print(f"[parity] FULL SDXL cfg1 grad {k}: cos {cos:.6f} rel-L2 {rl2:.3e} |g| {float(gr.norm()):.3e}")
+        worst = min(worst, cos)
+        assert rl2 <= 6e-2, (k, rl2)
+    assert worst >= 0.998
+
+
 def test_configs1_shape_step_properties(full):
     """BASELINE configs[1] (B=4, 1024^2): reproducible loss, finite gradients, accumulation = sum of micro-steps."""
     net = full
