@@ -687,7 +687,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW, BMT)) void g
     }
   };
   if (FORM == GEMM_TN || !p.geglu) {
-    if (FORM != GEMM_TN) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // MFMA results -> inline-asm VALU reads below
+    if (FORM != GEMM_TN) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // 24 wait states: MFMA results -> inline-asm VALU reads below (XDL write -> VALU read needs up to 18)
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = m0 + wm * (MI * 16) + i * 16 + l16;
