@@ -100,6 +100,11 @@ int sdxl_forward_loss(sdxl_handle* h, const sdxl_loss_config* lc, const sdxl_bat
 int sdxl_num_segments(sdxl_handle* h);
 int sdxl_segment_range(sdxl_handle* h, int seg, size_t* grad_elem_offset, size_t* grad_elems);
 int sdxl_backward_segment(sdxl_handle* h, int seg, float grad_scale, int first_micro, void* stream);
+/* By default the stream waits, at the end of every segment, for that segment's weight gradients (they run on an internal
+ * side stream), so a caller can hand the segment to the gradient exchange.  A caller that consumes gradients only after
+ * the whole backward (single GPU, or accumulation micro-steps without exchange) may set last_only = 1: the wait then
+ * happens once, in the last segment (sdxl_loss_fwd_bwd always ends with it). */
+int sdxl_set_join_mode(sdxl_handle* h, int last_only);
 /* convenience: forward + all backward segments */
 int sdxl_loss_fwd_bwd(sdxl_handle* h, const sdxl_loss_config* lc, const sdxl_batch* b, float grad_scale,
                       int first_micro, void* stream);

@@ -304,6 +304,11 @@ int sdxl_forward_loss(sdxl_handle* h, const sdxl_loss_config* lc, const sdxl_bat
 }
 
 int sdxl_num_segments(sdxl_handle* h) { return h ? h->e.nseg : -1; }
+int sdxl_set_join_mode(sdxl_handle* h, int last_only) {
+  H_CHECK(h);
+  h->e.join_last_only = last_only != 0;
+  return 0;
+}
 
 int sdxl_segment_range(sdxl_handle* h, int k, size_t* off, size_t* n) {
   H_CHECK(h);
@@ -319,7 +324,10 @@ static int run_backward_segment(Engine& e, int k, bool first, hipStream_t st) {
   int s = e.nseg - 1 - k;
   e.ev_used = 0;   // per-op events are consumed in order; a segment's waits are all enqueued before the pool is reused
   for (int i = p.seg_last_op[s]; i >= p.seg_first_op[s] && i >= 0; --i) CHK(p.ops[i]->bwd(p, st, first));
-  if (e.use_side && e.side) {  // the segment's weight gradients are complete once `st` passes this point
+  // the segment's weight gradients are complete once `st` passes this point -- unless the caller declared (sdxl_set_join_mode)
+  // that it only needs that of the whole backward (no per-segment gradient exchange): then the side stream runs free
+  // until the last segment (nothing on the main stream reads a weight gradient, and no gradient buffer is reused)
+  if (e.use_side && e.side && !(e.join_last_only && k != e.nseg - 1)) {
     HIP_CHECK_RET(hipEventRecord(e.ev_join, e.side));
     HIP_CHECK_RET(hipStreamWaitEvent(st, e.ev_join, 0));
   }

@@ -114,6 +114,7 @@ struct Engine {
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
   bool use_side = true;
+  bool join_last_only = false;   // sdxl_set_join_mode: main waits for the side stream at the last segment only
   hipEvent_t next_event();
   // builder state
   bool registering = true;

@@ -78,6 +78,7 @@ SIGNATURES = {
     "sdxl_op_groupnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "sdxl_op_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "sdxl_op_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "sdxl_set_join_mode": [_vp, _i],
     "sdxl_sumsq": [_vp, _i, _sz, _vp, _vp],
     "sdxl_clip_coef": [_vp, _f, _vp, _vp],
     "sdxl_param_range": [_vp, _i, _P(_sz), _P(_sz)],

@@ -183,6 +183,7 @@ class NativeUNet:
     def backward(self, grad_scale: float = 1.0, first_micro: bool = True, on_segment=None) -> None:
         """All backward segments in reverse execution order; `on_segment(k, offset, count)` is called after segment
         k's kernels are enqueued (used to start that bucket's gradient all-reduce under the rest of backward)."""
+        lib.check(self.L.sdxl_set_join_mode(self.h, 0 if on_segment is not None else 1))   # per-segment results needed?
         for k in range(self.num_segments):
             lib.check(self.L.sdxl_backward_segment(self.h, k, float(grad_scale), int(first_micro), _stream()),
                       f"backward segment {k}")
