@@ -43,6 +43,21 @@ def test_bad_arguments_are_reported_not_crashed():
     assert L.sdxl_default_config(None) == 1 and b"null" in L.sdxl_last_error()
     assert L.sdxl_bind_params(None, None, None) == 1
     assert L.sdxl_num_params(None) == -1
+    # row f1 / f3 entry points: argument errors are reported before anything touches a device
+    import ctypes as C
+    cfg = lib.AdamWConfig()
+    assert L.sdxl_adamw_default_config(C.byref(cfg)) == 0 and cfg.beta1 == 0.9 and cfg.reference_ema == 1
+    assert L.sdxl_adamw_default_config(None) == 1
+    buf = (C.c_char * 256)()
+    p16 = C.c_void_p((C.addressof(buf) + 15) & ~15)
+    assert L.sdxl_adamw_bf16_step(p16, p16, 0, p16, p16, p16, 7, C.byref(cfg), None, None, None) == 1      # n % 8
+    assert b"multiple of 8" in L.sdxl_last_error()
+    assert L.sdxl_adamw_bf16_step(p16, p16, 5, p16, p16, p16, 8, C.byref(cfg), None, None, None) == 1      # dtype
+    cfg.beta2 = 1.5
+    assert L.sdxl_adamw_bf16_step(p16, p16, 0, p16, p16, p16, 8, C.byref(cfg), None, None, None) == 1      # hyper-parameters
+    assert L.sdxl_adamw_bf16_step(None, p16, 0, p16, p16, p16, 8, None, None, None, None) == 1
+    assert L.sdxl_sumsq(None, 0, 8, None, None) == 1 and L.sdxl_clip_coef(None, 1.0, None, None) == 1
+    assert L.sdxl_set_join_mode(None, 1) == 1 and L.sdxl_param_range(None, 0, None, None) == 1
 
 
 def test_config_yaml_rule(tmp_path):
