@@ -154,13 +154,15 @@ int sdxl_op_layernorm_fwd(const void* x, void* y, const void* gamma, const void*
 int sdxl_op_layernorm_bwd(const void* x, const void* dy, const void* gamma, const float* stats, void* dx,
                           float* dgamma, float* dbeta, int M, int C, int accumulate, void* stream);
 /* GEGLU feed-forward pair, fused into the two projections' GEMM epilogues.  w1 [2*C4][K] / b1 [2*C4] and the
- * pre-activation u [M][2*C4] use the library's packed order: channel c's value half at row/column
- * (c/64)*128 + c%64, its gate half 64 further (sdxl_load_weight applies this to "ff.net.0.proj").
+ * pre-activation u [M][2*C4] use the library's packed order with group G = 64 or 80 (C4 % G == 0): channel c's value
+ * half at row/column (c/G)*2G + c%G, its gate half G further.  sdxl_load_weight applies this to "ff.net.0.proj" with
+ * G = 80 where 4*C divides (SDXL-base: 5120, 2560), else 64; callers only ever see the diffusers layout.
  * fwd: u = x @ w1^T + b1,  g[M][C4] = value * gelu(gate).
  * bwd: du[M][2*C4] from dy[M][C] @ w2[C][C4] (the second projection's input gradient) and u. */
 int sdxl_op_ff_geglu_fwd(const void* x, const void* w1, const void* b1, void* u, void* g, int M, int K, int C4,
+                         int group, void* stream);
+int sdxl_op_ff_geglu_bwd(const void* dy, const void* w2, const void* u, void* du, int M, int C, int C4, int group,
                          void* stream);
-int sdxl_op_ff_geglu_bwd(const void* dy, const void* w2, const void* u, void* du, int M, int C, int C4, void* stream);
 int sdxl_op_loss(const sdxl_loss_config* lc, const sdxl_batch* b, void* unet_in, const void* pred, void* dpred,
                  float grad_scale, float* out8_dev, int phase /*0 prepare,1 loss,2 dpred*/, void* stream);
 /* ---- row f1: fused AdamW_BF16 step (replaces AdamWBF16.step / _make_step,

@@ -538,7 +538,8 @@ int sdxl_op_layernorm_bwd(const void* x, const void* dy, const void* gamma, cons
   return launch_layernorm_bwd((const bf16*)x, (const bf16*)dy, (const bf16*)gamma, stats, (bf16*)dx,
                               accumulate ? (const bf16*)dx : nullptr, dgamma, dbeta, M, C, (hipStream_t)st);
 }
-int sdxl_op_ff_geglu_fwd(const void* x, const void* w1, const void* b1, void* u, void* g, int M, int K, int C4, void* st) {
+int sdxl_op_ff_geglu_fwd(const void* x, const void* w1, const void* b1, void* u, void* g, int M, int K, int C4, int group,
+                         void* st) {
   GemmP p;
   gemm_defaults(&p);
   p.form = GEMM_NT;
@@ -546,17 +547,18 @@ int sdxl_op_ff_geglu_fwd(const void* x, const void* w1, const void* b1, void* u,
   p.M = M; p.N = 2 * C4; p.K = K;
   p.lda = K; p.ldb = K; p.ldc = 2L * C4;
   p.bias = (const bf16*)b1;
-  p.geglu = 1; p.aux = (bf16*)g; p.ldaux = C4;
+  p.geglu = 1; p.geglu_group = group; p.aux = (bf16*)g; p.ldaux = C4;
   return launch_gemm(p, (hipStream_t)st);
 }
-int sdxl_op_ff_geglu_bwd(const void* dy, const void* w2, const void* u, void* du, int M, int C, int C4, void* st) {
+int sdxl_op_ff_geglu_bwd(const void* dy, const void* w2, const void* u, void* du, int M, int C, int C4, int group,
+                         void* st) {
   GemmP p;
   gemm_defaults(&p);
   p.form = GEMM_NN;
   p.A = (const bf16*)dy; p.B = (const bf16*)w2; p.C = du;
   p.M = M; p.N = C4; p.K = C;
   p.lda = C; p.ldb = C4; p.ldc = 2L * C4;
-  p.geglu = 2; p.aux = (bf16*)u; p.ldaux = 2L * C4;
+  p.geglu = 2; p.geglu_group = group; p.aux = (bf16*)u; p.ldaux = 2L * C4;
   return launch_gemm(p, (hipStream_t)st);
 }
 

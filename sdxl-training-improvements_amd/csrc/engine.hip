@@ -108,6 +108,7 @@ struct LinearOp : Op {
   Plan::GradDst dx, dres;
   // GEGLU feed-forward pair (GemmP::geglu): the first projection (y = u, interleaved value | gate columns) also
   // writes gact = value * gelu(gate); the second projection (x = gact) turns its input gradient straight into dU
+  int ggroup = 64;       // packing group of the GEGLU projection (64: 128-column tiles, 80: 160-column tiles)
   Act* gact = nullptr;   // first projection: fused activation output [rows][N/2]
   Act* gu = nullptr;     // second projection: the first projection's pre-activation u [rows][2K]
   LinearOp(Act* x_, Act* y_, PRef w_, PRef b_, int K_, int N_, Act* resid_) : x(x_), y(y_), resid(resid_), w(w_), b(b_), K(K_), N(N_) {}
@@ -120,7 +121,7 @@ struct LinearOp : Op {
     g.lda = K; g.ldb = K; g.ldc = N;
     g.bias = b.off == NONE ? nullptr : p.eng->Wp(b);
     if (resid) { g.resid = p.P(resid); g.ldr = N; }
-    if (gact) { g.geglu = 1; g.aux = p.P(gact); g.ldaux = N / 2; }
+    if (gact) { g.geglu = 1; g.geglu_group = ggroup; g.aux = p.P(gact); g.ldaux = N / 2; }
     return launch_gemm(g, st);
   }
   void plan_bwd(Plan& p) override {
@@ -161,7 +162,7 @@ struct LinearOp : Op {
       g.A = dy; g.B = p.eng->Wp(w); g.C = p.GP(dx.out);
       g.M = M; g.N = K; g.K = N;
       g.lda = N; g.ldb = K; g.ldc = K;
-      if (gu) { g.geglu = 2; g.aux = p.P(gu); g.ldaux = 2L * K; g.ldc = 2L * K; }
+      if (gu) { g.geglu = 2; g.geglu_group = ggroup; g.aux = p.P(gu); g.ldaux = 2L * K; g.ldc = 2L * K; }
       else if (dx.addend != NONE) { g.resid = p.GP(dx.addend); g.ldr = K; }
       CHK(launch_gemm(g, st));
     }
@@ -484,14 +485,14 @@ struct Builder {
     return op;
   }
   // ---- layers ----
-  // kind 2: GEGLU first projection, rows (and bias) packed value | gate interleaved in groups of 64 (repack_kernel)
+  // kind 2: GEGLU first projection, rows (and bias) packed value | gate interleaved in groups of `group` (repack_kernel)
   Act* linear(const std::string& name, Act* x, int K, int N, bool bias, Act* resid, bool conv1x1 = false, int kind = 0,
-              LinearOp** op_out = nullptr) {
+              LinearOp** op_out = nullptr, int group = 0) {
     PRef w = e.param((size_t)N * K);
     if (conv1x1) e.map_src(name + ".weight", {N, K, 1, 1}, w, 0, 0, 0);
-    else e.map_src(name + ".weight", {N, K}, w, kind, 0, 0);
+    else e.map_src(name + ".weight", {N, K}, w, kind, 0, group);
     PRef b;
-    if (bias) { b = e.param(N, true); e.map_src(name + ".bias", {N}, b, kind, 0, 0); }
+    if (bias) { b = e.param(N, true); e.map_src(name + ".bias", {N}, b, kind, 0, group); }
     if (!pl) return nullptr;
     Act* y = pl->new_act(x->rows, N);
     LinearOp* op = tagseg(pl->add<LinearOp>(x, y, w, b, K, N, resid), w);
@@ -582,12 +583,14 @@ struct Builder {
     Act* l3 = layernorm(b + ".norm3", x2, C);
     // feed-forward: GEGLU lives in the epilogues of the two projections (forward: value * gelu(gate) next to u;
     // backward: the second projection's dgrad writes dU directly), no separate activation pass
+    // packing group 80 (160-column tiles: fewer operand bytes per flop, fuller rounds) where 4C divides, else 64
+    const int group = (4 * C) % 80 == 0 ? 80 : 64;
     LinearOp *ff1 = nullptr, *ff2 = nullptr;
-    Act* u = linear(b + ".ff.net.0.proj", l3, C, 8 * C, true, nullptr, false, 2, &ff1);
+    Act* u = linear(b + ".ff.net.0.proj", l3, C, 8 * C, true, nullptr, false, 2, &ff1, group);
     Act* g = pl ? pl->new_act(x->rows, 4 * C) : nullptr;
-    if (ff1) ff1->gact = g;
+    if (ff1) { ff1->gact = g; ff1->ggroup = group; }
     Act* y = linear(b + ".ff.net.2", g, 4 * C, C, true, x2, false, 0, &ff2);
-    if (ff2) ff2->gu = u;
+    if (ff2) { ff2->gu = u; ff2->ggroup = group; }
     return y;
   }
   Act* transformer(const std::string& p, Act* x, Act* ehs, int h, int w_, int C, int depth) {
@@ -724,8 +727,8 @@ template <typename TS, typename TD>
 __global__ void repack_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long n, int kind, int co, int ci,
                               int ci_pad, int to_native) {
   // kind 0: flat copy.  kind 1: src [co][ci][3][3] <-> native [co][9][ci_pad]
-  // kind 2: GEGLU projection, src rows [value 0..C4) | gate 0..C4)] <-> native rows interleaved in groups of 64:
-  //         channel c -> value row (c/64)*128 + c%64, gate row +64   (co = 2*C4 rows of ci elements; bias: ci = 1)
+  // kind 2: GEGLU projection, src rows [value 0..C4) | gate 0..C4)] <-> native rows interleaved in groups of G = ci_pad
+  //         (64 or 80): channel c -> value row (c/G)*2G + c%G, gate row +G   (co = 2*C4 rows of ci elements; bias: ci = 1)
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     long s = i, d = i;
     if (kind == 1) {
@@ -736,8 +739,8 @@ __global__ void repack_kernel(const TS* __restrict__ src, TD* __restrict__ dst, 
       if (to_native) { s = i; d = nat; } else { s = nat; d = i; }
     } else if (kind == 2) {
       const long r = i / ci, k = i - r * ci;
-      const int c4 = co / 2, half = (int)(r / c4), c = (int)(r - (long)half * c4);
-      const long nat = ((long)(c >> 6) * 128 + half * 64 + (c & 63)) * ci + k;
+      const int c4 = co / 2, half = (int)(r / c4), c = (int)(r - (long)half * c4), G = ci_pad;
+      const long nat = ((long)(c / G) * (2 * G) + half * G + (c % G)) * ci + k;
       if (to_native) { s = i; d = nat; } else { s = nat; d = i; }
     }
     dst[d] = (TD)(float)src[s];

@@ -750,18 +750,19 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW, BMT)) void g
           *(f32x4*)(Cs + (wrow - half * 64 + i * 16 + l16) * LDC + wn * (BN / 2) + j * 16 + g * 4) = acc[i][j];
     }
     __syncthreads();
-    if (FORM != GEMM_TN && BN == 128) {
+    if (FORM != GEMM_TN && (BN == 128 || BN == 160)) {
       // GEGLU fused epilogues (see GemmP): both operate on the bf16-rounded values, exactly like a separate pass would
+      constexpr int G = BN / 2;   // channels per packing group = half a tile
       for (int id = tid; id < 64 * VPR; id += NT) {
         const int row = id / VPR, col = (id - row * VPR) * 8;
         const int m = m0 + half * 64 + row;
         if (m >= p.M) continue;
         if (FORM == GEMM_NT) {          // forward: this tile = value | gate halves of 64 channels
-          if (col >= 64 || n0 + col >= p.N) continue;
-          const int na = n0 + col, nt = na + 64;
+          if (col >= G || n0 + col >= p.N) continue;
+          const int na = n0 + col, nt = na + G;
           float xa[8], xt[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { xa[e] = Cs[row * LDC + col + e]; xt[e] = Cs[row * LDC + 64 + col + e]; }
+          for (int e = 0; e < 8; ++e) { xa[e] = Cs[row * LDC + col + e]; xt[e] = Cs[row * LDC + G + col + e]; }
           if (p.bias) {
             bf16x8 ba = *(const bf16x8*)(p.bias + na), bt = *(const bf16x8*)(p.bias + nt);
 #pragma unroll
@@ -780,9 +781,9 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW, BMT)) void g
         } else {                        // dgrad of the second projection: dG tile -> dU (value and gate halves)
           const int n = n0 + col;
           if (n >= p.N) continue;
-          const long cu = (long)(n >> 6) * 128 + (n & 63);
+          const long cu = (long)(n / G) * (2 * G) + (n % G);
           bf16x8 ua = *(const bf16x8*)(p.aux + (long)m * p.ldaux + cu);
-          bf16x8 ut = *(const bf16x8*)(p.aux + (long)m * p.ldaux + cu + 64);
+          bf16x8 ut = *(const bf16x8*)(p.aux + (long)m * p.ldaux + cu + G);
           bf16x8 oa, ot;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -793,7 +794,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW, BMT)) void g
             ot[e] = (bf16)(dv * (float)ua[e] * fmaf(tv, pdf, cdf));
           }
           *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + cu) = oa;
-          *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + cu + 64) = ot;
+          *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + cu + G) = ot;
         }
       }
     }
@@ -903,7 +904,8 @@ static int launch_one(const GemmP& p, hipStream_t st) {
   // 128x128 (1.25 rounds, 62 % of the slots used) but exactly 512 tiles of 128x160.
   const long zmul = FORM == GEMM_TN ? p.taps * p.splitk : 1;
   const long blocks = (long)cdiv(p.M, BM) * cdiv(p.N, 128) * zmul;
-  const bool n160 = p.N % 160 == 0 && !p.geglu;
+  const bool g80 = p.geglu && p.geglu_group == 80;        // packed for 160-column tiles: must run in a BN = 160 configuration
+  const bool n160 = p.N % 160 == 0 && (!p.geglu || g80);
   const long t160 = n160 ? (long)cdiv(p.M, BM) * (p.N / 160) * zmul : 0;
   auto fill = [](long t) { const long cap = 512; return (double)t / (double)(((t + cap - 1) / cap) * cap); };
   static int sel = -1;
@@ -927,7 +929,8 @@ static int launch_one(const GemmP& p, hipStream_t st) {
     if (pp_min > 0 && FORM == GEMM_NT && cfg == 1 && (!p.geglu || pp_geglu) && (long)cdiv(p.M, 256) * cdiv(p.N, 128) >= pp_min) cfg = 10;
   }
   if (g_force_cfg) cfg = g_force_cfg;
-  if (p.geglu && (cfg == 3 || cfg == 6 || cfg == 13)) cfg = 1;   // the fused GEGLU epilogues need 128-column tiles
+  if (p.geglu && !g80 && (cfg == 3 || cfg == 6 || cfg == 13)) cfg = 1;   // group-64 packing needs 128-column tiles
+  if (g80 && cfg != 3 && cfg != 13) cfg = 13;                            // group-80 packing needs 160-column tiles
   if (cfg == 3 && p.N % 160 != 0) cfg = 4;
   if (cfg == 13 && p.N % 160 != 0) cfg = 1;
   switch (cfg) {
@@ -1021,8 +1024,11 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
     ARG_CHECK(p.ldc % 8 == 0, "gemm: ldc=%ld must be a multiple of 8", p.ldc);
     if (p.accumulate) { p.resid = (const bf16*)p.C; p.ldr = p.ldc; }
     if (p.geglu) {
-      ARG_CHECK((p.geglu == 1 && p.form == GEMM_NT && p.N % 128 == 0) || (p.geglu == 2 && p.form == GEMM_NN && p.N % 64 == 0),
-                "gemm: geglu mode %d does not fit form %d / N=%d", p.geglu, p.form, p.N);
+      if (p.geglu_group == 0) p.geglu_group = 64;
+      ARG_CHECK(p.geglu_group == 64 || p.geglu_group == 80, "gemm: geglu group %d (64 or 80)", p.geglu_group);
+      const int G = p.geglu_group;
+      ARG_CHECK((p.geglu == 1 && p.form == GEMM_NT && p.N % (2 * G) == 0) || (p.geglu == 2 && p.form == GEMM_NN && p.N % G == 0),
+                "gemm: geglu mode %d does not fit form %d / N=%d / group %d", p.geglu, p.form, p.N, G);
       ARG_CHECK(p.aux && p.ldaux % 8 == 0 && ((uintptr_t)p.aux & 15) == 0 && p.taps == 1, "gemm: geglu needs an aligned aux matrix");
       ARG_CHECK(!p.resid && !p.rowvec && (p.geglu == 1 || !p.bias), "gemm: geglu epilogue takes no residual / row vector");
     }

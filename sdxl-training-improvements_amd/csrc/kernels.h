@@ -35,13 +35,14 @@ struct GemmP {
   const bf16* rowvec;
   long ldv;
   int rows_per_batch;
-  // GEGLU fused into the feed-forward GEMMs (bf16 output forms, 128-column tiles).  The 2*C4 columns of the first
-  // projection are stored interleaved in groups of 64: column (c/64)*128 + c%64 is the value half of channel c,
-  // +64 its gate half (the weight rows are packed in the same order), so one tile holds both halves of 64 channels.
+  // GEGLU fused into the feed-forward GEMMs (bf16 output forms, tile width = 2 * group).  The 2*C4 columns of the first
+  // projection are stored interleaved in groups of G = 64 or 80: column (c/G)*2G + c%G is the value half of channel c,
+  // +G its gate half (the weight rows are packed in the same order), so one tile holds both halves of 64 channels.
   //   geglu == 1 (NT, N = 2*C4):  C = u (pre-activation, kept for the backward), aux[m][c] = value * gelu(gate)
   //   geglu == 2 (NN, N = C4):    acc = dG;  C[m][2*C4] = dU from aux = u:  d value = dG * gelu(gate),
   //                                                                        d gate  = dG * value * gelu'(gate)
   int geglu;
+  int geglu_group;   // 64 (128-column tiles) or 80 (160-column tiles); 0 = 64
   bf16* aux;
   long ldaux;
   // fp32 output (wgrad): C_f32 (+)= acc.  splitk > 1: each split writes its partial [M][N*taps] tile set to

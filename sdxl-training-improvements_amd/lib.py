@@ -85,8 +85,8 @@ SIGNATURES = {
     "sdxl_adamw_default_config": [C.POINTER(AdamWConfig)],
     "sdxl_adamw_bf16_step": [_vp, _vp, _i, _vp, _vp, _vp, _sz, C.POINTER(AdamWConfig), _vp, _vp, _vp],
     "sdxl_adamw_decay": [_vp, _vp, _sz, _f, _vp],
-    "sdxl_op_ff_geglu_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "sdxl_op_ff_geglu_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "sdxl_op_ff_geglu_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sdxl_op_ff_geglu_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sdxl_op_loss": [_P(LossConfig), _P(Batch), _vp, _vp, _vp, _f, _vp, _i, _vp],
     "sdxl_probe_layout": [_vp, _vp],
     "sdxl_profile_gemm_begin": [],

@@ -276,22 +276,23 @@ def test_layernorm_fwd_bwd(L, M, Cc):
     report("layernorm dbeta", db, br.grad, 2e-3)
 
 
-def geglu_pack_rows(t, C4):
-    """[2*C4, ...] source order (value rows | gate rows) -> the library's packed order (groups of 64 interleaved)."""
+def geglu_pack_rows(t, C4, G=64):
+    """[2*C4, ...] source order (value rows | gate rows) -> the library's packed order (groups of G interleaved)."""
     a, g = t[:C4], t[C4:]
     shp = t.shape[1:]
-    return torch.stack([a.reshape(C4 // 64, 64, *shp), g.reshape(C4 // 64, 64, *shp)], 1).reshape(2 * C4, *shp).contiguous()
+    return torch.stack([a.reshape(C4 // G, G, *shp), g.reshape(C4 // G, G, *shp)], 1).reshape(2 * C4, *shp).contiguous()
 
 
-def geglu_unpack_cols(u, C4):
+def geglu_unpack_cols(u, C4, G=64):
     """[M, 2*C4] packed columns -> source order (value | gate)."""
     M = u.shape[0]
-    v = u.reshape(M, C4 // 64, 2, 64)
+    v = u.reshape(M, C4 // G, 2, G)
     return torch.cat([v[:, :, 0].reshape(M, C4), v[:, :, 1].reshape(M, C4)], 1)
 
 
-@pytest.mark.parametrize("M,K,C4", [(64, 128, 256), (308, 320, 1280), (4096, 1280, 5120)])
-def test_ff_geglu_fused_fwd_bwd(L, M, K, C4):
+@pytest.mark.parametrize("M,K,C4,G", [(64, 128, 256, 64), (308, 320, 1280, 64), (308, 320, 1280, 80), (100, 128, 160, 80),
+                                      (4096, 1280, 5120, 80)])
+def test_ff_geglu_fused_fwd_bwd(L, M, K, C4, G):
     """GEGLU fused into the two feed-forward projections (reference: diffusers GEGLU, ff.net.0.proj -> ff.net.2)."""
     x = rnd(M, K, seed=60)
     w1, b1 = rnd(2 * C4, K, seed=61, scale=K ** -0.5), rnd(2 * C4, seed=62, scale=0.1)
@@ -299,19 +300,19 @@ def test_ff_geglu_fused_fwd_bwd(L, M, K, C4):
     dy = rnd(M, K, seed=64)
     u = torch.empty(M, 2 * C4, dtype=torch.bfloat16, device=dev())
     g = torch.empty(M, C4, dtype=torch.bfloat16, device=dev())
-    w1p, b1p = geglu_pack_rows(w1, C4), geglu_pack_rows(b1, C4)     # keep alive until the launch has been enqueued
-    lib.check(L.sdxl_op_ff_geglu_fwd(ptr(x), ptr(w1p), ptr(b1p), ptr(u), ptr(g), M, K, C4, stream()))
+    w1p, b1p = geglu_pack_rows(w1, C4, G), geglu_pack_rows(b1, C4, G)     # keep alive until the launch has been enqueued
+    lib.check(L.sdxl_op_ff_geglu_fwd(ptr(x), ptr(w1p), ptr(b1p), ptr(u), ptr(g), M, K, C4, G, stream()))
     ur = (x.float() @ w1.float().t() + b1.float())
-    report("ff geglu: u", geglu_unpack_cols(u, C4), ur, 6e-3)
-    ub = geglu_unpack_cols(u, C4).float().requires_grad_(True)      # backward reference from the stored bf16 u
+    report("ff geglu: u", geglu_unpack_cols(u, C4, G), ur, 6e-3)
+    ub = geglu_unpack_cols(u, C4, G).float().requires_grad_(True)      # backward reference from the stored bf16 u
     a, t = ub.chunk(2, -1)
     gr = a * torch.nn.functional.gelu(t)
     report("ff geglu: g", g, gr.detach(), 6e-3)
     dg = dy.float() @ w2.float()
     gr.backward(dg)
     du = torch.empty_like(u)
-    lib.check(L.sdxl_op_ff_geglu_bwd(ptr(dy), ptr(w2), ptr(u), ptr(du), M, K, C4, stream()))
-    report("ff geglu: du", geglu_unpack_cols(du, C4), ub.grad, 1e-2)
+    lib.check(L.sdxl_op_ff_geglu_bwd(ptr(dy), ptr(w2), ptr(u), ptr(du), M, K, C4, G, stream()))
+    report("ff geglu: du", geglu_unpack_cols(du, C4, G), ub.grad, 1e-2)
 
 
 @pytest.mark.parametrize("method", [0, 1])
