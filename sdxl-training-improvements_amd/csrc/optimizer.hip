@@ -48,11 +48,11 @@ __global__ __launch_bounds__(256) void adamw_bf16_kernel(const AdamWP q) {
   const float gscale = q.grad_scale ? *q.grad_scale : 1.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
     const size_t e0 = i * 8;
-    bf16x8 pv = *(const bf16x8*)(q.p + e0), mv = *(const bf16x8*)(q.m + e0), vv = *(const bf16x8*)(q.v + e0),
-           sv = *(const bf16x8*)(q.shift + e0);
+    bf16x8 pv = __builtin_nontemporal_load((const bf16x8*)(q.p + e0)), mv = __builtin_nontemporal_load((const bf16x8*)(q.m + e0)),
+           vv = __builtin_nontemporal_load((const bf16x8*)(q.v + e0)), sv = __builtin_nontemporal_load((const bf16x8*)(q.shift + e0));
     float g[8];
     if (q.grad_f32) {
-      const f32x4 a = *(const f32x4*)(q.grad_f32 + e0), b = *(const f32x4*)(q.grad_f32 + e0 + 4);
+      const f32x4 a = __builtin_nontemporal_load((const f32x4*)(q.grad_f32 + e0)), b = __builtin_nontemporal_load((const f32x4*)(q.grad_f32 + e0 + 4));
       g[0] = a[0]; g[1] = a[1]; g[2] = a[2]; g[3] = a[3]; g[4] = b[0]; g[5] = b[1]; g[6] = b[2]; g[7] = b[3];
     } else {
       const bf16x8 gv = *(const bf16x8*)(q.grad_bf16 + e0);
@@ -102,10 +102,10 @@ __global__ __launch_bounds__(256) void adamw_bf16_kernel(const AdamWP q) {
       if (q.decay_alpha_bf16 != 0.f) s2b = rn(__builtin_fmaf(bf(p1b), q.decay_alpha_bf16, bf(s2b)));
       pv[e] = p1b; mv[e] = m2b; vv[e] = v2b; sv[e] = s2b;
     }
-    *(bf16x8*)(q.p + e0) = pv;
-    *(bf16x8*)(q.m + e0) = mv;
-    *(bf16x8*)(q.v + e0) = vv;
-    *(bf16x8*)(q.shift + e0) = sv;
+    __builtin_nontemporal_store(pv, (bf16x8*)(q.p + e0));      // streamed once per update: keep them out of the caches
+    __builtin_nontemporal_store(mv, (bf16x8*)(q.m + e0));
+    __builtin_nontemporal_store(vv, (bf16x8*)(q.v + e0));
+    __builtin_nontemporal_store(sv, (bf16x8*)(q.shift + e0));
   }
 }
 
