@@ -124,7 +124,12 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
-    D.init_process_group("nccl" if world > 1 else None)
+    # test hook (single-GPU boxes): SDXL_BENCH_BACKEND=gloo + SDXL_BENCH_ONE_DEVICE=1 run all ranks on cuda:0 to exercise the
+    # N > 1 control flow (barriers, per-segment exchange, MAX over ranks) without RCCL; never used for reported numbers
+    backend = os.environ.get("SDXL_BENCH_BACKEND", "nccl")
+    if os.environ.get("SDXL_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    D.init_process_group(backend if world > 1 else None)
     wl = WORKLOADS[args.workload]
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)

@@ -1,0 +1,28 @@
+"""bench.py's N > 1 control flow (one process per rank, per-segment cast + all-reduce overlapped with the backward,
+barrier + MAX-over-ranks timing, rank-0 JSON line) exercised with two ranks on ONE GPU over gloo (bench.py's test hook):
+everything but the RCCL transport itself.  The real multi-GPU runs are the driver's."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_two_ranks_one_device_gloo():
+    env = dict(os.environ, SDXL_BENCH_BACKEND="gloo", SDXL_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-optimizer",
+           "--profile-steps", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints exactly one JSON line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
+    assert out["scaling"] == "weak" and out["value"] > 0 and out["steps"] == 1
+    assert 0 < out["loss"] < 1000
