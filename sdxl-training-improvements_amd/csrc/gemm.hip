@@ -917,6 +917,10 @@ static int launch_one(const GemmP& p, hipStream_t st) {
   // 128x160 tiles, 4 waves x (64x80), 2-deep, 73 KiB (2 per CU): where they fill the rounds at least as well as 128x128
   // they also move 10 % fewer operand bytes per flop (measured +5..45 %: 16384x640x2560 641 -> 931 TFLOP/s)
   if (sel && n160 && t160 > 256 && fill(t160) * 1.05 >= fill(blocks)) cfg = 13;
+  // wgrad (side stream): always the wider tile where the output allows it -- 20 % fewer workgroups competing with the
+  // dgrad chain for CU slots is worth more at step level (-0.7 ms) than the tile's own speed (slower in isolation on
+  // some shapes: 10240x1280x4096 690 vs 762 TFLOP/s)
+  if (sel && n160 && FORM == GEMM_TN) cfg = 13;
   // forward problems that fit one round of one 128x160 workgroup per CU (N = 1280 outputs at M = 4096, the 1280-channel
   // convs): the 8-wave, 4-deep-ring configuration keeps 3 K-steps of DMA in flight and wins +15..30 % there.  Not for
   // dgrad / wgrad: a one-per-CU workgroup on one stream starves the other stream's kernels of LDS (168 vs 152 ms/step).
