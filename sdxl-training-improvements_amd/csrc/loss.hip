@@ -16,11 +16,12 @@
 __device__ __forceinline__ void loss_target(const LossP& p, int b, float x, float n, float sg, float* target,
                                             float* w) {
   if (p.method == 0) {
-    *target = p.prediction_type == 1 ? (n - x) / sqrtf(sg * sg) : n;
-    float snr = (1.f / sg) * (1.f / sg);
+    *target = p.prediction_type == 1 ? __fdiv_rn(__fsub_rn(n, x), __fsqrt_rn(__fmul_rn(sg, sg))) : n;
+    const float inv = __fdiv_rn(1.f, sg);
+    float snr = __fmul_rn(inv, inv);
     *w = p.use_min_snr ? fminf(snr, p.min_snr_gamma) : 1.f;
   } else {
-    *target = x - n;  // x1 - x0
+    *target = __fsub_rn(x, n);  // x1 - x0
     *w = 1.f;
   }
 }
@@ -36,11 +37,13 @@ __global__ void loss_prepare_kernel(const LossP p) {
     long idx = ((long)b * 4 + c) * p.HW + hw;
     float x = p.latents[idx], n = p.noise[idx];
     float v;
+    // every product and sum rounded on its own (no FMA contraction), exactly as the reference's separate torch ops do:
+    // the bf16 UNet input is then the round-to-nearest-even image of the reference's fp32 tensor, bit for bit
     if (p.method == 0) {
-      v = x + sg * n;
+      v = __fadd_rn(x, __fmul_rn(sg, n));
       if (p.use_ztsnr) v = fminf(fmaxf(v, -20000.f), 20000.f);
     } else {
-      v = (1.f - sg) * n + sg * x;
+      v = __fadd_rn(__fmul_rn(__fsub_rn(1.f, sg), n), __fmul_rn(sg, x));
     }
     o[c] = (bf16)v;
     o[c + 4] = (bf16)0.f;

@@ -7,6 +7,7 @@ oracle on the tiny UNet (tests/test_gpu_model.py) and checked here through size-
 (reproducibility, accumulation linearity, finite / non-trivial norms) at the BASELINE configs[1] shape (B=4, 1024^2).
 """
 import math
+import os
 
 import pytest
 import torch
@@ -92,6 +93,59 @@ def test_cfg1_gradients_match_cpu_oracle(full):
     assert worst >= 0.998
 
 
+HEADLINE_PROBES = ["down_blocks.0.resnets.0.conv1.weight",                                  # the 320 -> 320 conv at 128x128
+                   "down_blocks.1.attentions.0.transformer_blocks.0.attn1.to_q.weight",    # level-1 self attention, N = 4096
+                   "down_blocks.1.attentions.1.transformer_blocks.1.attn1.to_v.weight",
+                   "up_blocks.1.attentions.2.transformer_blocks.1.attn1.to_k.weight",      # level-1, up path
+                   "down_blocks.2.attentions.0.transformer_blocks.3.attn2.to_k.weight",    # cross attention
+                   "mid_block.attentions.0.transformer_blocks.9.ff.net.0.proj.weight",     # packed GEGLU projection
+                   "up_blocks.2.resnets.0.conv1.weight",                                   # 960 -> 320 at 128x128
+                   "up_blocks.0.upsamplers.0.conv.weight", "down_blocks.0.downsamplers.0.conv.weight",
+                   "conv_in.weight", "conv_out.weight", "up_blocks.2.resnets.2.norm2.weight"]
+
+
+@pytest.mark.parametrize("method", ["ddpm", "flow_matching"])
+def test_headline_shape_b1_loss_and_gradients_match_cpu_oracle(full, method):
+    """The HEADLINE shapes (latent 128x128 = 1024^2: level-1 self attention with Nq = Nk = 4096, the 128x128 convs)
+    against the fp32 CPU oracle: one sample of configs[1] / configs[2] (B = 4 is the 1/B-weighted sum of such samples,
+    test_flow_matching_batch_decomposes / test_ddpm_batch_decomposes below), loss <= 1e-3 relative (north_star) and 12
+    gradient probes.  ~20 TFLOP of host CPU work per method (fp32 autograd through the oracle)."""
+    net = full
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    x = _inputs(1, 128, 128, seed=515 if method == "ddpm" else 616)
+    w = U.synth_weights(U.SDXL_BASE, seed=0)
+    for k in HEADLINE_PROBES:
+        w[k].requires_grad_(True)
+    unet_fn = lambda s, t, e, p, ti: U.unet_forward(w, s, t, e, p, ti, U.SDXL_BASE)
+    batch = {"vae_latents": x["lat"], "prompt_embeds": x["ehs"], "pooled_prompt_embeds": x["pooled"], "time_ids": x["tid"]}
+    net.zero_grads()
+    if method == "ddpm":
+        ts = torch.tensor([613])
+        sig = R.karras_sigmas()[ts]
+        net.forward_loss("ddpm", x["lat"], x["noise"], sig, ts.float(), x["ehs"], x["pooled"], x["tid"])
+        ref = R.compute_loss_ddpm(unet_fn, batch, x["noise"], ts)
+    else:
+        t = torch.tensor([0.3671875])                      # exactly representable in bf16 (D6: t reaches the UNet in model dtype)
+        net.forward_loss("flow_matching", x["lat"], x["noise"], t, t, x["ehs"], x["pooled"], x["tid"])
+        ref = R.compute_loss_flow(unet_fn, batch, x["noise"], t)
+    net.backward(1.0, True)
+    got = net.read_loss()[0]
+    rel = abs(got - float(ref["loss"])) / abs(float(ref["loss"]))
+    print(f"[parity] FULL SDXL 1024^2 B=1 {method} loss: hip {got:.6e} oracle {float(ref['loss']):.6e} rel {rel:.3e}")
+    assert rel <= 1e-3
+    grads = torch.autograd.grad(ref["loss"], [w[k] for k in HEADLINE_PROBES])
+    worst = 1.0
+    for k, gr in zip(HEADLINE_PROBES, grads):
+        gh = net.export(k, grad=True).float().cpu().reshape(gr.shape)
+        a, b = gh.double().flatten(), gr.double().flatten()
+        cos = float((a @ b) / (a.norm() * b.norm()))
+        rl2 = float((gh - gr).norm() / gr.norm())
+        print(f"[parity] FULL SDXL 1024^2 {method} grad {k}: cos {cos:.6f} rel-L2 {rl2:.3e} |g| {float(gr.norm()):.3e}")
+        worst = min(worst, cos)
+        assert rl2 <= 6e-2, (k, rl2)
+    assert worst >= 0.998
+
+
 def test_configs1_shape_step_properties(full):
     """BASELINE configs[1] (B=4, 1024^2): reproducible loss, finite gradients, accumulation = sum of micro-steps."""
     net = full
@@ -124,7 +178,38 @@ def test_configs1_shape_step_properties(full):
     assert rel_g <= 5e-3
 
 
-@pytest.mark.parametrize("shape", [(4, 128, 128), (2, 96, 168)], ids=["configs2_1024sq", "configs4_bucket_1344x768"])
+def test_ddpm_batch_decomposes(full):
+    """configs[1] (ddpm v-pred + MinSNR, B=4, 1024^2): per-sample weights (D3) -- the batch loss is the mean of the
+    per-sample losses and the gradient the 1/B-weighted sum, which ties the B=4 step to the B=1 oracle comparison."""
+    net = full
+    B, H, W = 4, 128, 128
+    x = _inputs(B, H, W, seed=808)
+    ts = torch.tensor([12, 450, 700, 930])
+    sig = R.karras_sigmas()[ts]
+    probe = "down_blocks.1.attentions.0.transformer_blocks.0.attn1.to_q.weight"
+
+    def run(idx, scale, first):
+        s = slice(idx, idx + 1) if idx is not None else slice(None)
+        net.forward_loss("ddpm", x["lat"][s], x["noise"][s], sig[s], ts[s].float(), x["ehs"][s], x["pooled"][s], x["tid"][s])
+        net.backward(scale, first)
+        return net.read_loss()[0]
+
+    net.zero_grads()
+    lb = run(None, 1.0, True)
+    gb = net.export(probe, grad=True).clone()
+    nb = net.grad_norm()
+    net.zero_grads()
+    ls = [run(i, 1.0 / B, i == 0) for i in range(B)]
+    gs = net.export(probe, grad=True)
+    ns = net.grad_norm()
+    mean = sum(ls) / B
+    rel_g = float((gs - gb).norm() / gb.norm())
+    print(f"[parity] ddpm {B}x{H}x{W}: batch loss {lb:.6f} mean of per-sample {mean:.6f}; |grad| {nb:.4e} vs {ns:.4e}; probe rel {rel_g:.3e}")
+    assert abs(lb - mean) <= 1e-3 * abs(lb)
+    assert abs(nb - ns) <= 5e-3 * nb and rel_g <= 1e-2
+
+
+@pytest.mark.parametrize("shape", [(4, 128, 128), (4, 96, 168)], ids=["configs2_1024sq", "configs4_bucket_1344x768_b4"])
 def test_flow_matching_batch_decomposes(full, shape):
     """BASELINE configs[2] (flow matching, B=4, 1024^2) and the second bucket of configs[4] (1344x768 -> latent 96x168):
     size-independent property -- the batch loss is the mean of the per-sample losses (every sample has its own t and

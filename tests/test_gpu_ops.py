@@ -164,7 +164,13 @@ def _attn_ref(q, k, v, heads):
 
 @pytest.mark.parametrize("B,heads,Nq,Nk,self_attn", [(1, 1, 128, 64, False), (2, 2, 256, 256, True),
                                                      (2, 2, 200, 77, False), (1, 4, 1008, 1008, True),
-                                                     (2, 10, 1024, 77, False)])
+                                                     (2, 10, 1024, 77, False),
+                                                     # the headline shapes: level-1 self attention at 1024^2 (N = 4096, 10 heads),
+                                                     # level 1 / level 2 of the 1344x768 bucket (N = 4032 / 1008: ragged last key
+                                                     # tile), level-2 self attention (N = 1024, 20 heads), level-1 cross attention
+                                                     (1, 10, 4096, 4096, True), (1, 10, 4032, 4032, True),
+                                                     (1, 20, 1008, 1008, True), (1, 20, 1024, 1024, True),
+                                                     (1, 10, 4096, 77, False), (1, 10, 4032, 77, False)])
 def test_attention_fwd_bwd(L, B, heads, Nq, Nk, self_attn):
     Cc = heads * 64
     if self_attn:
