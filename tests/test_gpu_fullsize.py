@@ -29,6 +29,20 @@ def full():
     net.close()
 
 
+@pytest.fixture(scope="module")
+def oracle_w():
+    """fp32 CPU copy of the same synthetic weights for the oracle (10.3 GB, ~1.5 min of host hashing): built once."""
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    return U.synth_weights(U.SDXL_BASE, seed=0)                    # same bytes as synth.load_synthetic (tested on CPU)
+
+
+def _probe(w, keys):
+    for t in w.values():
+        t.requires_grad_(False)
+    for k in keys:
+        w[k].requires_grad_(True)
+
+
 def _inputs(B, H, W, seed):
     g = torch.Generator().manual_seed(seed)
     r = lambda *s: torch.randn(*s, generator=g)
@@ -37,14 +51,14 @@ def _inputs(B, H, W, seed):
                 tid=torch.tensor([[8.0 * W, 8.0 * H, 0, 0, 8.0 * W, 8.0 * H]] * B))
 
 
-def test_cfg1_loss_matches_cpu_oracle(full):
+def test_cfg1_loss_matches_cpu_oracle(full, oracle_w):
     net = full
     x = _inputs(1, 64, 64, seed=101)
     ts = torch.tensor([820])
     sig = R.karras_sigmas()[ts]
     net.forward_loss("ddpm", x["lat"], x["noise"], sig, ts.float(), x["ehs"], x["pooled"], x["tid"])
     got = net.read_loss()
-    w = U.synth_weights(U.SDXL_BASE, seed=0)                       # same bytes as synth.load_synthetic (tested on CPU)
+    w = oracle_w
     with torch.no_grad():
         ref = R.compute_loss_ddpm(lambda s, t, e, p, ti: U.unet_forward(w, s, t, e, p, ti, U.SDXL_BASE),
                                   {"vae_latents": x["lat"], "prompt_embeds": x["ehs"], "pooled_prompt_embeds": x["pooled"],
@@ -63,7 +77,7 @@ PROBES = ["conv_in.weight", "down_blocks.1.attentions.0.transformer_blocks.1.att
           "up_blocks.1.resnets.1.conv_shortcut.weight", "up_blocks.2.resnets.2.time_emb_proj.bias", "conv_out.weight"]
 
 
-def test_cfg1_gradients_match_cpu_oracle(full):
+def test_cfg1_gradients_match_cpu_oracle(full, oracle_w):
     """cfg 1 at full size, backward: gradients of probe parameters spread over the network (first and last layer,
     self / cross attention projections, the packed GEGLU projection, convs, a shortcut, norm and bias vectors) against
     autograd through the fp32 CPU oracle on identical inputs (~1 minute of host CPU)."""
@@ -74,9 +88,8 @@ def test_cfg1_gradients_match_cpu_oracle(full):
     net.zero_grads()
     net.forward_loss("ddpm", x["lat"], x["noise"], sig, ts.float(), x["ehs"], x["pooled"], x["tid"])
     net.backward(1.0, True)
-    w = U.synth_weights(U.SDXL_BASE, seed=0)
-    for k in PROBES:
-        w[k].requires_grad_(True)
+    w = oracle_w
+    _probe(w, PROBES)
     ref = R.compute_loss_ddpm(lambda s, t, e, p, ti: U.unet_forward(w, s, t, e, p, ti, U.SDXL_BASE),
                               {"vae_latents": x["lat"], "prompt_embeds": x["ehs"], "pooled_prompt_embeds": x["pooled"],
                                "time_ids": x["tid"]}, x["noise"], ts)
@@ -105,17 +118,15 @@ HEADLINE_PROBES = ["down_blocks.0.resnets.0.conv1.weight",                      
 
 
 @pytest.mark.parametrize("method", ["ddpm", "flow_matching"])
-def test_headline_shape_b1_loss_and_gradients_match_cpu_oracle(full, method):
+def test_headline_shape_b1_loss_and_gradients_match_cpu_oracle(full, oracle_w, method):
     """The HEADLINE shapes (latent 128x128 = 1024^2: level-1 self attention with Nq = Nk = 4096, the 128x128 convs)
     against the fp32 CPU oracle: one sample of configs[1] / configs[2] (B = 4 is the 1/B-weighted sum of such samples,
     test_flow_matching_batch_decomposes / test_ddpm_batch_decomposes below), loss <= 1e-3 relative (north_star) and 12
     gradient probes.  ~20 TFLOP of host CPU work per method (fp32 autograd through the oracle)."""
     net = full
-    torch.set_num_threads(min(32, os.cpu_count() or 8))
     x = _inputs(1, 128, 128, seed=515 if method == "ddpm" else 616)
-    w = U.synth_weights(U.SDXL_BASE, seed=0)
-    for k in HEADLINE_PROBES:
-        w[k].requires_grad_(True)
+    w = oracle_w
+    _probe(w, HEADLINE_PROBES)
     unet_fn = lambda s, t, e, p, ti: U.unet_forward(w, s, t, e, p, ti, U.SDXL_BASE)
     batch = {"vae_latents": x["lat"], "prompt_embeds": x["ehs"], "pooled_prompt_embeds": x["pooled"], "time_ids": x["tid"]}
     net.zero_grads()
