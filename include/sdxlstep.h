@@ -129,7 +129,8 @@ int sdxl_sumsq(const void* x_dev, int dtype, size_t n, float* out_dev, void* str
 int sdxl_clip_coef(const float* sumsq_dev, float max_norm, float* coef_dev, void* stream);
 
 /* ---- single-kernel entry points (parity tests call these; same kernels the plan launches) --------------------- */
-/* C[M,N] = A.B ; form 0: A[M,K],B[N,K] ; 1: A[M,K],B[K,N] ; 2: A[K,M],B[K,N] -> fp32 C (+= if accumulate) */
+/* C[M,N] = A.B ; form 0: A[M,K],B[N,K] ; 1: A[M,K],B[K,N] ; 2: A[K,M],B[K,N] -> fp32 C (+= if accumulate).
+ * form 2 (wgrad): `bias`, when given, is the fp32 bias-GRADIENT accumulator float[M]: += column sums of A. */
 int sdxl_op_gemm(int form, const void* A, const void* B, void* C, int M, int N, int K, const void* bias,
                  const void* resid, int accumulate, int splitk, void* stream);
 /* 3x3 conv, pad 1, token-major: x [B,H,W,Cin], w [Cout][9][Cin] ; y [B,Ho,Wo,Cout] */
@@ -196,6 +197,9 @@ int sdxl_probe_layout(void* out_dev, void* stream);
  * bracketed by HIP events on its launch stream; end synchronises and returns the summed algorithmic FLOPs
  * (2*M*N*K*taps), the summed event time and the number of launches. */
 int sdxl_profile_gemm_begin(void);
+/* tile-kernel selection of the GEMM family, for A/B measurements and parity tests: 0 = 128-row kernel only,
+ * 1 = 256 x 256 kernel where its grid fills the chip (default), 2 = 256 x 256 kernel wherever it is applicable. */
+int sdxl_set_gemm_mode(int mode);
 int sdxl_profile_gemm_end(double* flops, double* ms, int* launches);
 /* debug: checksum of every activation (grads != 0: of every activation gradient) of the current plan, in creation
  * order; synchronises the device.  n_out receives the number of activations. */

@@ -446,7 +446,8 @@ int sdxl_op_gemm(int form, const void* A, const void* B, void* C, int M, int N, 
     if (splitk > 1) CHK(test_slab(gemm_slab_floats(M, N, 1, splitk), &g.slab));
   }
   g.ldc = N;
-  g.bias = (const bf16*)bias;
+  if (form == GEMM_TN) g.bias_grad = (float*)bias;
+  else g.bias = (const bf16*)bias;
   if (resid) { g.resid = (const bf16*)resid; g.ldr = N; }
   g.accumulate = accumulate;
   return launch_gemm(g, (hipStream_t)st);
@@ -631,6 +632,11 @@ int sdxl_adamw_decay(void* shift, const void* p, size_t n, float decay, void* st
 
 int sdxl_probe_layout(void* out, void* st) { return probe_layout(out, (hipStream_t)st); }
 int sdxl_profile_gemm_begin(void) { return gemm_profile_begin(); }
+int sdxl_set_gemm_mode(int mode) {
+  ARG_CHECK(mode >= 0 && mode <= 2, "gemm mode %d (0, 1 or 2)", mode);
+  gemm_set_mode(mode);
+  return 0;
+}
 int sdxl_profile_gemm_end(double* flops, double* ms, int* launches) { return gemm_profile_end(flops, ms, launches); }
 
 // debug: order-independent checksum (sum of raw 16-bit patterns) of every activation of the current plan, in

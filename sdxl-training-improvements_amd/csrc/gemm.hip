@@ -13,7 +13,7 @@
 // MFMA operand slots: lane l holds slot (g = l>>4, j = 0..7) of row/col (l & 15).  The hardware pairs A slot (g,j)
 // with B slot (g,j); both operands map slot (g,j) to k = 8g + j of the 32-deep step, so the two read paths
 // (b128 / transpose) agree by construction.  C/D layout: col = l & 15, row = 4*(l>>4) + reg.
-#include "kernels.h"
+#include "gemm_tiles.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -24,94 +24,6 @@
 #ifndef GEMM_DIRECT_EPILOGUE
 #define GEMM_DIRECT_EPILOGUE 1
 #endif
-
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gbl_void;
-
-// 16 zero bytes in global memory: source of every out-of-range / padded 16-byte vector of the LDS-DMA loads
-__device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
-
-// ---- LDS images -----------------------------------------------------------------------------------------
-// Tiles are written by global_load_lds_dwordx4 (64 lanes x 16 B = one contiguous 1 KiB chunk per wave instruction,
-// no VGPR round trip, no ds_write).  The DMA destination is lane-linear, so the bank swizzle is applied on the
-// per-lane SOURCE address and again on the fragment read (same permutation on both sides).
-//  K-contiguous tile [R][BK]: BK = 64 -> 128-B rows, 8 vectors: slot = kv ^ (r & 7)
-//                             BK = 32 ->  64-B rows, 4 vectors: slot = kv ^ P[(r >> 2) & 3], P = {0,2,3,1}
-//     (conflict-free for the ds_read_b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31})
-//  N-contiguous tile [BK][W] (W = 128 or 160 columns, V = W/8 vectors per k-row):
-//     W = 128: vector v of k-row k sits at slot v ^ (F(k) << 1),  F(k) = (k & 3) | (((k >> 3) & 1) << 2)
-//     W = 160: 320-B rows already spread 4 consecutive k-rows over disjoint banks; rows k and k+8 would collide, so
-//              rows with bit 3 set are rotated by 2 vectors: slot = (v + 2*((k>>3)&1)) % 20
-//     (conflict-free for ds_read_b64_tr_b16)
-__device__ __forceinline__ int swzF(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
-template <int W>
-__device__ __forceinline__ int nc_phys(int k, int v) {
-  if (W == 128) return v ^ (swzF(k) << 1);
-  int q = v + 2 * ((k >> 3) & 1);
-  return q >= 20 ? q - 20 : q;
-}
-template <int W>
-__device__ __forceinline__ int nc_logical(int k, int pv) {
-  if (W == 128) return pv ^ (swzF(k) << 1);
-  int q = pv - 2 * ((k >> 3) & 1);
-  return q < 0 ? q + 20 : q;
-}
-template <int BKT>
-__device__ __forceinline__ int kc_swz(int r) {
-  if (BKT == 64) return r & 7;
-  return (0x78 >> (((r >> 2) & 3) * 2)) & 3;  // 0b01_11_10_00 -> {0,2,3,1}
-}
-template <int BKT>
-__device__ __forceinline__ bf16x8 frag_kc(const char* tile, int r, int kv) {
-  return *(const bf16x8*)(tile + r * (BKT * 2) + ((kv ^ kc_swz<BKT>(r)) << 4));
-}
-// 8 k-rows starting at kb (multiple of 8), 16 columns starting at col0 (multiple of 16): lane i of each 16-lane
-// group supplies the address of 4 contiguous bf16 of row (i>>2), columns 4*(i&3).., and receives column i.
-template <int W>
-__device__ __forceinline__ bf16x8 frag_nc(const char* tile, int kb, int col0, int l16) {
-  const int krow = kb + (l16 >> 2);
-  const int v = (col0 >> 3) + ((l16 >> 1) & 1);
-  const char* p0 = tile + krow * (W * 2) + (nc_phys<W>(krow, v) << 4) + (l16 & 1) * 8;
-  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * (W * 2)));  // rows +4: same swizzle
-  union { s16x4 s[2]; bf16x8 v; } u;
-  u.s[0] = lo;
-  u.s[1] = hi;
-  return u.v;
-}
-
-struct PixRow {  // decoded pixel of a gathered row
-  int b, y, x, ok;
-};
-__device__ __forceinline__ PixRow decode_pix(int m, int Mlimit, int Hm, int Wm) {
-  PixRow r;
-  r.ok = m < Mlimit;
-  int hw = Hm * Wm;
-  r.b = m / hw;
-  int rem = m - r.b * hw;
-  r.y = rem / Wm;
-  r.x = rem - r.y * Wm;
-  return r;
-}
-// source pixel index (in pixels) for tap (dy,dx) or -1
-__device__ __forceinline__ long gather_src(const PixRow& r, int dy, int dx, const GemmP& p) {
-  int ys = r.y * p.sm + dy - 1;
-  int xs = r.x * p.sm + dx - 1;
-  if (!r.ok || ys < 0 || xs < 0) return -1;
-  if (p.sd > 1) {
-    if ((ys % p.sd) | (xs % p.sd)) return -1;
-    ys /= p.sd;
-    xs /= p.sd;
-  }
-  if (ys >= p.Hs || xs >= p.Ws) return -1;
-  return ((long)r.b * p.Hs + ys) * p.Ws + xs;
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 static constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
 static constexpr int gemm_smem_bytes(int BN, int S, int BK, int BMT = BM) {
@@ -161,32 +73,8 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW, BMT)) void g
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int l16 = lane & 15, g = lane >> 4;
-  // XCD-aware tile order: hardware workgroup id i runs on XCD i % 8 (observed; used for speed only).  The 8 XCDs are
-  // laid out as a px x py grid over the (n, m) tile grid (chosen by the launcher to minimise the A-panel + B-panel
-  // footprint per XCD) so that each private 4 MiB L2 sees a compact rectangle of output tiles; inside a rectangle
-  // tiles go n-fastest in strips of 8 columns.  Falls back to the identity when the grid does not divide.
-  int bx = blockIdx.x, by = blockIdx.y;
-  if (p.xcd_px > 0 && gridDim.x % p.xcd_px == 0 && gridDim.y % (8 / p.xcd_px) == 0) {
-    const int gx = gridDim.x, gy = gridDim.y;
-    const int px = p.xcd_px, py = 8 / px;
-    const int tn = gx / px, tm = gy / py;
-    const int id = blockIdx.y * gx + blockIdx.x;
-    const int xcd = id & 7, li = id >> 3;
-    const int sw = tn < 8 ? tn : 8;
-    const int full = (tn / sw) * sw * tm;
-    int ln, lm;
-    if (li < full) {
-      const int strip = li / (sw * tm), w = li - strip * (sw * tm);
-      lm = w / sw;
-      ln = strip * sw + (w - lm * sw);
-    } else {
-      const int rw = tn - (tn / sw) * sw, w = li - full;
-      lm = w / rw;
-      ln = (tn / sw) * sw + (w - lm * rw);
-    }
-    bx = (xcd % px) * tn + ln;
-    by = (xcd / px) * tm + lm;
-  }
+  int bx, by;
+  xcd_tile_map(p.xcd_px, bx, by);   // XCD-aware tile order (gemm_tiles.h)
   const int n0 = bx * BN;
   const int m0 = by * BMT;
 #ifdef SDXL_GEMM_DIAG   // scratch diagnostics only (never defined in the product build): knock out one pipeline component
@@ -993,6 +881,8 @@ int gemm_profile_end(double* flops, double* ms, int* launches) {
   if (launches) *launches = (int)g_prof.flops.size();
   return 0;
 }
+static int g_mode256 = -1;
+void gemm_set_mode(int mode) { g_mode256 = mode; }
 static int launch_gemm_impl(const GemmP& pin, hipStream_t st);
 int launch_gemm(const GemmP& p, hipStream_t st) {
   if (!g_prof.on) return launch_gemm_impl(p, st);
@@ -1063,6 +953,25 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
   }
   const bool conv = p.taps == 9;
   int rc;
+  {   // 256 x 256 kernel (gemm256.hip)
+    if (g_mode256 < 0) { const char* e = getenv("SDXL_GEMM_G256"); g_mode256 = e ? atoi(e) : 1; }
+    const int g256 = g_mode256;
+    if (g256 && gemm256_applicable(p)) {
+      const long wgs = (long)(p.M / 256) * (p.N / 256) * p.splitk;
+      if (g256 == 2 || wgs >= 192) {
+        rc = launch_gemm256(p, st);
+        if (rc == 0 && p.splitk > 1) {
+          const long nv = (long)p.M * (p.N / 4);
+          int g = (int)((nv + 255) / 256);
+          if (g > 2048) g = 2048;
+          hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, st, p.slab, (float*)p.C, p.M, p.N, p.ldc, p.slab_ld,
+                             p.splitk, p.accumulate);
+          HIP_CHECK_RET(hipGetLastError());
+        }
+        return rc;
+      }
+    }
+  }
   switch (p.form) {
     case GEMM_NT: return conv ? launch_one<GEMM_NT, true>(p, st) : launch_one<GEMM_NT, false>(p, st);
     case GEMM_NN: return conv ? launch_one<GEMM_NN, true>(p, st) : launch_one<GEMM_NN, false>(p, st);

@@ -60,6 +60,10 @@ struct GemmP {
 size_t gemm_slab_floats(int M, int N, int taps, int splitk);
 void gemm_defaults(GemmP* p);
 int launch_gemm(const GemmP& p, hipStream_t st);
+// 256 x 256 tile, 8-phase kernel (gemm256.hip): M, N multiples of 256, K of 64, no 3x3 gather
+bool gemm256_applicable(const GemmP& p);
+void gemm_set_mode(int mode);   // 0: never, 1: where the 256 x 256 grid fills the chip, 2: wherever applicable
+int launch_gemm256(const GemmP& p, hipStream_t st);
 // per-launch HIP-event timing of every GEMM launch between begin and end (end synchronises the device)
 int gemm_profile_begin();
 bool gemm_profiling();   // true between begin and end: the engine then runs everything on one stream (clean durations)

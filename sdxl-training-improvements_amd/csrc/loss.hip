@@ -13,15 +13,28 @@
 // produces token-major [B*HW][8] bf16 (4 real channels + 4 zero pad so every row is one 16-byte vector).
 #include "kernels.h"
 
+// a * b + c and friends with every operation rounded on its own, as separate torch ops do (hipcc contracts a * b + c into
+// an FMA by default, and __fmul_rn / __fadd_rn are plain operators to it)
+__device__ __forceinline__ float mul_add_rn(float a, float b, float c) {
+#pragma clang fp contract(off)
+  const float t = a * b;
+  return t + c;
+}
+__device__ __forceinline__ float mul_mul_add_rn(float a, float b, float c, float d) {   // a * b + c * d
+#pragma clang fp contract(off)
+  const float t = a * b, u = c * d;
+  return t + u;
+}
+
 __device__ __forceinline__ void loss_target(const LossP& p, int b, float x, float n, float sg, float* target,
                                             float* w) {
   if (p.method == 0) {
-    *target = p.prediction_type == 1 ? __fdiv_rn(__fsub_rn(n, x), __fsqrt_rn(__fmul_rn(sg, sg))) : n;
-    const float inv = __fdiv_rn(1.f, sg);
-    float snr = __fmul_rn(inv, inv);
+    *target = p.prediction_type == 1 ? (n - x) / sqrtf(sg * sg) : n;
+    const float inv = 1.f / sg;
+    float snr = inv * inv;
     *w = p.use_min_snr ? fminf(snr, p.min_snr_gamma) : 1.f;
   } else {
-    *target = __fsub_rn(x, n);  // x1 - x0
+    *target = x - n;  // x1 - x0
     *w = 1.f;
   }
 }
@@ -40,10 +53,10 @@ __global__ void loss_prepare_kernel(const LossP p) {
     // every product and sum rounded on its own (no FMA contraction), exactly as the reference's separate torch ops do:
     // the bf16 UNet input is then the round-to-nearest-even image of the reference's fp32 tensor, bit for bit
     if (p.method == 0) {
-      v = __fadd_rn(x, __fmul_rn(sg, n));
+      v = mul_add_rn(sg, n, x);
       if (p.use_ztsnr) v = fminf(fmaxf(v, -20000.f), 20000.f);
     } else {
-      v = __fadd_rn(__fmul_rn(__fsub_rn(1.f, sg), n), __fmul_rn(sg, x));
+      v = mul_mul_add_rn(1.f - sg, n, sg, x);
     }
     o[c] = (bf16)v;
     o[c + 4] = (bf16)0.f;

@@ -90,6 +90,7 @@ SIGNATURES = {
     "sdxl_op_loss": [_P(LossConfig), _P(Batch), _vp, _vp, _vp, _f, _vp, _i, _vp],
     "sdxl_probe_layout": [_vp, _vp],
     "sdxl_profile_gemm_begin": [],
+    "sdxl_set_gemm_mode": [_i],
     "sdxl_profile_gemm_end": [_P(C.c_double), _P(C.c_double), _P(_i)],
     "sdxl_debug_act_checksums": [_vp, _P(C.c_ulonglong), _i, _P(_i), _i],
 }

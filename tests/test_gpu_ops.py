@@ -113,6 +113,56 @@ def test_gemm_tn_wgrad(L, M, N, K, splitk):
         report("gemm_tn overwrite", out, ref, 2e-5 * math.sqrt(K) + 1e-5)
 
 
+@pytest.fixture
+def g256(L):
+    """force the 256 x 256 / 8-phase kernel (gemm256.hip) wherever it is applicable, restore the default policy after"""
+    lib.check(L.sdxl_set_gemm_mode(2))
+    yield L
+    lib.check(L.sdxl_set_gemm_mode(1))
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 768, 192), (1024, 256, 1280), (4096, 3840, 1280)])
+def test_gemm256_nt_nn(g256, M, N, K):
+    """asymmetric data, every epilogue input: odd K-tile counts (1, 2, 3: the prologue / tail of the 8-phase pipeline)"""
+    L = g256
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    lib.check(L.sdxl_op_gemm(0, ptr(a), ptr(w), ptr(out), M, N, K, ptr(bias), ptr(res), 0, 1, stream()))
+    report(f"gemm256 nt {M}x{N}x{K}", out, a.float() @ w.float().t() + bias.float() + res.float(), 6e-3)
+    wn = rnd(K, N, seed=6, scale=K ** -0.5)
+    lib.check(L.sdxl_op_gemm(1, ptr(a), ptr(wn), ptr(out), M, N, K, None, None, 0, 1, stream()))
+    ref = a.float() @ wn.float()
+    report(f"gemm256 nn {M}x{N}x{K}", out, ref, 6e-3)
+    base = rnd(M, N, seed=7)
+    out2 = base.clone()
+    lib.check(L.sdxl_op_gemm(1, ptr(a), ptr(wn), ptr(out2), M, N, K, None, None, 1, 1, stream()))
+    report(f"gemm256 nn+= {M}x{N}x{K}", out2, ref + base.float(), 6e-3)
+    # the result must not depend on which kernel ran beyond accumulation order: compare with the 128-row kernel
+    lib.check(L.sdxl_set_gemm_mode(0))
+    out3 = torch.empty_like(out)
+    lib.check(L.sdxl_op_gemm(1, ptr(a), ptr(wn), ptr(out3), M, N, K, None, None, 0, 1, stream()))
+    lib.check(L.sdxl_set_gemm_mode(2))
+    report("gemm256 vs gemm128", out, out3.float(), 8e-3)
+
+
+@pytest.mark.parametrize("M,N,K,splitk", [(256, 256, 64, 1), (512, 256, 192, 1), (1280, 1280, 4096, 3), (256, 512, 1024, 4),
+                                          (256, 256, 320, 5)])
+def test_gemm256_tn_wgrad_bias(g256, M, N, K, splitk):
+    L = g256
+    a, b = rnd(K, M, seed=8), rnd(K, N, seed=9)
+    out = torch.zeros(M, N, dtype=torch.float32, device=dev())
+    bg = torch.zeros(M, dtype=torch.float32, device=dev())
+    lib.check(L.sdxl_op_gemm(2, ptr(a), ptr(b), ptr(out), M, N, K, ptr(bg), None, 1, splitk, stream()))
+    ref = a.float().t() @ b.float()
+    report(f"gemm256 tn {M}x{N}x{K} splitk={splitk}", out, ref, 2e-5 * math.sqrt(K) + 1e-5)
+    report("gemm256 tn bias grad", bg, a.float().sum(0), 2e-5 * math.sqrt(K) + 1e-5)
+    lib.check(L.sdxl_op_gemm(2, ptr(a), ptr(b), ptr(out), M, N, K, None, None, 1, splitk, stream()))    # accumulate
+    report("gemm256 tn +=", out, 2 * ref, 2e-5 * math.sqrt(K) + 1e-5)
+    lib.check(L.sdxl_op_gemm(2, ptr(a), ptr(b), ptr(out), M, N, K, None, None, 0, splitk, stream()))    # overwrite
+    report("gemm256 tn =", out, ref, 2e-5 * math.sqrt(K) + 1e-5)
+
+
 def _conv_ref(x_nhwc, w_native, bias, stride):
     """x [B,H,W,Cin], w [Cout][9][Cin] -> y [B,Ho,Wo,Cout] via F.conv2d fp32."""
     cout, _, cin = w_native.shape
@@ -297,8 +347,16 @@ def geglu_unpack_cols(u, C4, G=64):
 
 
 @pytest.mark.parametrize("M,K,C4,G", [(64, 128, 256, 64), (308, 320, 1280, 64), (308, 320, 1280, 80), (100, 128, 160, 80),
-                                      (4096, 1280, 5120, 80)])
+                                      (4096, 1280, 5120, 80), (4096, 1280, 5120, 64), (256, 256, 256, 64), (512, 256, 1280, 64)])
 def test_ff_geglu_fused_fwd_bwd(L, M, K, C4, G):
+    lib.check(L.sdxl_set_gemm_mode(2 if G == 64 else 1))      # group 64: through the 256 x 256 kernel's in-register GEGLU epilogues
+    try:
+        _ff_geglu_case(L, M, K, C4, G)
+    finally:
+        lib.check(L.sdxl_set_gemm_mode(1))
+
+
+def _ff_geglu_case(L, M, K, C4, G):
     """GEGLU fused into the two feed-forward projections (reference: diffusers GEGLU, ff.net.0.proj -> ff.net.2)."""
     x = rnd(M, K, seed=60)
     w1, b1 = rnd(2 * C4, K, seed=61, scale=K ** -0.5), rnd(2 * C4, seed=62, scale=0.1)
