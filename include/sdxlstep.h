@@ -198,7 +198,8 @@ int sdxl_probe_layout(void* out_dev, void* stream);
  * (2*M*N*K*taps), the summed event time and the number of launches. */
 int sdxl_profile_gemm_begin(void);
 /* tile-kernel selection of the GEMM family, for A/B measurements and parity tests: 0 = 128-row kernel only,
- * 1 = 256 x 256 kernel where its grid fills the chip (default), 2 = 256 x 256 kernel wherever it is applicable. */
+ * 1 = 256 x 256 kernel where its grid fills the chip (default), 2 = 256 x 256 kernel wherever it is applicable;
+ * + 4 * c forces configuration c (1, 2, 3 or 13) of the 128-row kernel. */
 int sdxl_set_gemm_mode(int mode);
 int sdxl_profile_gemm_end(double* flops, double* ms, int* launches);
 /* debug: checksum of every activation (grads != 0: of every activation gradient) of the current plan, in creation

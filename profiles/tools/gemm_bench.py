@@ -16,6 +16,8 @@ import sdxl_amd  # noqa: E402,F401
 from sdxl_amd import lib  # noqa: E402
 
 dev = torch.device("cuda:0")
+if "--lib" in sys.argv:       # diagnostics: a library built with -DG256_DIAG=<bits> (knock-outs), same C ABI
+    lib.LIB_PATH = Path(sys.argv[sys.argv.index("--lib") + 1]).resolve()
 L = lib.load()
 
 
@@ -67,9 +69,11 @@ for form, M, N, K, sk in SHAPES:
     t_blas = bench(lambda: ref_fn(ob))
     out = torch.empty(M, N, device=dev, dtype=torch.float32 if form == "TN" else torch.bfloat16)
     res = {}
+    args = (FORMS[form], a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, None, None, 0, sk, st())   # built once: the
+    fn = lambda: L.sdxl_op_gemm(*args)                                                                    # launch loop must not be host-bound
     for mode in (0, 2):
         lib.check(L.sdxl_set_gemm_mode(mode))
-        fn = lambda: lib.check(L.sdxl_op_gemm(FORMS[form], ptr(a), ptr(b), ptr(out), M, N, K, None, None, 0, sk, st()))
+        lib.check(fn())
         res[mode] = bench(fn)
     ref = ob.float()
     err = float((out.float() - ref).abs().max() / ref.abs().max())

@@ -60,17 +60,10 @@ int sdxl_create(const sdxl_unet_config* cfg, int device, sdxl_handle** out) {
   h->e.cfg = *cfg;
   h->e.device = device;
   h->e.build(nullptr);
-  const char* ns = getenv("SDXL_NO_SIDE_STREAM");
-  h->e.use_side = !(ns && ns[0] == '1');
+  const char* ns = getenv("SDXL_NO_SIDE_STREAM");     // measurement mode: everything on the caller's stream (clean per-kernel
+  h->e.use_side = !(ns && ns[0] == '1');              // durations for the serialized rocprof summaries under profiles/)
   if (h->e.use_side) {
-    {  // the side stream carries work that is off the critical path: lowest priority unless SDXL_SIDE_PRIO says otherwise
-      int lo = 0, hi = 0;
-      HIP_CHECK_RET(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      const char* sp = getenv("SDXL_SIDE_PRIO");
-      int mode = sp ? atoi(sp) : 0;     // 0 default priority, 1 lowest, 2 highest
-      int prio = mode == 1 ? lo : (mode == 2 ? hi : 0);
-      HIP_CHECK_RET(hipStreamCreateWithPriority(&h->e.side, hipStreamNonBlocking, prio));
-    }
+    HIP_CHECK_RET(hipStreamCreateWithFlags(&h->e.side, hipStreamNonBlocking));   // (stream priorities: measured, neutral)
     HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_join, hipEventDisableTiming));
     HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_hoist, hipEventDisableTiming));
   }
@@ -633,7 +626,8 @@ int sdxl_adamw_decay(void* shift, const void* p, size_t n, float decay, void* st
 int sdxl_probe_layout(void* out, void* st) { return probe_layout(out, (hipStream_t)st); }
 int sdxl_profile_gemm_begin(void) { return gemm_profile_begin(); }
 int sdxl_set_gemm_mode(int mode) {
-  ARG_CHECK(mode >= 0 && mode <= 2, "gemm mode %d (0, 1 or 2)", mode);
+  const int cfg = mode >> 2;
+  ARG_CHECK(mode >= 0 && (mode & 3) <= 2 && (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 3 || cfg == 13), "gemm mode %d", mode);
   gemm_set_mode(mode);
   return 0;
 }

@@ -80,20 +80,7 @@ bool Plan::grad_alias(Act* x, Act* y) {
 // ================================================================================================
 // Ops
 // ================================================================================================
-// split-K factor of a wgrad GEMM: enough workgroups to fill 256 CUs x 2, at least 8 K-steps per split
-static int pick_splitk(long out_rows, long out_cols, int taps, long red) {
-  long tiles = (long)cdiv(out_rows, 128) * cdiv(out_cols, 128) * taps;
-  long ktiles = cdiv(red, 64);
-  static long target = -1;
-  if (target < 0) { const char* e = getenv("SDXL_SPLITK_TARGET"); target = e ? atol(e) : 384; }
-  long s = target / tiles;
-  if (s < 1) s = 1;
-  long maxs = ktiles / 8;
-  if (maxs < 1) maxs = 1;
-  if (s > maxs) s = maxs;
-  if (s > 32) s = 32;
-  return (int)s;
-}
+static int pick_splitk(long out_rows, long out_cols, int taps, long red) { return gemm_pick_splitk((int)out_rows, (int)out_cols, taps, red); }
 static void want_slab(Plan& p, int M, int N, int taps, int splitk) {
   size_t need = gemm_slab_floats(M, N, taps, splitk);
   if (need > p.slab_floats) p.slab_floats = need;
@@ -296,13 +283,8 @@ struct LayerNormOp : Op {
   }
   void plan_bwd(Plan& p) override { dy_off = y->goff; dx = p.grad_dst(x); }
   int bwd(Plan& p, hipStream_t st, bool) override {
-    // dgamma / dbeta are leaves: they go to the side stream with the weight gradients
-    static int ln_side = -1;
-    if (ln_side < 0) { const char* e = getenv("SDXL_LN_SIDE"); ln_side = e ? atoi(e) : 0; }   // measured: no gain from moving them off the main stream
-    if (!ln_side) CHK(launch_layernorm_bwd_params(p.P(x), p.GP(dy_off), p.F(stats_off), p.eng->Gp(gm), p.eng->Gp(bt), (int)x->rows, C, st));
-    else CHK(on_side(p, st, [&](hipStream_t s2) -> int {
-      return launch_layernorm_bwd_params(p.P(x), p.GP(dy_off), p.F(stats_off), p.eng->Gp(gm), p.eng->Gp(bt), (int)x->rows, C, s2);
-    }));
+    // dgamma / dbeta column sums (moving them to the side stream was measured: no gain)
+    CHK(launch_layernorm_bwd_params(p.P(x), p.GP(dy_off), p.F(stats_off), p.eng->Gp(gm), p.eng->Gp(bt), (int)x->rows, C, st));
     return launch_layernorm_bwd_dx(p.P(x), p.GP(dy_off), p.eng->Wp(gm), p.F(stats_off), p.GP(dx.out), p.GP(dx.addend),
                                    (int)x->rows, C, st);
   }

@@ -25,14 +25,17 @@
 #define GEMM_DIRECT_EPILOGUE 1
 #endif
 
+static int g_mode256 = 1;     // 0: 128-row kernel only, 1: selection policy (gemm_use256), 2: 256 x 256 kernel wherever applicable
+static int g_force_cfg = 0;   // > 0: force that configuration of the 128-row kernel (microbenchmarks; sdxl_set_gemm_mode)
+
 static constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
-static constexpr int gemm_smem_bytes(int BN, int S, int BK, int BMT = BM) {
-  int ring = S * (BMT + BN) * BK * 2 + 1024, stg = 64 * (BN + 4) * 4;
+static constexpr int gemm_smem_bytes(int BN, int S, int BK) {
+  int ring = S * (BM + BN) * BK * 2 + 1024, stg = 64 * (BN + 4) * 4;
   return ring > stg ? ring : stg;
 }
 // workgroups per CU the register budget is sized for: what the 160 KiB of LDS admits, at most 3 (4-wave) / 1 (8-wave)
-static constexpr int gemm_occupancy(int BN, int S, int BK, int NW, int BMT = BM) {
-  int byl = (160 * 1024) / gemm_smem_bytes(BN, S, BK, BMT);
+static constexpr int gemm_occupancy(int BN, int S, int BK, int NW) {
+  int byl = (160 * 1024) / gemm_smem_bytes(BN, S, BK);
   return NW == 8 ? 1 : (byl > 3 ? 3 : (byl < 1 ? 1 : byl));
 }
 
@@ -43,12 +46,9 @@ static constexpr int gemm_occupancy(int BN, int S, int BK, int NW, int BMT = BM)
 //        source is a running pointer (conv: fixed base + uniform offset + border predicate) advanced by a
 //        per-lane constant each K-step (0 for out-of-range rows, which keep pointing at the zero vector), and the DMA
 //        pieces are issued between groups of MFMAs so their issue cost hides under the matrix pipe.
-// BMT  : output rows per workgroup (128; 256 for the ping-pong configuration)
-// PP   : ping-pong schedule (8 waves = two groups of four, one wave of each group per SIMD): while one group's MFMAs
-//        run, the other group reads its next fragments from LDS and vice versa -- see the main loop
-template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW, int BMT = BM, bool PP = false>
-__global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW, BMT)) void gemm_kernel(const GemmP p) {
-  static_assert(!PP || (FAST && NW == 8 && S >= 3 && FORM != GEMM_TN), "ping-pong: FAST NT / NN, 8 waves, ring >= 3");
+template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW>
+__global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_kernel(const GemmP p) {
+  constexpr int BMT = BM;
   constexpr int A_TILE_BYTES = BMT * BK * 2;      // [BMT][BK] or [BK][128] bf16
   constexpr int B_TILE_BYTES = BN * BK * 2;       // [BN][BK] or [BK][BN] bf16
   constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW, BMT)) void g
 
   // ---- S-deep ring: K-steps t+1 .. t+S-1 are in flight (LDS-DMA) while step t is multiplied ----
   const int T = kt_end - kt_begin;
-  constexpr int U = (PP && BK == 32) ? 2 : 1;   // ping-pong, BK = 32: two K-steps per phase (finer DMA granularity, same phase length)
+  constexpr int U = 1;
 #pragma unroll
   for (int d = 0; d < S - U; ++d) {
     if (d < T) stage(kt_begin + d, d);
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW, BMT)) void g
 #pragma unroll
       for (int i = 0; i < MI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[i], ones, accb[i], 0, 0, 0);
     }
-    if (!FAST || PP) __builtin_amdgcn_s_setprio(1);
+    if (!FAST) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW, BMT)) void g
         else if (DIRECT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b[j], f.a[i], acc[i][j], 0, 0, 0);
         else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
       }
-      if (FAST && !PP) {  // one DMA piece per MFMA group
+      if (FAST) {  // one DMA piece per MFMA group
         constexpr int NSLOT = KS * MI;
         const int slot = ks * MI + i;
 #pragma unroll
@@ -450,49 +450,8 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW, BMT)) void g
           if (pc % NSLOT == slot) issue_piece(pc, wslot, live);
       }
     }
-    if (!FAST || PP) __builtin_amdgcn_s_setprio(0);
+    if (!FAST) __builtin_amdgcn_s_setprio(0);
   };
-  if (PP) {
-    // ---- ping-pong schedule.  Waves 0-3 (group 0, tile rows 0..127) and waves 4-7 (group 1, rows 128..255) share every
-    // barrier but group 1 runs one barrier late, so on each SIMD one wave is in its MFMA phase while the other reads
-    // its next fragments from LDS (and waits for them): the LDS latency chain and the matrix pipe overlap by
-    // construction.  Per wave and K-step u:  B1 | read(u, ks 0) | B2 | mfma(ks 0) + DMA | B3 | read(u, ks 1), vmcnt | B4 |
-    // mfma(ks 1) + DMA.   DMA pieces issued during the products of step u belong to step u + S - 1 and land in the slot of
-    // step u - 1, whose last reader (group 1, ks 1) retired its reads (lgkmcnt 0) before its B4(u - 1), which is group
-    // 0's B1(u) and precedes every product phase of step u.  Step u + 1 is first read by group 0 after its B1(u + 1) =
-    // group 1's B4(u): every wave therefore waits, before its own B4(u), until its pieces of step u + 1 have landed
-    // (outstanding allowed: steps u + 2 .. u + S - 2 and the pieces of step u + S - 1 issued in the ks 0 phase).
-    const int grp = wave >> 2;
-    FragK f[KS * U];
-    wait_vmcnt<(S - 2 * U) * NL>();                   // steps 0 .. U-1 landed (mine)
-    if (grp == 1) __builtin_amdgcn_s_barrier();       // skew
-    for (int t = 0; t < T; t += U) {
-      __builtin_amdgcn_s_barrier();                                   // B1
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int slot = rd + u >= S ? rd + u - S : rd + u;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) read_ks(slot, ks, f[u * KS + ks]);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {                                   // DMA of steps t + S - U + u -> slots of steps t - U + u
-        const bool live = t + u + S - U < T;
-#pragma unroll
-        for (int pc = 0; pc < NL; ++pc) issue_piece(pc, wr, live);
-        advance();
-        wr = wr + 1 == S ? 0 : wr + 1;
-      }
-      wait_vmcnt<(S - 2 * U) * NL>();                                 // my pieces of the next iteration's steps have landed
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                                   // B2
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) mfma_ks(f[u * KS + ks], ks, 0, false);
-      rd = rd + U >= S ? rd + U - S : rd + U;
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();       // both groups execute the same number of barriers
-  } else
   // (A register-prefetch variant -- fragments of step t + 1 read while the products of step t run, one ring slot
   // fewer in flight -- was measured on the S >= 3 configurations: 5-20 % slower, so the loop stays as it is.)
   for (int t = 0; t < T; ++t) {
@@ -717,76 +676,39 @@ void gemm_defaults(GemmP* p) {
   p->rows_per_batch = 1;
 }
 
-template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW, int BMT = BM, bool PP = false>
+template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW>
 static int launch_k(const GemmP& p, hipStream_t st) {
   static bool attr_set = false;
-  constexpr int smem = gemm_smem_bytes(BN, S, BK, BMT);
+  constexpr int smem = gemm_smem_bytes(BN, S, BK);
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW, BMT, PP>,
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  dim3 grid(cdiv(p.N, BN), cdiv(p.M, BMT), FORM == GEMM_TN ? p.taps * p.splitk : 1);
-  hipLaunchKernelGGL((gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW, BMT, PP>), grid, dim3(NW * 64), smem, st, p);
+  dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), FORM == GEMM_TN ? p.taps * p.splitk : 1);
+  hipLaunchKernelGGL((gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW>), grid, dim3(NW * 64), smem, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-template <int FORM, bool CONV, int BN, int S, int BK, int NW, int BMT = BM>
+template <int FORM, bool CONV, int BN, int S, int BK, int NW>
 static int launch_cfg(const GemmP& p, hipStream_t st) {
-  static int nofast = -1;
-  if (nofast < 0) { const char* e = getenv("SDXL_GEMM_NOFAST"); nofast = e ? atoi(e) : 0; }   // 1: all, 2: conv only
-  if (!CONV && p.K % BK == 0 && nofast != 1) return launch_k<FORM, false, BN, S, BK, true, NW, BMT>(p, st);
+  if (!CONV && p.K % BK == 0) return launch_k<FORM, false, BN, S, BK, true, NW>(p, st);
   // same-size stride-1 3x3 convolutions (all but the two downsamplers, their transposed dgrads and conv_in)
-  if (CONV && nofast == 0 && p.taps == 9 && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws && p.K % BK == 0 &&
-      true)
-    return launch_k<FORM, true, BN, S, BK, true, NW, BMT>(p, st);
-  return launch_k<FORM, CONV, BN, S, BK, false, NW, BMT>(p, st);
+  if (CONV && p.taps == 9 && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws && p.K % BK == 0)
+    return launch_k<FORM, true, BN, S, BK, true, NW>(p, st);
+  return launch_k<FORM, CONV, BN, S, BK, false, NW>(p, st);
 }
 
-// configurations 10 / 11 (experimental, off by default): 256x128 tile, 8 waves in the ping-pong schedule, BK 64 with a
-// 3-deep ring or BK 32 with a 6-deep ring (145 KiB, 1 workgroup per CU).  FAST staging only (NT / NN); anything else
-// falls back to configuration 1.  Measured: +5..7 % over configuration 1 on large grids (8192^3: 1135 vs 1058 TFLOP/s,
-// 4096x3840x1280: 857 vs 846), equal or slower elsewhere, neutral at step level (SDXL_GEMM_PP_MIN=<tiles> enables it
-// for forward problems with at least that many 256x128 tiles); knock-outs show the read phase (~550 cycles for 4 x 16
-// ds_read_b128 + wait) and the one-step DMA lead of a 3-deep ring, not the MFMA phase (512 cycles), set the pace.
-template <int FORM, bool CONV, int S, int BK>
-static int launch_pp(const GemmP& p, hipStream_t st) {
-  if constexpr (FORM == GEMM_TN) {
-    return launch_cfg<FORM, CONV, 128, 2, 64, 4>(p, st);
-  } else {
-    if (!CONV && p.K % 64 == 0) return launch_k<FORM, false, 128, S, BK, true, 8, 256, true>(p, st);
-    if (CONV && p.taps == 9 && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws && p.K % 64 == 0)
-      return launch_k<FORM, true, 128, S, BK, true, 8, 256, true>(p, st);
-    return launch_cfg<FORM, CONV, 128, 2, 64, 4>(p, st);
-  }
-}
-
-// Tile / pipeline selection.  Configurations (SDXL_GEMM_CFG=<id> forces one, for benchmarking):
+// Tile / pipeline selection of the 128-row kernel.  Four configurations:
 //   1: 128x128, BK 64, 2-deep ring, 4 waves  (65 KiB LDS, 2 workgroups per CU)          -- default
-//   2: 128x128, BK 32, 2-deep ring, 4 waves  (34 KiB LDS, 3-4 per CU)                   -- large-grid dgrad / wgrad
+//   2: 128x128, BK 32, 2-deep ring, 4 waves  (34 KiB LDS, 3-4 per CU)                   -- large-grid dgrad
 //   3: 128x160, BK 64, 4-deep ring, 8 waves  (145 KiB LDS, 1 per CU, 3 K-steps of DMA in flight)
-//   4: 128x128, BK 64, 4-deep ring, 8 waves  (129 KiB LDS, 1 per CU)
-//   5: 128x128, BK 64, 3-deep ring, 4 waves  (97 KiB LDS, 1 per CU)
-//  13: 128x160, BK 64, 2-deep ring, 4 waves x (64x80)  (73 KiB, 2 per CU)            -- where 160-wide tiles fill the rounds
-//  (a 64x160 variant for the N = 1280 dgrads was +4 % in isolation and -5 % at step level: twice the workgroups crowd
-//   out the side stream's wgrad)
-static int g_force_cfg = -1;
+//  13: 128x160, BK 64, 2-deep ring, 4 waves x (64x80)  (73 KiB, 2 per CU)               -- where 160-wide tiles fill the rounds
+// (Measured and dropped: 4-deep / 3-deep 128x128 rings, 6-deep BK 32 rings, a 64x160 tile, a 256x128 ping-pong schedule --
+//  DESIGN.md section 10.)
 template <int FORM, bool CONV>
 static int launch_one(const GemmP& p, hipStream_t st) {
-  if (g_force_cfg < 0) {
-    const char* e = getenv("SDXL_GEMM_CFG");
-    g_force_cfg = e ? atoi(e) : 0;
-  }
   int cfg = 1;
-  static int c3 = -1, tn_cfg = 1, tnc_cfg = 1, nn_small = 1, nn_big = 2;
-  if (c3 < 0) {
-    const char* e = getenv("SDXL_GEMM_C3");
-    c3 = e ? atoi(e) : 1;
-    if ((e = getenv("SDXL_GEMM_TN_CFG"))) tn_cfg = atoi(e);
-    if ((e = getenv("SDXL_GEMM_TNC_CFG"))) tnc_cfg = atoi(e);
-    if ((e = getenv("SDXL_GEMM_NN_SMALL"))) nn_small = atoi(e);
-    if ((e = getenv("SDXL_GEMM_NN_BIG"))) nn_big = atoi(e);
-  }
   // Tile-count quantisation decides most of it on this model's shapes: a launch of t workgroups runs in
   // ceil(t / 512) rounds of (256 CUs x 2 resident workgroups), so e.g. an N = 640 output at M = 16384 is 640 tiles of
   // 128x128 (1.25 rounds, 62 % of the slots used) but exactly 512 tiles of 128x160.
@@ -796,47 +718,27 @@ static int launch_one(const GemmP& p, hipStream_t st) {
   const bool n160 = p.N % 160 == 0 && (!p.geglu || g80);
   const long t160 = n160 ? (long)cdiv(p.M, BM) * (p.N / 160) * zmul : 0;
   auto fill = [](long t) { const long cap = 512; return (double)t / (double)(((t + cap - 1) / cap) * cap); };
-  static int sel = -1;
-  if (sel < 0) { const char* e = getenv("SDXL_GEMM_SEL"); sel = e ? atoi(e) : 1; }
-  // the transpose-read forms (dgrad / wgrad) spend twice the LDS-read issue slots per K-step: BK = 32 variants with
-  // 3-4 workgroups per CU hide that better on large grids
-  if (FORM == GEMM_NN) cfg = blocks >= 700 ? nn_big : nn_small;
-  if (FORM == GEMM_TN) cfg = CONV ? tnc_cfg : tn_cfg;
+  // the transpose-read forms (dgrad) spend twice the LDS-read issue slots per K-step: the BK = 32 variant with 3-4
+  // workgroups per CU hides that better on large grids
+  if (FORM == GEMM_NN) cfg = blocks >= 700 ? 2 : 1;
   // 128x160 tiles, 4 waves x (64x80), 2-deep, 73 KiB (2 per CU): where they fill the rounds at least as well as 128x128
   // they also move 10 % fewer operand bytes per flop (measured +5..45 %: 16384x640x2560 641 -> 931 TFLOP/s)
-  if (sel && n160 && t160 > 256 && fill(t160) * 1.05 >= fill(blocks)) cfg = 13;
+  if (n160 && t160 > 256 && fill(t160) * 1.05 >= fill(blocks)) cfg = 13;
   // wgrad (side stream): always the wider tile where the output allows it -- 20 % fewer workgroups competing with the
-  // dgrad chain for CU slots is worth more at step level (-0.7 ms) than the tile's own speed (slower in isolation on
-  // some shapes: 10240x1280x4096 690 vs 762 TFLOP/s)
-  if (sel && n160 && FORM == GEMM_TN) cfg = 13;
+  // dgrad chain for CU slots is worth more at step level (-0.7 ms) than the tile's own speed
+  if (n160 && FORM == GEMM_TN) cfg = 13;
   // forward problems that fit one round of one 128x160 workgroup per CU (N = 1280 outputs at M = 4096, the 1280-channel
   // convs): the 8-wave, 4-deep-ring configuration keeps 3 K-steps of DMA in flight and wins +15..30 % there.  Not for
   // dgrad / wgrad: a one-per-CU workgroup on one stream starves the other stream's kernels of LDS (168 vs 152 ms/step).
-  if (FORM == GEMM_NT && (c3 & 1) && n160 && t160 <= (sel ? 256 : 512)) cfg = 3;
-  {   // experiment knob: ping-pong configuration for forward problems with >= pp_min 256x128 tiles
-    static long pp_min = -1;
-    if (pp_min < 0) { const char* e = getenv("SDXL_GEMM_PP_MIN"); pp_min = e ? atol(e) : 0; }
-    static int pp_geglu = -1;
-    if (pp_geglu < 0) { const char* e = getenv("SDXL_GEMM_PP_GEGLU"); pp_geglu = e ? atoi(e) : 0; }
-    if (pp_min > 0 && FORM == GEMM_NT && cfg == 1 && (!p.geglu || pp_geglu) && (long)cdiv(p.M, 256) * cdiv(p.N, 128) >= pp_min) cfg = 10;
-  }
-  if (g_force_cfg) cfg = g_force_cfg;
-  if (p.geglu && !g80 && (cfg == 3 || cfg == 6 || cfg == 13)) cfg = 1;   // group-64 packing needs 128-column tiles
-  if (g80 && cfg != 3 && cfg != 13) cfg = 13;                            // group-80 packing needs 160-column tiles
-  if (cfg == 3 && p.N % 160 != 0) cfg = 4;
-  if (cfg == 13 && p.N % 160 != 0) cfg = 1;
+  if (FORM == GEMM_NT && n160 && t160 <= 256) cfg = 3;
+  if (g_force_cfg > 0) cfg = g_force_cfg;
+  if (p.geglu && !g80 && (cfg == 3 || cfg == 13)) cfg = 1;   // group-64 packing needs 128-column tiles
+  if (g80 && cfg != 3 && cfg != 13) cfg = 13;                // group-80 packing needs 160-column tiles
+  if ((cfg == 3 || cfg == 13) && p.N % 160 != 0) cfg = 1;
   switch (cfg) {
     case 2: return launch_cfg<FORM, CONV, 128, 2, 32, 4>(p, st);
     case 3: return launch_cfg<FORM, CONV, 160, 4, 64, 8>(p, st);
-    case 4: return launch_cfg<FORM, CONV, 128, 4, 64, 8>(p, st);
-    case 5: return launch_cfg<FORM, CONV, 128, 3, 64, 4>(p, st);
-    case 6: return launch_cfg<FORM, CONV, 160, 3, 64, 8>(p, st);
-    case 7: return launch_cfg<FORM, CONV, 128, 4, 32, 4>(p, st);
-    case 8: return launch_cfg<FORM, CONV, 128, 3, 32, 4>(p, st);
-    case 9: return launch_cfg<FORM, CONV, 128, 6, 32, 8>(p, st);
     case 13: return launch_cfg<FORM, CONV, 160, 2, 64, 4>(p, st);
-    case 10: return launch_pp<FORM, CONV, 3, 64>(p, st);
-    case 11: return launch_pp<FORM, CONV, 6, 32>(p, st);
     default: return launch_cfg<FORM, CONV, 128, 2, 64, 4>(p, st);
   }
 }
@@ -881,8 +783,42 @@ int gemm_profile_end(double* flops, double* ms, int* launches) {
   if (launches) *launches = (int)g_prof.flops.size();
   return 0;
 }
-static int g_mode256 = -1;
-void gemm_set_mode(int mode) { g_mode256 = mode; }
+// Selection between the two kernels (measured on MI355X, profiles/r02*_gemm_bench.txt).  The 256 x 256 kernel runs one
+// workgroup per CU, so what counts is how well its tiles fill rounds of 256 CUs and how many K-tiles amortise its ~12 us of
+// unoverlapped prologue + epilogue per tile (with 2-3 workgroups per CU the 128-row kernel overlaps those by itself):
+//   wgrad (TN, reduction over 4096+ rows): +25..35 % wherever tiles x splits reaches ~3/4 of a round;
+//   forward / dgrad: only where the tiles fill their rounds (>= 90 %): 4096x3840x1280 (240 tiles) +5..20 %,
+//   16384x5120x640 (5 rounds) +12 %; 640 tiles (2.5 rounds) or 320 tiles lose to the 128-row kernel.
+bool gemm_use256(int form, int M, int N, int K, int splitk) {
+  if (M % 256 || N % 256 || K % 64) return false;
+  const long wgs = (long)(M / 256) * (N / 256) * (form == GEMM_TN ? splitk : 1);
+  const double fill = (double)wgs / (double)(((wgs + 255) / 256) * 256);
+  if (form == GEMM_TN) return wgs >= 160 && (fill >= 0.75 || wgs >= 1024) && K / 64 / splitk >= 8;
+  return wgs >= 192 && (fill >= 0.9 || wgs >= 1024);
+}
+// split-K factor of a wgrad GEMM [M][N*taps] (+)= A^T . B over `red` rows
+int gemm_pick_splitk(int M, int N, int taps, long red) {
+  if (taps == 1 && g_mode256 && M % 256 == 0 && N % 256 == 0 && red % 64 == 0) {   // one round of 256 x 256 tiles
+    const long t256 = (long)(M / 256) * (N / 256);
+    if (t256 >= 48) {
+      long s = (224 + t256 / 2) / t256;
+      if (s < 1) s = 1;
+      while (s > 1 && red / 64 / s < 8) --s;
+      if (gemm_use256(GEMM_TN, M, N, (int)red, (int)s)) return (int)s;
+    }
+  }
+  // 128-row kernel: enough workgroups to fill 256 CUs x 2 (tiles x splits ~ 384), at least 8 K-steps per split
+  const long tiles = (long)cdiv(M, 128) * cdiv(N, 128) * taps;
+  const long ktiles = cdiv(red, 64);
+  long s = 384 / tiles;
+  if (s < 1) s = 1;
+  long maxs = ktiles / 8;
+  if (maxs < 1) maxs = 1;
+  if (s > maxs) s = maxs;
+  if (s > 32) s = 32;
+  return (int)s;
+}
+void gemm_set_mode(int mode) { g_mode256 = mode & 3; g_force_cfg = mode >> 2; }
 static int launch_gemm_impl(const GemmP& pin, hipStream_t st);
 int launch_gemm(const GemmP& p, hipStream_t st) {
   if (!g_prof.on) return launch_gemm_impl(p, st);
@@ -932,10 +868,8 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
   }
   if (p.splitk < 1) p.splitk = 1;
   {
-    static int xs = -1;
-    if (xs < 0) { const char* e = getenv("SDXL_GEMM_XCD"); xs = e ? atoi(e) : 1; }
     p.xcd_px = 0;
-    if (xs) {   // px x (8/px) XCD grid over (n, m) tiles minimising per-XCD operand footprint ~ N/px + M/py
+    {   // px x (8/px) XCD grid over (n, m) tiles minimising per-XCD operand footprint ~ N/px + M/py
       const int gx = cdiv(p.N, 128), gy = cdiv(p.M, BM);
       double best = 1e30;
       for (int px = 1; px <= 8; px *= 2) {
@@ -954,11 +888,8 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
   const bool conv = p.taps == 9;
   int rc;
   {   // 256 x 256 kernel (gemm256.hip)
-    if (g_mode256 < 0) { const char* e = getenv("SDXL_GEMM_G256"); g_mode256 = e ? atoi(e) : 1; }
-    const int g256 = g_mode256;
-    if (g256 && gemm256_applicable(p)) {
-      const long wgs = (long)(p.M / 256) * (p.N / 256) * p.splitk;
-      if (g256 == 2 || wgs >= 192) {
+    if (g_mode256 && gemm256_applicable(p)) {
+      if (g_mode256 == 2 || gemm_use256(p.form, p.M, p.N, p.K, p.splitk)) {
         rc = launch_gemm256(p, st);
         if (rc == 0 && p.splitk > 1) {
           const long nv = (long)p.M * (p.N / 4);

@@ -10,18 +10,20 @@
 //   * the A tile [256][64] and B tile [256][64] of a K-step live in LDS as four 16 KiB REGIONS: A-a0 / A-a1 (the first /
 //     second 64 rows of both wave rows), B-b0 / B-b1 (the first / second 32 columns of all four wave columns); two
 //     buffers (even / odd K-tile).
-//   * a K-tile is multiplied in four PHASES, one 64 x 32 accumulator quadrant of every wave each (16 MFMAs):
-//       P1 (a0,b0)  P2 (a0,b1)  P3 (a1,b1)  P4 (a1,b0)        reads: P1 A-a0 + B-b0, P2 B-b1, P3 A-a1, P4 none
-//     phase = { ds_reads of the phase ; 2 LDS-DMA pieces (one region of a later K-tile) ; s_waitcnt vmcnt(8) ; s_barrier ;
-//               lgkmcnt(0) ; s_setprio 1 ; 16 MFMA ; s_setprio 0 ; s_barrier }.
+//   * a K-tile is multiplied in two PHASES, one 64 x 64 half of every wave's accumulator tile each (32 MFMAs):
+//       A: rows 0..63   reads A-a0 (8 b128) + B-b0, B-b1 (8)          B: rows 64..127   reads A-a1 (8), B kept in registers
+//     phase = { ds_reads of the phase ; counted s_waitcnt vmcnt ; s_barrier ; s_setprio 1 ; 32 MFMA with the phase's LDS-DMA
+//               pieces (regions of later K-tiles) issued between them ; s_setprio 0 ; s_barrier }.
 //     Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA section while the other issues
-//     its LDS reads / DMA -- the matrix pipe and the LDS path alternate by construction.
-//   * region schedule (regions are restaged as soon as they are dead):  P1(t) <- B-b1(t+1), P2(t) <- A-a1(t+1),
-//     P3(t) <- A-a0(t+2), P4(t) <- B-b0(t+2).  Hazards, with global barrier b_2p-2 = first barrier of phase p for waves
-//     0-3 (b_2p-1 for waves 4-7):  WAR -- a region last read in phase p has been read by every wave before b_2p, the
-//     earliest DMA of phase p+2 is issued after b_2p+1;  RAW -- a piece issued in phase q is complete for its issuing wave
-//     after the vmcnt(8) of phase q+4 (2 pieces per phase, in-order return), i.e. before b_2(q+4)-1 for every wave, and
-//     is first read in phase q+5 or later (after b_2(q+4)-1).  Four phases (= one K-tile of MFMA time) of lead.
+//     its LDS reads and waits at the barrier -- the matrix pipe and the LDS path alternate by construction.  (A four-phase
+//     version -- 16 MFMAs per phase, the guide's template -- was measured first: the 12 ds_read_b128 of its first phase take
+//     longer than the partner's 16 MFMAs and every s_barrier costs ~55 cycles of latency, profiles/r02*_g256_stamps.)
+//   * region schedule (regions are restaged as soon as they are dead):  phase A(t) <- A-a1(t+1), phase B(t) <- A-a0, B-b0,
+//     B-b1 of K-tile t+2.  Hazards, with the DMA of a phase issued in its MFMA section (after the phase's first barrier):
+//     WAR -- a region last read in phase p has been read by every wave before the second barrier of phase p of waves 4-7,
+//     which precedes every MFMA section of phase p+1;  RAW -- a piece issued in phase q is waited for (counted vmcnt: only
+//     the pieces of phase q+1 may be outstanding) before the first barrier of phase q+2 of its issuing wave and first read
+//     in phase q+3.  One K-tile of MFMA time of lead.
 //   * LDS-DMA = buffer_load_dwordx4 ... lds through a raw buffer descriptor: per-lane 32-bit offset (constant for the
 //     whole kernel) + scalar offset per piece; out-of-range (tail) pieces return zeros without touching memory.
 //   * bank swizzles, fragment reads, transposed reads for the N-contiguous operands: gemm_tiles.h (same as gemm.hip).
@@ -42,6 +44,22 @@ constexpr unsigned OOB = 0x80000000u;  // per-lane offset beyond num_records: th
 
 template <int N>
 struct IC { static constexpr int v = N; };
+
+#ifndef G256_DIAG      // scratch diagnostics only (never defined in the product build): knock out one pipeline component
+#define G256_DIAG 0    // bit 0: no MFMA, bit 1: no DMA in the main loop, bit 2: no LDS fragment reads, bit 3: no explicit lgkmcnt(0)
+#endif                 // bit 4: s_memtime stamps of waves 0 and 4 of workgroup 0 (K-tiles 8..11) into g256_stamps
+#if G256_DIAG & 16
+__device__ unsigned long long g256_stamps[2 * 4 * 4 * 8];   // [wave half][K-tile 8..11][phase (2 used)][event]
+#define STAMP(ev)                                                                                              \
+  do {                                                                                                         \
+    if (stamp_on && t >= 8 && t < 12) {                                                                        \
+      unsigned long long ts_ = __builtin_amdgcn_s_memtime();                                                   \
+      if (lane == 0) g256_stamps[((wr * 4 + (t - 8)) * 4 + ph_) * 8 + (ev)] = ts_;                             \
+    }                                                                                                          \
+  } while (0)
+#else
+#define STAMP(ev) do { } while (0)
+#endif
 
 template <int FORM, bool BIAS>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmP p) {
@@ -83,22 +101,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmP p) {
     voA = A_KC ? (unsigned)(kc_row * lda + kc_vec * 8) * 2u : (unsigned)(nc_row * lda + 128 * (c >> 6) + (c & 63)) * 2u;
     voB = B_KC ? (unsigned)(kc_row * ldb + kc_vec * 8) * 2u : (unsigned)(nc_row * ldb + 64 * (c >> 5) + (c & 31)) * 2u;
   }
-  // region R (0: A-a0, 1: A-a1, 2: B-b0, 3: B-b1) of K-tile `tile` (relative to kt_begin) -> buffer buf; 2 pieces per wave
-  auto stage = [&](auto REG, int tile, int buf) {
+  // piece h (0 / 1) of this wave's share of region R (0: A-a0, 1: A-a1, 2: B-b0, 3: B-b1) of K-tile `tile` (relative to
+  // kt_begin) -> buffer buf.  Tiles beyond the range become dummy loads (zeros into the pad) so that the vmcnt arithmetic
+  // stays uniform.
+  auto piece = [&](auto REG, int h, int tile, int buf) {
     constexpr int R = decltype(REG)::v;
     constexpr int ab = R & 1;
     const bool live = tile < T;
+    if ((G256_DIAG & 2) && tile >= 2) return;
     const int k0 = (kt_begin + tile) * 64;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int q = wave + 8 * h;
-      int so;
-      if (R < 2) so = A_KC ? (m0 + 128 * h + 64 * ab + 8 * wave) * lda + k0 : (k0 + 4 * q) * lda + m0 + 64 * ab;
-      else so = B_KC ? (n0 + cbase(2 * h + (wave >> 2), ab) + 8 * (wave & 3)) * ldb + k0 : (k0 + 4 * q) * ldb + n0 + 32 * ab;
-      char* dst = live ? smem + buf * BUFB + R * REGION + q * 1024 : smem + PAD_OFF;
-      const unsigned vo = live ? (R < 2 ? voA : voB) : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(R < 2 ? ra : rb, (lds_void*)dst, 16, (int)vo, live ? so * 2 : 0, 0, 0);
-    }
+    const int q = wave + 8 * h;
+    int so;
+    if (R < 2) so = A_KC ? (m0 + 128 * h + 64 * ab + 8 * wave) * lda + k0 : (k0 + 4 * q) * lda + m0 + 64 * ab;
+    else so = B_KC ? (n0 + cbase(2 * h + (wave >> 2), ab) + 8 * (wave & 3)) * ldb + k0 : (k0 + 4 * q) * ldb + n0 + 32 * ab;
+    char* dst = live ? smem + buf * BUFB + R * REGION + q * 1024 : smem + PAD_OFF;
+    const unsigned vo = live ? (R < 2 ? voA : voB) : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(R < 2 ? ra : rb, (lds_void*)dst, 16, (int)vo, live ? so * 2 : 0, 0, 0);
+  };
+  auto stage = [&](auto REG, int tile, int buf) {
+    piece(REG, 0, tile, buf);
+    piece(REG, 1, tile, buf);
   };
 
   f32x4 acc[8][4];
@@ -115,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmP p) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
-  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+  bf16x8 fa[4][2], fb[4][2];
   auto read_a = [&](int buf, auto AQ) {
     constexpr int a = decltype(AQ)::v;
     const char* R = smem + buf * BUFB + a * REGION;
@@ -123,37 +145,55 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmP p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        if (A_KC) fa[i][ks] = frag_kc<64>(R, 64 * wr + 16 * i + l16, ks * 4 + g);
+        if (G256_DIAG & 4) fa[i][ks] = ones;
+        else if (A_KC) fa[i][ks] = frag_kc<64>(R, 64 * wr + 16 * i + l16, ks * 4 + g);
         else fa[i][ks] = frag_nc<128>(R, ks * 32 + g * 8, 64 * wr + 16 * i, l16);
       }
   };
-  auto read_b = [&](int buf, auto BQ) {
-    constexpr int b = decltype(BQ)::v;
-    const char* R = smem + buf * BUFB + (2 + b) * REGION;
+  auto read_b = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 4; ++j) {
+      const char* R = smem + buf * BUFB + (2 + (j >> 1)) * REGION;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 f;
-        if (B_KC) f = frag_kc<64>(R, 32 * wc + 16 * j + l16, ks * 4 + g);
-        else f = frag_nc<128>(R, ks * 32 + g * 8, 32 * wc + 16 * j, l16);
-        if (b == 0) fb0[j][ks] = f; else fb1[j][ks] = f;
+        if (G256_DIAG & 4) fb[j][ks] = ones;
+        else if (B_KC) fb[j][ks] = frag_kc<64>(R, 32 * wc + 16 * (j & 1) + l16, ks * 4 + g);
+        else fb[j][ks] = frag_nc<128>(R, ks * 32 + g * 8, 32 * wc + 16 * (j & 1), l16);
       }
+    }
   };
-  auto mma = [&](auto AQ, auto BQ) {
-    constexpr int a = decltype(AQ)::v, b = decltype(BQ)::v;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // 32 products of one accumulator half (64 rows x 64 columns of the wave tile); the phase's LDS-DMA pieces are issued
+  // between the MFMAs (one after every four), where their issue cost hides under the matrix pipe
+  auto mma = [&](auto AQ, int tile_next) {
+    constexpr int a = decltype(AQ)::v;
+    const int nbuf = tile_next & 1;
+    if (!(G256_DIAG & 8)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[4 * a + i][2 * b + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b == 0 ? fb0[j][ks] : fb1[j][ks], fa[i][ks],
-                                                                              acc[4 * a + i][2 * b + j], 0, 0, 0);
-      if (BIAS && b == 1 && do_bias) {   // once per A quadrant (phases P2 and P3)
+        for (int j = 0; j < 4; ++j)
+          if (G256_DIAG & 1) acc[4 * a + i][j][0] += (float)fa[i][ks][0] + (float)fb[j][ks][0];
+          else acc[4 * a + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[4 * a + i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int slot = ks * 4 + i;          // 8 slots of 4 MFMAs
+        if (a == 0) {                         // phase A: A-a1 of the next K-tile
+          if (slot == 2) piece(IC<1>{}, 0, tile_next, nbuf);
+          if (slot == 5) piece(IC<1>{}, 1, tile_next, nbuf);
+        } else {                              // phase B: A-a0, B-b0, B-b1 of the K-tile after the next
+          if (slot == 0) piece(IC<0>{}, 0, tile_next, nbuf);
+          if (slot == 1) piece(IC<0>{}, 1, tile_next, nbuf);
+          if (slot == 2) piece(IC<2>{}, 0, tile_next, nbuf);
+          if (slot == 3) piece(IC<2>{}, 1, tile_next, nbuf);
+          if (slot == 4) piece(IC<3>{}, 0, tile_next, nbuf);
+          if (slot == 5) piece(IC<3>{}, 1, tile_next, nbuf);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (BIAS && do_bias) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           accb[BIAS ? 4 * a + i : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i][ks], accb[BIAS ? 4 * a + i : 0], 0, 0, 0);
@@ -161,54 +201,56 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmP p) {
     }
     __builtin_amdgcn_s_setprio(0);
   };
-  // phase boundaries
-  auto pre = [&]() {   // reads + DMA of the phase are issued: counted DMA wait, then the first barrier of the phase
-    wait_vmcnt<8>();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-  };
   auto post = [&]() {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
   };
 
-  // ---- prologue: K-tile 0 complete, A-a0 / B-b0 of K-tile 1 in flight ----
+  // ---- prologue: K-tile 0 complete; A-a0, B-b0, B-b1 of K-tile 1 in flight (complete at the first phase B) ----
   stage(IC<0>{}, 0, 0);
   stage(IC<2>{}, 0, 0);
   stage(IC<3>{}, 0, 0);
   stage(IC<1>{}, 0, 0);
   stage(IC<0>{}, 1, 1);
   stage(IC<2>{}, 1, 1);
-  wait_vmcnt<4>();
+  stage(IC<3>{}, 1, 1);
+  wait_vmcnt<6>();
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind
 
+#if G256_DIAG & 16
+  const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && (wave & 3) == 0;
+#endif
   for (int t = 0; t < T; ++t) {
-    const int cb = t & 1, nb = cb ^ 1;
-    // P1: quadrant (a0, b0)
+    const int cb = t & 1;
+    int ph_ = 0;
+    (void)ph_;
+    // phase A: rows 0..63 of the wave tile x all 64 columns; DMA: A-a1 of K-tile t+1
+    STAMP(0);
     read_a(cb, IC<0>{});
-    read_b(cb, IC<0>{});
-    stage(IC<3>{}, t + 1, nb);
-    pre();
-    mma(IC<0>{}, IC<0>{});
+    read_b(cb);
+    STAMP(1);
+    wait_vmcnt<6>();                       // A-a1 of this K-tile (issued in phase A of K-tile t-1) has landed
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    STAMP(2);
+    mma(IC<0>{}, t + 1);
+    STAMP(3);
     post();
-    // P2: (a0, b1)
-    read_b(cb, IC<1>{});
-    stage(IC<1>{}, t + 1, nb);
-    pre();
-    mma(IC<0>{}, IC<1>{});
-    post();
-    // P3: (a1, b1)
+    STAMP(4);
+    // phase B: rows 64..127; DMA: A-a0, B-b0, B-b1 of K-tile t+2
+    ph_ = 1;
+    STAMP(0);
     read_a(cb, IC<1>{});
-    stage(IC<0>{}, t + 2, cb);
-    pre();
-    mma(IC<1>{}, IC<1>{});
+    STAMP(1);
+    wait_vmcnt<2>();                       // A-a0, B-b0, B-b1 of K-tile t+1 (issued in phase B of K-tile t-1) have landed
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    STAMP(2);
+    mma(IC<1>{}, t + 2);
+    STAMP(3);
     post();
-    // P4: (a1, b0)
-    stage(IC<2>{}, t + 2, cb);
-    pre();
-    mma(IC<1>{}, IC<0>{});
-    post();
+    STAMP(4);
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();   // both halves execute the same number of barriers
   wait_vmcnt<0>();                              // dummy tail pieces must not outlive the workgroup's LDS allocation
@@ -345,7 +387,7 @@ bool gemm256_applicable(const GemmP& p) {
   if (p.taps != 1) return false;
   if (p.M % 256 || p.N % 256 || p.K % 64) return false;
   if (p.lda % 8 || p.ldb % 8) return false;
-  if (p.geglu == 1 && (p.geglu_group != 64 && p.geglu_group != 128)) return false;   // value | gate halves inside one wave's 64 columns
+  if (p.geglu == 1 && p.geglu_group != 64) return false;   // value | gate halves (32 + 32 columns) inside one wave's 64 columns
   if (p.geglu == 2 && p.geglu_group % 8) return false;
   // 32-bit buffer offsets
   const long abytes = 2 * (p.form == GEMM_TN ? (long)p.K * p.lda : (long)p.M * p.lda);
@@ -354,8 +396,28 @@ bool gemm256_applicable(const GemmP& p) {
   return true;
 }
 
-int launch_gemm256(const GemmP& p, hipStream_t st) {
-  ARG_CHECK(gemm256_applicable(p), "gemm256: problem %dx%dx%d (form %d) does not fit the 256x256 kernel", p.M, p.N, p.K, p.form);
+#if G256_DIAG & 16
+extern "C" int sdxl_debug_g256_stamps(unsigned long long* out) {   // diagnostics build only
+  HIP_CHECK_RET(hipDeviceSynchronize());
+  HIP_CHECK_RET(hipMemcpyFromSymbol(out, HIP_SYMBOL(g256_stamps), sizeof(unsigned long long) * 2 * 4 * 4 * 8));
+  return 0;
+}
+#endif
+
+int launch_gemm256(const GemmP& pin, hipStream_t st) {
+  ARG_CHECK(gemm256_applicable(pin), "gemm256: problem %dx%dx%d (form %d) does not fit the 256x256 kernel", pin.M, pin.N, pin.K, pin.form);
+  GemmP p = pin;
+  {   // px x (8/px) XCD grid over the (n, m) tile grid minimising the per-XCD operand footprint ~ N/px + M/py
+    const int gx = p.N / 256, gy = p.M / 256;
+    double best = 1e30;
+    p.xcd_px = 0;
+    for (int px = 1; px <= 8; px *= 2) {
+      const int py = 8 / px;
+      if (gx % px || gy % py) continue;
+      const double cost = (double)p.N / px + (double)p.M / py;
+      if (cost < best) { best = cost; p.xcd_px = px; }
+    }
+  }
   switch (p.form) {
     case GEMM_NT: return launch256<GEMM_NT, false>(p, st);
     case GEMM_NN: return launch256<GEMM_NN, false>(p, st);

@@ -62,7 +62,9 @@ void gemm_defaults(GemmP* p);
 int launch_gemm(const GemmP& p, hipStream_t st);
 // 256 x 256 tile, 8-phase kernel (gemm256.hip): M, N multiples of 256, K of 64, no 3x3 gather
 bool gemm256_applicable(const GemmP& p);
-void gemm_set_mode(int mode);   // 0: never, 1: where the 256 x 256 grid fills the chip, 2: wherever applicable
+void gemm_set_mode(int mode);   // bits 0-1: 0 never / 1 policy / 2 wherever applicable; bits 2..: force a 128-row configuration
+bool gemm_use256(int form, int M, int N, int K, int splitk);   // the policy of mode 1
+int gemm_pick_splitk(int M, int N, int taps, long red);        // split-K factor the wgrad launchers should request
 int launch_gemm256(const GemmP& p, hipStream_t st);
 // per-launch HIP-event timing of every GEMM launch between begin and end (end synchronises the device)
 int gemm_profile_begin();
