@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--no-optimizer", action="store_true", help="skip the (untimed) fused-optimizer measurement")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--profile-steps", type=int, default=1, help="extra steps with per-launch GEMM event timing")
+    ap.add_argument("--gemm-mode", type=int, default=None, help="A/B runs: sdxl_set_gemm_mode (0 = 128-row kernel only)")
     args = ap.parse_args()
 
     import sdxl_amd  # noqa: F401
@@ -134,6 +135,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    if args.gemm_mode is not None:
+        lib.check(lib.load().sdxl_set_gemm_mode(args.gemm_mode))
     net = NU.NativeUNet(NU.make_config(), device=local_rank)
     synth.load_synthetic(net, seed=0)                      # same weights on every rank
     net.plan(wl["B"], wl["H"], wl["W"], 77)

@@ -783,28 +783,32 @@ int gemm_profile_end(double* flops, double* ms, int* launches) {
   if (launches) *launches = (int)g_prof.flops.size();
   return 0;
 }
-// Selection between the two kernels (measured on MI355X, profiles/r02*_gemm_bench.txt).  The 256 x 256 kernel runs one
-// workgroup per CU, so what counts is how well its tiles fill rounds of 256 CUs and how many K-tiles amortise its ~12 us of
-// unoverlapped prologue + epilogue per tile (with 2-3 workgroups per CU the 128-row kernel overlaps those by itself):
-//   wgrad (TN, reduction over 4096+ rows): +25..35 % wherever tiles x splits reaches ~3/4 of a round;
-//   forward / dgrad: only where the tiles fill their rounds (>= 90 %): 4096x3840x1280 (240 tiles) +5..20 %,
-//   16384x5120x640 (5 rounds) +12 %; 640 tiles (2.5 rounds) or 320 tiles lose to the 128-row kernel.
+// Selection between the two kernels (measured on MI355X, profiles/r02b_gemm_bench.txt, r02c_g256_insitu.txt).  The 256 x 256
+// kernel runs one 128 KiB-LDS workgroup per CU, so what counts is how well its tiles fill rounds of 256 CUs and how many
+// K-tiles amortise its ~12 us of unoverlapped prologue + epilogue per tile (with 2-3 workgroups per CU the 128-row kernel
+// overlaps those by itself).  In isolation: wgrad (TN, reduction over 4096+ rows) +25..35 % wherever tiles x splits reaches
+// ~3/4 of a round; forward / dgrad only where the tiles fill their rounds (>= 90 %): 4096x3840x1280 (240 tiles) +5..20 %,
+// 16384x5120x640 (5 rounds) +12 %; 640 tiles (2.5 rounds) or 320 tiles lose to the 128-row kernel.
+// In the training step the backward runs wgrad (side stream) and dgrad / attention / norms (caller's stream) CONCURRENTLY,
+// and that overlap lives on LDS co-residency (two 65 KiB workgroups per CU): a 128 KiB workgroup on either stream evicts the
+// other stream from its CU -- with the wgrads on the 256 x 256 kernel the GEMM family itself got 3.4 ms faster and the step
+// 1.7 ms slower.  Policy: the 256 x 256 kernel in the forward pass only (NT form; nothing else competes for the CUs there).
 bool gemm_use256(int form, int M, int N, int K, int splitk) {
   if (M % 256 || N % 256 || K % 64) return false;
-  const long wgs = (long)(M / 256) * (N / 256) * (form == GEMM_TN ? splitk : 1);
+  if (form != GEMM_NT) return false;
+  const long wgs = (long)(M / 256) * (N / 256);
   const double fill = (double)wgs / (double)(((wgs + 255) / 256) * 256);
-  if (form == GEMM_TN) return wgs >= 160 && (fill >= 0.75 || wgs >= 1024) && K / 64 / splitk >= 8;
   return wgs >= 192 && (fill >= 0.9 || wgs >= 1024);
 }
 // split-K factor of a wgrad GEMM [M][N*taps] (+)= A^T . B over `red` rows
 int gemm_pick_splitk(int M, int N, int taps, long red) {
-  if (taps == 1 && g_mode256 && M % 256 == 0 && N % 256 == 0 && red % 64 == 0) {   // one round of 256 x 256 tiles
+  if (taps == 1 && g_mode256 == 2 && M % 256 == 0 && N % 256 == 0 && red % 64 == 0) {   // forced 256 x 256 kernel: one round of tiles
     const long t256 = (long)(M / 256) * (N / 256);
     if (t256 >= 48) {
       long s = (224 + t256 / 2) / t256;
       if (s < 1) s = 1;
       while (s > 1 && red / 64 / s < 8) --s;
-      if (gemm_use256(GEMM_TN, M, N, (int)red, (int)s)) return (int)s;
+      return (int)s;
     }
   }
   // 128-row kernel: enough workgroups to fill 256 CUs x 2 (tiles x splits ~ 384), at least 8 K-steps per split

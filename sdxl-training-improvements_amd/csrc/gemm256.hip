@@ -6,7 +6,7 @@
 // 128 x 64 wave tile needs 0.375 LDS fragment reads per MFMA instead of 0.5, so the LDS read phase of one wave group
 // fits inside the MFMA phase of the other.
 //
-// Structure (per workgroup, one per CU, 129 KiB LDS):
+// Structure (per workgroup, one per CU, 128 KiB LDS):
 //   * the A tile [256][64] and B tile [256][64] of a K-step live in LDS as four 16 KiB REGIONS: A-a0 / A-a1 (the first /
 //     second 64 rows of both wave rows), B-b0 / B-b1 (the first / second 32 columns of all four wave columns); two
 //     buffers (even / odd K-tile).
@@ -38,8 +38,7 @@ namespace {
 
 constexpr int REGION = 16384;          // 128 rows x 128 B (K-contiguous)  or  64 k-rows x 256 B (N-contiguous)
 constexpr int BUFB = 4 * REGION;       // A-a0, A-a1, B-b0, B-b1
-constexpr int PAD_OFF = 2 * BUFB;      // 1 KiB: destination of the tail's dummy pieces
-constexpr int SMEM256 = 2 * BUFB + 1024;
+constexpr int SMEM256 = 2 * BUFB;      // 128 KiB
 constexpr unsigned OOB = 0x80000000u;  // per-lane offset beyond num_records: the load returns zeros
 
 template <int N>
@@ -102,8 +101,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmP p) {
     voB = B_KC ? (unsigned)(kc_row * ldb + kc_vec * 8) * 2u : (unsigned)(nc_row * ldb + 64 * (c >> 5) + (c & 31)) * 2u;
   }
   // piece h (0 / 1) of this wave's share of region R (0: A-a0, 1: A-a1, 2: B-b0, 3: B-b1) of K-tile `tile` (relative to
-  // kt_begin) -> buffer buf.  Tiles beyond the range become dummy loads (zeros into the pad) so that the vmcnt arithmetic
-  // stays uniform.
+  // kt_begin) -> buffer buf.  Tiles beyond the range become dummy loads (out-of-range offset: zeros, no memory traffic) so
+  // that the vmcnt arithmetic stays uniform.
   auto piece = [&](auto REG, int h, int tile, int buf) {
     constexpr int R = decltype(REG)::v;
     constexpr int ab = R & 1;
@@ -114,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmP p) {
     int so;
     if (R < 2) so = A_KC ? (m0 + 128 * h + 64 * ab + 8 * wave) * lda + k0 : (k0 + 4 * q) * lda + m0 + 64 * ab;
     else so = B_KC ? (n0 + cbase(2 * h + (wave >> 2), ab) + 8 * (wave & 3)) * ldb + k0 : (k0 + 4 * q) * ldb + n0 + 32 * ab;
-    char* dst = live ? smem + buf * BUFB + R * REGION + q * 1024 : smem + PAD_OFF;
+    char* dst = smem + buf * BUFB + R * REGION + q * 1024;   // (a dummy piece overwrites a region no K-tile will read again)
     const unsigned vo = live ? (R < 2 ? voA : voB) : OOB;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(R < 2 ? ra : rb, (lds_void*)dst, 16, (int)vo, live ? so * 2 : 0, 0, 0);
   };
