@@ -1,8 +1,17 @@
-import gzip,collections,sys
+"""Stream busy / gap analysis of one training step from a rocprofv3 --kernel-trace (raw *_kernel_trace.csv or the
+compact .csv.gz written by trace.sh): python profiles/tools/timeline.py <trace>"""
+import gzip,collections,sys,csv
 rows=[]
-for line in gzip.open(sys.argv[1] if len(sys.argv)>1 else 'gpurun_out/trace/compact.csv.gz','rt'):
-    s,e,q,st,name=line.rstrip('\n').split(',',4)
-    rows.append((int(s),int(e),q,name))
+path=sys.argv[1] if len(sys.argv)>1 else 'gpurun_out/trace/compact.csv.gz'
+if path.endswith('.gz'):
+    for line in gzip.open(path,'rt'):
+        s,e,q,st,name=line.rstrip('\n').split(',',4)
+        rows.append((int(s),int(e),q,name))
+else:
+    for r in csv.DictReader(open(path)):
+        rows.append((int(r['Start_Timestamp']),int(r['End_Timestamp']),str(r['Queue_Id']),r['Kernel_Name'][:60].replace(',',';')))
+mainq=collections.Counter(r[2] for r in rows if 'loss_prepare' in r[3]).most_common(1)[0][0]   # the caller's stream
+rows=[(a,b,'2' if q==mainq else 'x',n) for a,b,q,n in rows]
 rows.sort()
 lp=[i for i,r in enumerate(rows) if 'loss_prepare' in r[3]]
 lb=[i for i,r in enumerate(rows) if 'loss_bwd' in r[3]]

@@ -283,10 +283,9 @@ struct LayerNormOp : Op {
   }
   void plan_bwd(Plan& p) override { dy_off = y->goff; dx = p.grad_dst(x); }
   int bwd(Plan& p, hipStream_t st, bool) override {
-    // dgamma / dbeta column sums (moving them to the side stream was measured: no gain)
-    CHK(launch_layernorm_bwd_params(p.P(x), p.GP(dy_off), p.F(stats_off), p.eng->Gp(gm), p.eng->Gp(bt), (int)x->rows, C, st));
-    return launch_layernorm_bwd_dx(p.P(x), p.GP(dy_off), p.eng->Wp(gm), p.F(stats_off), p.GP(dx.out), p.GP(dx.addend),
-                                   (int)x->rows, C, st);
+    // dx and the dgamma / dbeta column sums in one pass (norm.hip)
+    return launch_layernorm_bwd(p.P(x), p.GP(dy_off), p.eng->Wp(gm), p.F(stats_off), p.GP(dx.out), p.GP(dx.addend),
+                                p.eng->Gp(gm), p.eng->Gp(bt), (int)x->rows, C, st);
   }
 };
 

@@ -29,13 +29,15 @@ static int g_mode256 = 1;     // 0: 128-row kernel only, 1: selection policy (ge
 static int g_force_cfg = 0;   // > 0: force that configuration of the 128-row kernel (microbenchmarks; sdxl_set_gemm_mode)
 
 static constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
-static constexpr int gemm_smem_bytes(int BN, int S, int BK) {
-  int ring = S * (BM + BN) * BK * 2 + 1024, stg = 64 * (BN + 4) * 4;
+static constexpr int gemm_smem_bytes(int BN, int S, int BK, int NW = 4) {
+  // + 1 KiB that absorbs the padding DMA pieces, where the tiles' 1 KiB chunks do not divide evenly among the waves
+  const bool pad = ((BM * BK * 2 / 1024) % NW) != 0 || ((BN * BK * 2 / 1024) % NW) != 0;
+  int ring = S * (BM + BN) * BK * 2 + (pad ? 1024 : 0), stg = BK == 32 ? 0 : 64 * (BN + 4) * 4;   // (GEGLU staging: BK 64 only)
   return ring > stg ? ring : stg;
 }
 // workgroups per CU the register budget is sized for: what the 160 KiB of LDS admits, at most 3 (4-wave) / 1 (8-wave)
 static constexpr int gemm_occupancy(int BN, int S, int BK, int NW) {
-  int byl = (160 * 1024) / gemm_smem_bytes(BN, S, BK);
+  int byl = (160 * 1024) / gemm_smem_bytes(BN, S, BK, NW);
   return NW == 8 ? 1 : (byl > 3 ? 3 : (byl < 1 ? 1 : byl));
 }
 
@@ -679,7 +681,7 @@ void gemm_defaults(GemmP* p) {
 template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW>
 static int launch_k(const GemmP& p, hipStream_t st) {
   static bool attr_set = false;
-  constexpr int smem = gemm_smem_bytes(BN, S, BK);
+  constexpr int smem = gemm_smem_bytes(BN, S, BK, NW);
   if (!attr_set) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -735,6 +737,7 @@ static int launch_one(const GemmP& p, hipStream_t st) {
   if (p.geglu && !g80 && (cfg == 3 || cfg == 13)) cfg = 1;   // group-64 packing needs 128-column tiles
   if (g80 && cfg != 3 && cfg != 13) cfg = 13;                // group-80 packing needs 160-column tiles
   if ((cfg == 3 || cfg == 13) && p.N % 160 != 0) cfg = 1;
+  if (p.geglu && cfg == 2) cfg = 1;                           // the BK = 32 configuration has no room for the GEGLU staging tile
   switch (cfg) {
     case 2: return launch_cfg<FORM, CONV, 128, 2, 32, 4>(p, st);
     case 3: return launch_cfg<FORM, CONV, 160, 4, 64, 8>(p, st);
@@ -792,7 +795,8 @@ int gemm_profile_end(double* flops, double* ms, int* launches) {
 // In the training step the backward runs wgrad (side stream) and dgrad / attention / norms (caller's stream) CONCURRENTLY,
 // and that overlap lives on LDS co-residency (two 65 KiB workgroups per CU): a 128 KiB workgroup on either stream evicts the
 // other stream from its CU -- with the wgrads on the 256 x 256 kernel the GEMM family itself got 3.4 ms faster and the step
-// 1.7 ms slower.  Policy: the 256 x 256 kernel in the forward pass only (NT form; nothing else competes for the CUs there).
+// 1.7-3 ms slower; shrinking the dgrad kernels to 32 KiB (BK = 32) so that they fit beside a 128 KiB workgroup: +7 ms.
+// Policy: the 256 x 256 kernel in the forward pass only (NT form; nothing else competes for the CUs there).
 bool gemm_use256(int form, int M, int N, int K, int splitk) {
   if (M % 256 || N % 256 || K % 64) return false;
   if (form != GEMM_NT) return false;

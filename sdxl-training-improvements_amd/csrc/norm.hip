@@ -418,47 +418,102 @@ int launch_layernorm_fwd(const bf16* x, bf16* y, const bf16* gamma, const bf16* 
   return 0;
 }
 
-// backward, dx: same geometry as forward (16 lanes per row), nothing carried between rows
-template <int NV, int LPR, bool ACC>
+// backward: dx (same geometry as forward, whole row in registers) and -- PARAMS -- the dgamma / dbeta column sums of the
+// rows this block handles, from the values it already holds (the separate column-sum pass re-read x and dy: 2.8 ms per
+// step).  A block walks ITER groups of 256 / LPR rows; per 8-column vector the per-row products are summed over the rows of
+// a wave with lane shuffles, over the 4 waves through LDS, and one fp32 atomicAdd per column and block goes to dgamma / dbeta
+// (these small-parameter gradients are accumulated with atomics everywhere and zeroed per cycle, sdxl_zero_grads).
+template <int NV, int LPR, bool ACC, bool PARAMS>
 __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                  const bf16* __restrict__ gamma, const float* __restrict__ stats,
-                                 bf16* dx, const bf16* addend, int M) {
+                                 bf16* dx, const bf16* addend, float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
+                                 int iters) {
   constexpr int C = NV * LPR * 8;
+  constexpr int RPB = 256 / LPR;                     // rows per block and iteration
+  __shared__ float red[PARAMS ? 4 : 1][2][PARAMS ? C : 8];
   const int sub = threadIdx.x & (LPR - 1);
-  const int row = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
-  if (row >= M) return;
-  const float mean = stats[(long)row * 2], rstd = stats[(long)row * 2 + 1];
-  bf16x8 v[NV], d[NV];
-  float s1 = 0.f, s2 = 0.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (PARAMS) {   // each wave accumulates into its own LDS slice (lanes 0 .. LPR-1 own fixed columns: no conflicts, no barrier)
+    if (lane < LPR) {
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    v[i] = *(const bf16x8*)(x + (long)row * C + (i * LPR + sub) * 8);
-    d[i] = *(const bf16x8*)(dy + (long)row * C + (i * LPR + sub) * 8);
-    bf16x8 gv = *(const bf16x8*)(gamma + (i * LPR + sub) * 8);
+      for (int i = 0; i < NV; ++i)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float h = ((float)v[i][e] - mean) * rstd;
-      float t = (float)d[i][e] * (float)gv[e];
-      s1 += t;
-      s2 += t * h;
+        for (int q = 0; q < 2; ++q) {
+          *(f32x4*)&red[wave][q][(i * LPR + sub) * 8] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          *(f32x4*)&red[wave][q][(i * LPR + sub) * 8 + 4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     }
   }
-  s1 = group_sum<LPR>(s1) * (1.f / C);
-  s2 = group_sum<LPR>(s2) * (1.f / C);
+  for (int it = 0; it < iters; ++it) {
+    const int row = (blockIdx.x * iters + it) * RPB + threadIdx.x / LPR;
+    const bool ok = row < M;                      // (rows beyond M contribute zeros; the wave stays converged for the shuffles)
+    const long ro = ok ? (long)row * C : 0;
+    const float mean = ok ? stats[(long)row * 2] : 0.f, rstd = ok ? stats[(long)row * 2 + 1] : 0.f;
+    bf16x8 v[NV], d[NV];
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    bf16x8 gv = *(const bf16x8*)(gamma + (i * LPR + sub) * 8);
-    bf16x8 o;
-    if (ACC) o = *(const bf16x8*)(addend + (long)row * C + (i * LPR + sub) * 8);
+    for (int i = 0; i < NV; ++i) {
+      v[i] = *(const bf16x8*)(x + ro + (i * LPR + sub) * 8);
+      d[i] = *(const bf16x8*)(dy + ro + (i * LPR + sub) * 8);
+      if (!ok) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float h = ((float)v[i][e] - mean) * rstd;
-      float t = (float)d[i][e] * (float)gv[e];
-      float g = rstd * (t - s1 - h * s2);
-      if (ACC) g += (float)o[e];
-      o[e] = (bf16)g;
+        for (int e = 0; e < 8; ++e) d[i][e] = (bf16)0.f;
+      }
+      bf16x8 gv = *(const bf16x8*)(gamma + (i * LPR + sub) * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float h = ((float)v[i][e] - mean) * rstd;
+        float t = (float)d[i][e] * (float)gv[e];
+        s1 += t;
+        s2 += t * h;
+      }
     }
-    *(bf16x8*)(dx + (long)row * C + (i * LPR + sub) * 8) = o;
+    s1 = group_sum<LPR>(s1) * (1.f / C);
+    s2 = group_sum<LPR>(s2) * (1.f / C);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      bf16x8 gv = *(const bf16x8*)(gamma + (i * LPR + sub) * 8);
+      bf16x8 o;
+      if (ACC) o = *(const bf16x8*)(addend + ro + (i * LPR + sub) * 8);
+      float pg[8], pb[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float h = ((float)v[i][e] - mean) * rstd;
+        float t = (float)d[i][e] * (float)gv[e];
+        float g = rstd * (t - s1 - h * s2);
+        if (ACC) g += (float)o[e];
+        o[e] = (bf16)g;
+        pg[e] = (float)d[i][e] * h;
+        pb[e] = (float)d[i][e];
+      }
+      if (ok) *(bf16x8*)(dx + ro + (i * LPR + sub) * 8) = o;
+      if (PARAMS) {   // the rows of this wave (64 / LPR) -> lanes 0 .. LPR-1 -> the wave's LDS accumulators
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+          for (int off = LPR; off < 64; off <<= 1) {
+            pg[e] += __shfl_xor(pg[e], off, 64);
+            pb[e] += __shfl_xor(pb[e], off, 64);
+          }
+        }
+        if (lane < LPR) {
+          float* rg = &red[wave][0][(i * LPR + sub) * 8];
+          float* rb = &red[wave][1][(i * LPR + sub) * 8];
+          f32x4 a0 = *(f32x4*)rg, a1 = *(f32x4*)(rg + 4), b0 = *(f32x4*)rb, b1 = *(f32x4*)(rb + 4);
+          a0[0] += pg[0]; a0[1] += pg[1]; a0[2] += pg[2]; a0[3] += pg[3];
+          a1[0] += pg[4]; a1[1] += pg[5]; a1[2] += pg[6]; a1[3] += pg[7];
+          b0[0] += pb[0]; b0[1] += pb[1]; b0[2] += pb[2]; b0[3] += pb[3];
+          b1[0] += pb[4]; b1[1] += pb[5]; b1[2] += pb[6]; b1[3] += pb[7];
+          *(f32x4*)rg = a0; *(f32x4*)(rg + 4) = a1; *(f32x4*)rb = b0; *(f32x4*)(rb + 4) = b1;
+        }
+      }
+    }
+  }
+  if (!PARAMS) return;
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dgamma + c, red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c]);
+    atomicAdd(dbeta + c, red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c]);
   }
 }
 
@@ -517,50 +572,64 @@ static void col_reduce_geom(int M, int C, dim3* grid, int* rows_per_chunk) {
   *grid = dim3(colblocks, cdiv(M, *rows_per_chunk));
 }
 
+static int ln_bwd_launch(const bf16* x, const bf16* dy, const bf16* gamma, const float* stats, bf16* dx, const bf16* addend,
+                         float* dgamma, float* dbeta, int M, int C, hipStream_t st) {
+  ARG_CHECK(C % 128 == 0, "layernorm bwd: C=%d must be a multiple of 128", C);
+  const bool accumulate = addend != nullptr, params = dgamma != nullptr;
+  ARG_CHECK(!params || dbeta, "layernorm bwd: dgamma and dbeta go together");
+  dim3 blk(256);
+  // with the column sums: several row groups per block (fewer atomics), keeping >= 256 blocks
+#define LN_LAUNCH(NV, LPR)                                                                                               \
+  {                                                                                                                      \
+    int iters = 1;                                                                                                       \
+    if (params) { iters = M / ((256 / LPR) * 256); iters = iters < 1 ? 1 : (iters > 4 ? 4 : iters); }                    \
+    dim3 grid(cdiv(M, (256 / LPR) * iters));                                                                             \
+    if (params) {                                                                                                        \
+      if (accumulate) hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, LPR, true, true>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, dgamma, dbeta, M, iters); \
+      else hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, LPR, false, true>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, dgamma, dbeta, M, iters);          \
+    } else {                                                                                                             \
+      if (accumulate) hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, LPR, true, false>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, dgamma, dbeta, M, iters); \
+      else hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, LPR, false, false>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, dgamma, dbeta, M, iters);          \
+    }                                                                                                                    \
+  }
+  if (C % 256 == 0 && C >= 1024) {
+    switch (C / 256) {
+      case 4: LN_LAUNCH(4, 32) break;
+      case 5: LN_LAUNCH(5, 32) break;
+      case 8: LN_LAUNCH(8, 32) break;
+      case 10: LN_LAUNCH(10, 32) break;
+      default: ARG_CHECK(false, "layernorm bwd: C=%d not instantiated", C);
+    }
+  } else {
+    switch (C / 128) {
+      case 1: LN_LAUNCH(1, 16) break;
+      case 2: LN_LAUNCH(2, 16) break;
+      case 3: LN_LAUNCH(3, 16) break;
+      case 4: LN_LAUNCH(4, 16) break;
+      case 5: LN_LAUNCH(5, 16) break;
+      case 6: LN_LAUNCH(6, 16) break;
+      case 7: LN_LAUNCH(7, 16) break;
+      default: ARG_CHECK(false, "layernorm bwd: C=%d not instantiated", C);
+    }
+  }
+#undef LN_LAUNCH
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+// dx and dgamma / dbeta (+=) in one pass over x and dy
 int launch_layernorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const float* stats, bf16* dx,
                          const bf16* addend, float* dgamma, float* dbeta, int M, int C, hipStream_t st) {
-  int rc = launch_layernorm_bwd_dx(x, dy, gamma, stats, dx, addend, M, C, st);
-  return rc ? rc : launch_layernorm_bwd_params(x, dy, stats, dgamma, dbeta, M, C, st);
+  return ln_bwd_launch(x, dy, gamma, stats, dx, addend, dgamma, dbeta, M, C, st);
+}
+int launch_layernorm_bwd_dx(const bf16* x, const bf16* dy, const bf16* gamma, const float* stats, bf16* dx,
+                            const bf16* addend, int M, int C, hipStream_t st) {
+  return ln_bwd_launch(x, dy, gamma, stats, dx, addend, nullptr, nullptr, M, C, st);
 }
 int launch_layernorm_bwd_params(const bf16* x, const bf16* dy, const float* stats, float* dgamma, float* dbeta, int M,
                                 int C, hipStream_t st) {
   dim3 g2; int rpc;
   col_reduce_geom(M, C, &g2, &rpc);
   hipLaunchKernelGGL(col_reduce_kernel, g2, dim3(256), 0, st, x, dy, (long)C, stats, dgamma, dbeta, M, C, rpc);
-  HIP_CHECK_RET(hipGetLastError());
-  return 0;
-}
-int launch_layernorm_bwd_dx(const bf16* x, const bf16* dy, const bf16* gamma, const float* stats, bf16* dx,
-                            const bf16* addend, int M, int C, hipStream_t st) {
-  ARG_CHECK(C % 128 == 0, "layernorm bwd: C=%d must be a multiple of 128", C);
-  const int accumulate = addend != nullptr;
-  dim3 blk(256);
-#define LN_LAUNCH(NV, LPR, grid)                                                                                        \
-  if (accumulate) hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, LPR, true>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, M); \
-  else hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, LPR, false>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, M);
-  if (C % 256 == 0 && C >= 1024) {
-    dim3 grid(cdiv(M, 8));
-    switch (C / 256) {
-      case 4: { LN_LAUNCH(4, 32, grid) } break;
-      case 5: { LN_LAUNCH(5, 32, grid) } break;
-      case 8: { LN_LAUNCH(8, 32, grid) } break;
-      case 10: { LN_LAUNCH(10, 32, grid) } break;
-      default: ARG_CHECK(false, "layernorm bwd: C=%d not instantiated", C);
-    }
-  } else {
-    dim3 grid(cdiv(M, 16));
-    switch (C / 128) {
-      case 1: { LN_LAUNCH(1, 16, grid) } break;
-      case 2: { LN_LAUNCH(2, 16, grid) } break;
-      case 3: { LN_LAUNCH(3, 16, grid) } break;
-      case 4: { LN_LAUNCH(4, 16, grid) } break;
-      case 5: { LN_LAUNCH(5, 16, grid) } break;
-      case 6: { LN_LAUNCH(6, 16, grid) } break;
-      case 7: { LN_LAUNCH(7, 16, grid) } break;
-      default: ARG_CHECK(false, "layernorm bwd: C=%d not instantiated", C);
-    }
-  }
-#undef LN_LAUNCH
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
