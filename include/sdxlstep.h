@@ -184,6 +184,9 @@ typedef struct {
                                   0: the documented EMA m <- SR(beta1*m + (1-beta1)*g) */
   int grad_round_bf16;         /* 1: round the scaled gradient to bf16 first (the reference's gradients are bf16) */
   unsigned long long seed;
+  unsigned long long elem_offset; /* arena index of element 0 of this call (multiple of 8).  The stochastic-rounding counters are
+                                   * (seed, step, arena index), so updating a sub-range [elem_offset, elem_offset + n) of the arena
+                                   * (one rank's ZeRO-1 shard) gives exactly the bits of the full-arena update. */
 } sdxl_adamw_config;
 int sdxl_adamw_default_config(sdxl_adamw_config* c);   /* lr 1e-4, betas (0.9, 0.999), eps 1e-8, reference_ema 1 */
 int sdxl_adamw_bf16_step(void* p, const void* grad, int grad_dtype, void* m, void* v, void* shift, size_t n,

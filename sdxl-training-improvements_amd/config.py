@@ -32,6 +32,9 @@ class OptimizerConfig:                   # data/config.py:42-49
     beta2: float = 0.999
     epsilon: float = 1e-8
     optimizer_type: str = "adamw_bf16"
+    reference_ema: bool = True           # build-only key: True = the reference's actual first-moment update (its
+                                         # add_stochastic_ operand order, SURVEY D17: almost no momentum), False = the
+                                         # documented EMA; see optimizer.py::AdamWBF16
 
 
 @dataclass
@@ -45,6 +48,8 @@ class TrainingConfig:                    # data/config.py:152-168
     prediction_type: str = "v_prediction"
     clip_grad_norm: float = 1.0
     num_workers: int = 4
+    shard_optimizer: bool = True         # build-only key: data parallel = ZeRO-1 (reduce-scatter -> sharded fused AdamW ->
+                                         # all-gather) instead of all-reduce + a full update on every rank
 
 
 @dataclass

@@ -615,6 +615,7 @@ int sdxl_adamw_bf16_step(void* p, const void* grad, int grad_dtype, void* m, voi
   q.rand = rand_inject;
   q.seed_lo = (unsigned)c->seed; q.seed_hi = (unsigned)(c->seed >> 32);
   q.step_counter = (unsigned)c->step;
+  q.elem_offset = (size_t)c->elem_offset;
   return launch_adamw_bf16(q, (hipStream_t)st);
 }
 int sdxl_adamw_decay(void* shift, const void* p, size_t n, float decay, void* st) {

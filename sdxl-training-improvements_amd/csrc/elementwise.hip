@@ -216,9 +216,14 @@ int launch_bf16_to_f32(const bf16* x, float* y, long n, hipStream_t st) {
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-// sum of squares of an fp32 or bf16 array (gradient norm): 16-byte vectors, wave reduction, one atomic per wave
+// sum of squares of an fp32 or bf16 array (gradient norm): 16-byte vectors; fixed summation order (per-thread stride loop ->
+// wave shuffle tree -> waves of a block in order -> one partial per block -> a second single-block pass over the partials in
+// index order), so the norm and the clip coefficient derived from it are bit-reproducible run to run and rank to rank.
+#define SUMSQ_MAX_BLOCKS 4096
+__device__ float g_sumsq_partials[SUMSQ_MAX_BLOCKS];   // scratch of the (stream-ordered) two-pass reduction
 template <typename T>
-__global__ void sumsq_kernel(const T* __restrict__ x, long n, float* __restrict__ out) {
+__global__ __launch_bounds__(EW_BLOCK) void sumsq_kernel(const T* __restrict__ x, long n) {
+  __shared__ float wsum[EW_BLOCK / 64];
   constexpr int V = 16 / sizeof(T);
   float s = 0.f;
   const long nv = n / V;
@@ -234,18 +239,35 @@ __global__ void sumsq_kernel(const T* __restrict__ x, long n, float* __restrict_
   }
   if (blockIdx.x == 0 && threadIdx.x < n - nv * V) { const float t = (float)x[nv * V + threadIdx.x]; s += t * t; }
   s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < EW_BLOCK / 64; ++w) t += wsum[w];
+    g_sumsq_partials[blockIdx.x] = t;
+  }
 }
-int launch_sumsq_f32(const float* x, long n, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(sumsq_kernel<float>, dim3(ew_grid(n / 4 + 1)), dim3(EW_BLOCK), 0, st, x, n, out);
+__global__ __launch_bounds__(256) void sumsq_final_kernel(int nblocks, float* __restrict__ out) {
+  __shared__ float wsum[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) s += g_sumsq_partials[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out += (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+template <typename T>
+static int sumsq_launch(const T* x, long n, float* out, hipStream_t st) {
+  int g = ew_grid(n / (16 / (long)sizeof(T)) + 1);
+  if (g > SUMSQ_MAX_BLOCKS) g = SUMSQ_MAX_BLOCKS;
+  hipLaunchKernelGGL(sumsq_kernel<T>, dim3(g), dim3(EW_BLOCK), 0, st, x, n);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, g, out);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-int launch_sumsq_bf16(const bf16* x, long n, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(sumsq_kernel<bf16>, dim3(ew_grid(n / 8 + 1)), dim3(EW_BLOCK), 0, st, x, n, out);
-  HIP_CHECK_RET(hipGetLastError());
-  return 0;
-}
+int launch_sumsq_f32(const float* x, long n, float* out, hipStream_t st) { return sumsq_launch(x, n, out, st); }
+int launch_sumsq_bf16(const bf16* x, long n, float* out, hipStream_t st) { return sumsq_launch(x, n, out, st); }
 // torch.nn.utils.clip_grad_norm_'s coefficient from the squared norm, on the device (no host round trip):
 // coef = min(1, max_norm / (sqrt(sumsq) + 1e-6))
 __global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* coef) {

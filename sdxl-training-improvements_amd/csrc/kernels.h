@@ -187,6 +187,8 @@ struct AdamWP {
   const float* grad_scale;     // device scalar multiplied into the gradient (unscale / clip), or nullptr
   const unsigned short* rand;  // [4][n] injected random 16-bit integers (parity tests), or nullptr = Philox
   unsigned seed_lo, seed_hi, step_counter;
+  size_t elem_offset;          // arena index of element 0 of this launch (multiple of 8): the Philox counters are those of the
+                               // full-arena launch, so a sharded (ZeRO-1) update is bit-identical to the unsharded one
 };
 int launch_adamw_bf16(const AdamWP& q, hipStream_t st);
 int launch_adamw_decay(bf16* shift, const bf16* p, size_t n, float alpha_bf16, hipStream_t st);

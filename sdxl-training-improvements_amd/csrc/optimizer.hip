@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void adamw_bf16_kernel(const AdamWP q) {
     if (!INJECT) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const size_t pair = i * 4 + k;
+        const size_t pair = q.elem_offset / 2 + i * 4 + k;
         philox4x32_7((unsigned)pair, (unsigned)(pair >> 32), q.step_counter, 0x5D71A3B1u, q.seed_lo, q.seed_hi, rnd[k]);
       }
     }
@@ -117,7 +117,7 @@ __global__ void adamw_decay_kernel(bf16* shift, const bf16* p, size_t n, float a
 
 int launch_adamw_bf16(const AdamWP& q, hipStream_t st) {
   ARG_CHECK(q.p && q.m && q.v && q.shift && (q.grad_f32 || q.grad_bf16), "adamw: missing buffers");
-  ARG_CHECK(q.n % 8 == 0, "adamw: n=%zu must be a multiple of 8", q.n);
+  ARG_CHECK(q.n % 8 == 0 && q.elem_offset % 8 == 0, "adamw: n=%zu, elem_offset=%zu: each must be a multiple of 8", q.n, q.elem_offset);
   ARG_CHECK((((uintptr_t)q.p | (uintptr_t)q.m | (uintptr_t)q.v | (uintptr_t)q.shift | (uintptr_t)q.grad_f32 | (uintptr_t)q.grad_bf16) & 15) == 0,
             "adamw: buffers must be 16-byte aligned");
   if (q.n == 0) return 0;

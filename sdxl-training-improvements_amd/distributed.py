@@ -6,6 +6,12 @@ as a segment's kernels are enqueued its fp32 gradients are cast to bf16 (pre-sca
 gradients are bf16 too) and all-reduced asynchronously, so the exchange of the 5.1 GB of UNet gradients runs under
 the remaining backward.  Buckets of ~190 MB keep RCCL in its bandwidth regime on the 7-link xGMI mesh.
 With gradient accumulation the exchange happens on the last micro-step only.
+
+ShardedGradSync (row f3, ZeRO-1) is the same bucketing with REDUCE-SCATTER instead of all-reduce: rank r keeps slice r of
+every bucket, computes the squared norm of its slices (one float all-reduced -> the clip coefficient is identical on all
+ranks by construction), runs the fused AdamW only on its slices (1/world of the 51 GB optimizer traffic) and the updated
+parameters are all-gathered bucket by bucket.  On the point-to-point xGMI mesh reduce-scatter + all-gather move the same
+bytes as the all-reduce they replace, without the redundant full-arena update and norm on every rank.
 """
 from __future__ import annotations
 
@@ -92,3 +98,76 @@ class GradSync:
     def reduced(self) -> Optional[torch.Tensor]:
         """The averaged gradients (bf16 arena layout) after finish(); None at world size 1."""
         return self.comm
+
+
+def _via_host(fn, out: torch.Tensor, inp: torch.Tensor, **kw):
+    """gloo has no device-side reduce-scatter / all-gather: the CPU tests and the one-GPU control-flow test stage through host
+    memory (synchronously); RCCL (backend "nccl") takes the tensors as they are."""
+    if dist.get_backend(kw.get("group")) == "gloo" and out.is_cuda:
+        o, i = out.cpu(), inp.cpu()
+        fn(o, i, **{k: v for k, v in kw.items() if k != "async_op"})
+        out.copy_(o)
+        return None
+    return fn(out, inp, **kw)
+
+
+class ShardedGradSync(GradSync):
+    """Bucketed, overlapped REDUCE-SCATTER of the gradient arena + all-gather of the updated parameters (ZeRO-1).
+
+    Every bucket (= backward segment, sizes multiples of 8 * world elements) is reduce-scattered as soon as its segment
+    is enqueued; this rank's slices land back to back in `gshard` (bf16, total / world elements)."""
+
+    def __init__(self, total_elems: int, cast, comm_dtype=torch.bfloat16, device="cuda", group=None):
+        super().__init__(total_elems, cast, comm_dtype, device, group)
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.gshard = torch.zeros((total_elems + self.world - 1) // self.world + 8, dtype=comm_dtype, device=device) \
+            if self.world > 1 else None
+        self.pieces: List = []          # (arena offset of this rank's slice, count, offset into gshard), in exchange order
+        self.buckets: List = []         # (arena offset, count) of every bucket
+        self._cursor = 0
+
+    def begin(self) -> None:
+        self.pieces.clear()
+        self.buckets.clear()
+        self._cursor = 0
+
+    def on_segment(self, k: int, offset: int, count: int) -> None:
+        if self.world < 2 or not self.enabled:
+            return
+        if k == 0:
+            self.begin()
+        if count % (8 * self.world):
+            raise ValueError(f"bucket of {count} elements does not split into {self.world} slices of whole 16-byte vectors")
+        n = count // self.world
+        buf = self.comm[offset:offset + count]
+        self.cast(offset, count, buf)
+        out = self.gshard[self._cursor:self._cursor + n]
+        w = _via_host(dist.reduce_scatter_tensor, out, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if w is not None:
+            self.pending.append(w)
+        self.pieces.append((offset + self.rank * n, n, self._cursor))
+        self.buckets.append((offset, count))
+        self._cursor += n
+
+    def reduced(self) -> Optional[torch.Tensor]:
+        """This rank's averaged gradient slices (bf16), `pieces` says where each lives in the arena."""
+        return None if self.world < 2 else self.gshard[:self._cursor]
+
+    def global_sumsq(self, local_sumsq: torch.Tensor) -> torch.Tensor:
+        """sum over ranks of the slices' squared norms: one float on the wire, the same bits on every rank."""
+        if self.world > 1:
+            dist.all_reduce(local_sumsq, op=dist.ReduceOp.SUM, group=self.group)
+        return local_sumsq
+
+    def gather_params(self, weights: torch.Tensor) -> None:
+        """all-gather the updated slices back into every rank's full weight arena, bucket by bucket."""
+        if self.world < 2:
+            return
+        works = []
+        for (off, cnt), (poff, n, _g) in zip(self.buckets, self.pieces):
+            mine = weights[poff:poff + n].clone()       # (in-place all-gather is an RCCL feature, not a gloo one)
+            w = _via_host(dist.all_gather_into_tensor, weights[off:off + cnt], mine, group=self.group, async_op=True)
+            if w is not None:
+                works.append(w)
+        for w in works:
+            w.wait()

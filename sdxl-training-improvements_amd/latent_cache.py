@@ -113,8 +113,12 @@ class BucketBatchSampler:
     """samplers.py:8-61, same batch construction and the same use of the `random` module for the shuffle."""
 
     def __init__(self, bucket_indices: Dict[Tuple[int, ...], List[int]], batch_size: int, drop_last: bool = True,
-                 shuffle: bool = True):
+                 shuffle: bool = True, seed: Optional[int] = None):
+        """seed None: `random.shuffle` on the process-global state, exactly as the reference (single process).  With a seed the
+        permutation of epoch e comes from a private random.Random(seed + e): every rank of a data-parallel job then draws the
+        SAME batch order (set_epoch advances it), which rank-strided sharding needs."""
         self.bucket_indices, self.batch_size, self.drop_last, self.shuffle = bucket_indices, batch_size, drop_last, shuffle
+        self.seed, self.epoch = seed, 0
         self.batches: List[List[int]] = []
         for _shape, indices in bucket_indices.items():
             if len(indices) < batch_size and drop_last:
@@ -126,9 +130,17 @@ class BucketBatchSampler:
         if not self.batches:
             raise ValueError("No valid batches created - check bucket sizes and batch size")
 
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = int(epoch)
+
     def __iter__(self) -> Iterator[List[int]]:
+        if self.shuffle and self.seed is None:
+            random.shuffle(self.batches)                       # reference behaviour (samplers.py:52-55)
+            return iter(self.batches)
         if self.shuffle:
-            random.shuffle(self.batches)
+            order = list(self.batches)                          # same starting order on every rank and epoch
+            random.Random(self.seed + self.epoch).shuffle(order)
+            return iter(order)
         return iter(self.batches)
 
     def __len__(self) -> int:
@@ -159,11 +171,20 @@ class CachedLatentLoader:
     (batch k goes to rank k mod world, so every rank sees same-bucket batches and the same number of steps)."""
 
     def __init__(self, cache: LatentCache, batch_size: int, items: Optional[Sequence[str]] = None, drop_last: bool = True,
-                 shuffle: bool = True, rank: int = 0, world: int = 1):
+                 shuffle: bool = True, rank: int = 0, world: int = 1, seed: Optional[int] = None):
+        """world > 1 needs the same permutation on every rank: a seed is then mandatory in effect -- seed None falls back to 0
+        (never to the per-process global `random` state, which differs between torchrun processes); world == 1 with seed None
+        keeps the reference's global-`random` shuffle."""
         self.cache = cache
         self.items = list(items) if items is not None else cache.keys()
-        self.sampler = BucketBatchSampler(cache.bucket_indices(self.items), batch_size, drop_last, shuffle)
+        if world > 1 and seed is None:
+            seed = 0
+        self.sampler = BucketBatchSampler(cache.bucket_indices(self.items), batch_size, drop_last, shuffle, seed=seed)
         self.rank, self.world = rank, world
+
+    def set_epoch(self, epoch: int) -> None:
+        """new permutation for the next pass (call once per epoch on every rank, like DistributedSampler.set_epoch)"""
+        self.sampler.set_epoch(epoch)
 
     def __len__(self) -> int:
         return len(self.sampler) // self.world

@@ -36,7 +36,7 @@ class Batch(C.Structure):
 class AdamWConfig(C.Structure):
     _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
                 ("step", C.c_double), ("decay_this_iteration", C.c_double), ("reference_ema", C.c_int),
-                ("grad_round_bf16", C.c_int), ("seed", C.c_ulonglong)]
+                ("grad_round_bf16", C.c_int), ("seed", C.c_ulonglong), ("elem_offset", C.c_ulonglong)]
 
 
 _vp, _i, _f, _l, _sz = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t

@@ -27,6 +27,10 @@ class AdamWBF16:
 
     def __init__(self, net, *, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, reference_ema: bool = True,
                  grad_round_bf16: bool = False, seed: int = 0):
+        """reference_ema (config key optimizer.reference_ema, default True): True reproduces the reference's ACTUAL first
+        moment, m <- SR(g + (1-beta1) * beta1 * m) -- `add_stochastic_(_input, other, alpha)` computes other + alpha*_input
+        (stochastic/__init__.py:96), i.e. almost no momentum; False selects the documented EMA
+        m <- SR(beta1 * m + (1-beta1) * g)."""
         if not 0.0 <= eps:
             raise ValueError(f"Invalid epsilon value: {eps}")
         if not 0.0 <= betas[0] < 1.0:
@@ -51,6 +55,11 @@ class AdamWBF16:
         # each tensor starts its decay account at a random phase so that they do not all pay at once (:116-119)
         g = torch.Generator().manual_seed(self.seed)
         self.accumulated_decay = {k: float(torch.rand([], generator=g) * self.decay_threshold) for k in self.ranges}
+        self._post_step_hooks = []
+
+    def register_step_post_hook(self, fn) -> None:
+        """fn(optimizer) after every step() (same idea as torch.optim.Optimizer.register_step_post_hook)."""
+        self._post_step_hooks.append(fn)
 
     # ------------------------------------------------------------------ reference surface
     def zero_grad(self, set_to_none: bool = False) -> None:
@@ -71,15 +80,18 @@ class AdamWBF16:
 
     @torch.no_grad()
     def step(self, grads: Optional[torch.Tensor] = None, grad_scale: Optional[torch.Tensor] = None,
-             zero_grad: bool = False, _rand: Optional[torch.Tensor] = None) -> None:
+             zero_grad: bool = False, _rand: Optional[torch.Tensor] = None, pieces=None) -> None:
         """One update of every parameter.  grads: None = the net's fp32 gradient arena, or a bf16 / fp32 tensor in
         arena layout (the all-reduced bf16 gradients under data parallelism).  grad_scale: optional 1-element device
-        tensor multiplied into the gradient inside the kernel (clip coefficient, 1/accumulation)."""
+        tensor multiplied into the gradient inside the kernel (clip coefficient, 1/accumulation).
+        pieces (ZeRO-1, distributed.ShardedGradSync.pieces): [(arena offset, count, offset into `grads`)] -- only those
+        ranges of the arenas are updated, `grads` then holds just this rank's reduce-scattered shard; the stochastic-rounding
+        counters are keyed by arena index, so the union over ranks is bit-identical to the unsharded update."""
         if self.L is None:
             raise lib.SdxlError("AdamWBF16.step needs libsdxlstep.so (there is no PyTorch fallback for the optimizer step)")
         grp = self.param_groups[0]
         g = self.net.grads if grads is None else grads
-        if g.dtype not in (torch.float32, torch.bfloat16) or g.numel() != self.net.weights.numel():
+        if g.dtype not in (torch.float32, torch.bfloat16) or (pieces is None and g.numel() != self.net.weights.numel()):
             raise ValueError("grads must be an fp32 or bf16 tensor in arena layout")
         self.step_count += 1
         lr, wd = float(grp["lr"]), float(grp["weight_decay"])
@@ -98,14 +110,24 @@ class AdamWBF16:
         cfg.reference_ema = int(self.reference_ema)
         cfg.grad_round_bf16 = int(self.grad_round_bf16)
         cfg.seed = self.seed
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        n = self.net.weights.numel()
-        lib.check(self.L.sdxl_adamw_bf16_step(_ptr(self.net.weights), _ptr(g), 0 if g.dtype == torch.float32 else 1,
-                                              _ptr(self.exp_avg), _ptr(self.exp_avg_sq), _ptr(self.shift), n,
-                                              C.byref(cfg), _ptr(grad_scale), _ptr(_rand), st), "sdxl_adamw_bf16_step")
-        for k, d in due:                                       # :191-193 `shift.add_(p, alpha=-decay)`
-            off, cnt = self.ranges[k]
-            lib.check(self.L.sdxl_adamw_decay(C.c_void_p(self.shift.data_ptr() + 2 * off),
-                                              C.c_void_p(self.net.weights.data_ptr() + 2 * off), cnt, d, st), "sdxl_adamw_decay")
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream) if self.net.weights.is_cuda else None
+        gsz = g.element_size()
+        todo = [(0, self.net.weights.numel(), 0)] if pieces is None else list(pieces)
+        for off, cnt, goff in todo:
+            cfg.elem_offset = off
+            at = lambda t, o=off: C.c_void_p(t.data_ptr() + 2 * o)
+            lib.check(self.L.sdxl_adamw_bf16_step(at(self.net.weights), C.c_void_p(g.data_ptr() + gsz * goff),
+                                                  0 if g.dtype == torch.float32 else 1, at(self.exp_avg), at(self.exp_avg_sq),
+                                                  at(self.shift), cnt, C.byref(cfg), _ptr(grad_scale), _ptr(_rand), st),
+                      "sdxl_adamw_bf16_step")
+        for k, d in due:                                       # :191-193 `shift.add_(p, alpha=-decay)`, on the owned part
+            toff, tcnt = self.ranges[k]
+            for off, cnt, _g in todo:
+                lo, hi = max(off, toff), min(off + cnt, toff + tcnt)
+                if lo < hi:
+                    lib.check(self.L.sdxl_adamw_decay(C.c_void_p(self.shift.data_ptr() + 2 * lo),
+                                                      C.c_void_p(self.net.weights.data_ptr() + 2 * lo), hi - lo, d, st), "sdxl_adamw_decay")
         if zero_grad:
             self.net.zero_grads()
+        for fn in self._post_step_hooks:
+            fn(self)

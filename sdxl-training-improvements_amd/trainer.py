@@ -16,14 +16,23 @@ Reference contract mirrored here:
     flow matching loss, x0_norm, x1_norm, time_mean, time_std, velocity_norm, batch_size, lr
     (flow_matching_trainer.py:338-347).
 Selected by `training.method` in config.yaml exactly like the reference (sdxl_trainer.py:128-152): "ddpm" or
-"flow_matching"; anything else raises ValueError.
+"flow_matching"; anything else raises ValueError.  (The module `native_mi355x.py` is the file a maintainer drops into the
+reference's `methods/` directory; it registers this class under the method name "native_mi355x".)
+
+`model` is what the reference hands every trainer (models/sdxl.py:11-62): an object whose `.unet` is the PyTorch /
+diffusers UNet.  Its diffusers-keyed `state_dict()` is imported into the packed native arena at construction
+(`sdxl_load_weight`), and `sync_to_model()` / `save_checkpoint()` write the trained weights back into that module, so the
+reference's `model.save_pretrained` (models/sdxl.py:246-288) keeps producing a loadable diffusers checkpoint.  A
+`NativeUNet` may be passed directly as well.
 """
 from __future__ import annotations
 
 import ctypes as C
+import json
 import math
 import time
 from collections import defaultdict
+from pathlib import Path
 from typing import Any, Dict, Optional
 
 import torch
@@ -33,7 +42,7 @@ from . import lib
 from .config import Config
 from .optimizer import AdamWBF16
 from .scheduler import NoiseScheduler
-from .unet import NativeUNet
+from .unet import NativeUNet, config_from_unet
 
 REQUIRED_KEYS = {"vae_latents", "prompt_embeds", "pooled_prompt_embeds", "time_ids", "metadata"}
 
@@ -69,20 +78,40 @@ class NativeSDXLTrainer:
             raise ValueError(f"Unsupported training method: {self.config.training.method}")   # sdxl_trainer.py:151
         self.method = method
         self.gradient_accumulation_steps = int(self.config.training.gradient_accumulation_steps)
-        self.net: NativeUNet = model.unet if hasattr(model, "unet") else model
-        for attr in ("forward_loss", "backward", "read_loss", "zero_grads", "param_elems"):
-            if not hasattr(self.net, attr):
-                raise TypeError("model.unet must be a NativeUNet (use NativeUNet.load_state_dict to import a torch "
-                                f"UNet); missing `{attr}`")
+        unet = model.unet if hasattr(model, "unet") else model
+        native_attrs = ("forward_loss", "backward", "read_loss", "zero_grads", "param_elems")
+        self._torch_unet = None
+        if all(hasattr(unet, a) for a in native_attrs):
+            self.net = unet                                            # already a NativeUNet
+        elif callable(getattr(unet, "state_dict", None)):
+            # the reference's model object: import the PyTorch UNet's diffusers-keyed weights (models/sdxl.py:40, :92)
+            sd = unet.state_dict()
+            factory = kwargs.pop("native_factory", None)               # (tests: a stand-in for machines without a GPU)
+            ncfg = kwargs.pop("native_config", None) or config_from_unet(unet, sd)
+            dev = self.device.index if isinstance(self.device, torch.device) and self.device.index is not None else 0
+            self.net = factory(ncfg) if factory is not None else NativeUNet(ncfg, device=dev)
+            self.net.load_state_dict(sd, strict=True)                   # KeyError on any missing / unexpected key
+            self._torch_unet = unet
+        else:
+            raise TypeError("model.unet must be a NativeUNet or a module with a diffusers-keyed state_dict(); got "
+                            f"{type(unet).__name__}")
         self.noise_scheduler = NoiseScheduler(self.config, "cpu")
         self.optimizer = optimizer if optimizer is not None else AdamWBF16(       # main.py:73-86 (optimizer_type adamw_bf16)
             self.net, lr=self.config.optimizer.learning_rate, betas=(self.config.optimizer.beta1, self.config.optimizer.beta2),
-            eps=self.config.optimizer.epsilon, weight_decay=self.config.optimizer.weight_decay)
+            eps=self.config.optimizer.epsilon, weight_decay=self.config.optimizer.weight_decay,
+            reference_ema=bool(getattr(self.config.optimizer, "reference_ema", True)))
         self._clip_coef = None
-        self.sync = D.GradSync(self.net.param_elems, self._cast, torch.bfloat16, getattr(self.net, "device", "cpu"))
+        # data parallel: ZeRO-1 (reduce-scatter, sharded fused AdamW, all-gather) with the fused optimizer, else all-reduce
+        self.sharded = bool(getattr(self.config.training, "shard_optimizer", True)) and isinstance(self.optimizer, AdamWBF16)
+        Sync = D.ShardedGradSync if self.sharded else D.GradSync
+        self.sync = Sync(self.net.param_elems, self._cast, torch.bfloat16, getattr(self.net, "device", "cpu"))
         self._micro = 0                      # micro-step index inside the accumulation cycle
+        self._zeroed = False                 # gradients already zeroed for the cycle in progress
         self._anchor = torch.zeros((), requires_grad=True)
         self._exchange = True
+        hook = getattr(self.optimizer, "register_step_post_hook", None)
+        if callable(hook):                   # an optimizer step ends the accumulation cycle, whoever calls it
+            hook(lambda *_a, **_k: self._end_cycle())
 
     # -------------------------------------------------------------------------------- loss
     def _cast(self, off, n, dst):
@@ -139,35 +168,62 @@ class NativeSDXLTrainer:
 
     training_step = compute_loss                                        # DDPM trainer's name for it
 
+    def _end_cycle(self) -> None:
+        self._micro = 0
+        self._zeroed = False
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        """Start a new accumulation cycle (the direct `compute_loss(...)["loss"].backward()` loop calls this or
+        `optimizer.step()` between cycles, like the reference's template loop, example_method.py:191-206)."""
+        self.net.zero_grads()
+        self._micro = 0
+        self._zeroed = True
+
     def _native_backward(self, grad_scale: float) -> None:
+        """backward of the 0-d loss: runs from `_execute_training_step` and from a caller-owned
+        `compute_loss(batch)["loss"].backward()` loop alike, so the accumulation state lives here."""
         first = self._micro == 0
+        if first and not self._zeroed:       # the small-parameter gradients accumulate with atomics: zero them per cycle
+            self.net.zero_grads()
         world = self.sync.world
-        self.sync.enabled = self._exchange
-        self.net.backward(grad_scale / world, first, on_segment=self.sync.on_segment if world > 1 else None)
+        exchange = self._exchange and world > 1
+        self.sync.enabled = exchange
+        # per-segment joins (side stream -> caller's stream) only on the micro-step that exchanges gradients
+        self.net.backward(grad_scale / world, first, on_segment=self.sync.on_segment if exchange else None)
+        self._micro += 1
+        self._zeroed = False
 
     # -------------------------------------------------------------------------------- loop pieces
     def _execute_training_step(self, batch, accumulate: bool = False, is_last_accumulation_step: bool = True, **kw):
         N = self.gradient_accumulation_steps if accumulate else 1
         if self._micro == 0:
             self.net.zero_grads()                                      # start of the cycle (D10 repair)
+            self._zeroed = True
         self._exchange = (not accumulate) or is_last_accumulation_step
         out = self.compute_loss(batch, **kw)
         loss = out["loss"] / N if accumulate else out["loss"]
         loss.backward()
-        self._micro = 0 if self._exchange else self._micro + 1
         if self._exchange:
+            self._end_cycle()
             self.sync.finish()
+        self._exchange = True
         return loss.detach() * N, out["metrics"]
 
     def clip_grad_norm_(self, max_norm: float) -> float:
-        """torch.nn.utils.clip_grad_norm_ over the flat arena (flow_matching_trainer.py:181-186)."""
+        """torch.nn.utils.clip_grad_norm_ over the flat arena (flow_matching_trainer.py:181-186).  Under data parallelism
+        the norm is taken over the exchanged gradients: the whole all-reduced arena, or (ZeRO-1) this rank's
+        reduce-scattered slices + one float all-reduced -- the coefficient is then the same bits on every rank."""
+        self.sync.finish()                                   # the asynchronous exchange must have landed
         fused = isinstance(self.optimizer, AdamWBF16)        # the coefficient rides into the fused optimizer kernel
         g = self.sync.reduced() if self.sync.world > 1 else self.net.grads
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream) if g.is_cuda else None
         if g.is_cuda:                                        # squared norm + coefficient on the device (HIP kernels)
             buf = torch.empty(2, dtype=torch.float32, device=g.device)
-            lib.check(self.net.L.sdxl_sumsq(C.c_void_p(g.data_ptr()), 0 if g.dtype == torch.float32 else 1, g.numel(),
+            n = (g.numel() // 8) * 8
+            lib.check(self.net.L.sdxl_sumsq(C.c_void_p(g.data_ptr()), 0 if g.dtype == torch.float32 else 1, n,
                                             C.c_void_p(buf.data_ptr()), st), "sdxl_sumsq")
+            if self.sharded and self.sync.world > 1:
+                self.sync.global_sumsq(buf[0:1])
             lib.check(self.net.L.sdxl_clip_coef(C.c_void_p(buf.data_ptr()), float(max_norm),
                                                 C.c_void_p(buf.data_ptr() + 4), st), "sdxl_clip_coef")
             if fused:
@@ -175,7 +231,10 @@ class NativeSDXLTrainer:
             else:
                 g.mul_(buf[1])
             return float(buf[0].sqrt())                      # the reference logs the norm (one read-back)
-        norm = float(g.float().norm())                       # host-logic tests with a stand-in net (no GPU)
+        sq = g.float().pow(2).sum().reshape(1)               # host-logic tests with a stand-in net (no GPU)
+        if self.sharded and self.sync.world > 1:
+            self.sync.global_sumsq(sq)
+        norm = float(sq.sqrt())
         coef = max_norm / (norm + 1e-6) if norm > max_norm else 1.0
         if fused:
             self._clip_coef = torch.tensor([coef], dtype=torch.float32) if coef != 1.0 else None
@@ -184,27 +243,39 @@ class NativeSDXLTrainer:
         return norm
 
     def optimizer_step(self) -> Optional[float]:
+        self.sync.finish()
         gn = None
         if self.config.training.clip_grad_norm and self.config.training.clip_grad_norm > 0:
             gn = self.clip_grad_norm_(float(self.config.training.clip_grad_norm))
         if self.optimizer is not None:
             if isinstance(self.optimizer, AdamWBF16):
-                self.optimizer.step(self.sync.reduced() if self.sync.world > 1 else None, grad_scale=self._clip_coef)
+                if self.sync.world > 1 and self.sharded:     # ZeRO-1: update this rank's slices, then all-gather the parameters
+                    self.optimizer.step(self.sync.reduced(), grad_scale=self._clip_coef, pieces=self.sync.pieces)
+                    self.sync.gather_params(self.net.weights)
+                else:
+                    self.optimizer.step(self.sync.reduced() if self.sync.world > 1 else None, grad_scale=self._clip_coef)
                 self._clip_coef = None
             else:
                 self.optimizer.step()
+        self._end_cycle()
         return gn
 
-    def train(self, num_epochs: int) -> None:
+    def train(self, num_epochs: int, save_checkpoints: bool = False) -> None:
+        """The template loop.  save_checkpoints: the reference's cadence (flow_matching_trainer.py:211-234): a checkpoint
+        whenever the epoch's mean loss improves, and `final_checkpoint` at the end (off by default: writing the 5 GB UNet
+        is the caller's decision, `SDXLTrainer.save_checkpoint` in the reference)."""
         N = self.gradient_accumulation_steps
         global_step = 0
+        best = float("inf")
         for epoch in range(num_epochs):
             acc_loss, acc_metrics = 0.0, defaultdict(float)
+            ep_loss, ep_n = 0.0, 0
             for step, batch in enumerate(self.train_dataloader):
                 t0 = time.time()
                 last = (step + 1) % N == 0
                 loss, metrics = self._execute_training_step(batch, accumulate=True, is_last_accumulation_step=last)
                 acc_loss += float(loss)
+                ep_loss, ep_n = ep_loss + float(loss), ep_n + 1
                 for k, v in metrics.items():
                     acc_metrics[k] += v
                 if last:
@@ -220,11 +291,56 @@ class NativeSDXLTrainer:
                             print({k: (round(v, 6) if isinstance(v, float) else v) for k, v in eff.items()}, flush=True)
                     acc_loss, acc_metrics = 0.0, defaultdict(float)
                 global_step += 1
+            if save_checkpoints and ep_n and ep_loss / ep_n < best:
+                best = ep_loss / ep_n
+                self.save_checkpoint(epoch + 1, is_final=False)
+        if save_checkpoints:
+            self.save_checkpoint(num_epochs, is_final=True)
 
-    def save_checkpoint(self, path, is_final: bool = False) -> None:
-        """UNet weights back as a diffusers-keyed state_dict (row f4); the rest of the pipeline stays PyTorch."""
-        if D.is_main_process():
-            torch.save({k: v.cpu() for k, v in self.net.state_dict().items()}, path)
+    # -------------------------------------------------------------------------------- weights out (row f4)
+    def sync_to_model(self) -> None:
+        """Write the trained native weights back into the caller's PyTorch UNet (diffusers keys, the module's own dtypes), so
+        everything the reference does with `model.unet` afterwards -- `save_pretrained` (models/sdxl.py:246-288), validation
+        sampling -- sees them."""
+        if self._torch_unet is None:
+            return
+        sd = self.net.state_dict()
+        ref = self._torch_unet.state_dict()
+        self._torch_unet.load_state_dict({k: v.to(device=ref[k].device, dtype=ref[k].dtype) for k, v in sd.items()}, strict=True)
+
+    def save_checkpoint(self, epoch_or_path=0, is_final: bool = False) -> Optional[Path]:
+        """sdxl_trainer.py:162-210: `outputs/checkpoint-<epoch>` or `outputs/final_checkpoint` (main.py:111 passes a
+        directory instead of an epoch: accepted too); the model through `model.save_pretrained(dir, safe_serialization=True)`
+        when the caller's model has it (weights synced back first), else the UNet as diffusers-keyed safetensors;
+        `optimizer.pt` = optimizer.state_dict(); `config.json` = the training config."""
+        if not D.is_main_process():
+            return None
+        if isinstance(epoch_or_path, (str, Path)):
+            save_dir = Path(epoch_or_path)
+        else:
+            save_dir = Path("outputs") / ("final_checkpoint" if is_final else f"checkpoint-{int(epoch_or_path):04d}")
+        save_dir.mkdir(parents=True, exist_ok=True)
+        self.sync_to_model()
+        if self._torch_unet is not None and callable(getattr(self.model, "save_pretrained", None)):
+            self.model.save_pretrained(str(save_dir), safe_serialization=True)
+        else:
+            from safetensors.torch import save_file
+            (save_dir / "unet").mkdir(exist_ok=True)
+            save_file({k: v.cpu().contiguous() for k, v in self.net.state_dict().items()},
+                      str(save_dir / "unet" / "diffusion_pytorch_model.safetensors"))
+        if self.optimizer is not None and callable(getattr(self.optimizer, "state_dict", None)):
+            osd = self.optimizer.state_dict()
+            if isinstance(osd.get("state"), dict):
+                osd["state"] = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in osd["state"].items()}
+            torch.save(osd, str(save_dir / "optimizer.pt"))
+        with open(save_dir / "config.json", "w") as f:
+            json.dump(self.config.to_dict(), f, indent=2)
+        return save_dir
+
+    def load_optimizer_state(self, checkpoint_dir) -> None:
+        """resume: optimizer.pt written by save_checkpoint (the UNet weights come back through the model object)."""
+        sd = torch.load(str(Path(checkpoint_dir) / "optimizer.pt"), map_location="cpu", weights_only=False)
+        self.optimizer.load_state_dict(sd)
 
 
 def create_trainer(model, optimizer=None, train_dataloader=None, device=None, wandb_logger=None, config=None, **kw):

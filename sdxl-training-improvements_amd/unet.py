@@ -36,6 +36,41 @@ def make_config(**over) -> lib.UNetConfig:
     return c
 
 
+def config_from_unet(unet, sd=None) -> lib.UNetConfig:
+    """sdxl_unet_config of a PyTorch / diffusers UNet2DConditionModel: from its `.config` where present (diffusers), else
+    from the shapes of its diffusers-keyed state dict (what models/sdxl.py:25-40 loads)."""
+    sd = sd if sd is not None else unet.state_dict()
+    c = getattr(unet, "config", None)
+    get = (lambda k, d=None: (c.get(k, d) if isinstance(c, dict) else getattr(c, k, d))) if c is not None else (lambda k, d=None: d)
+    ch = get("block_out_channels")
+    if ch is None:
+        ch = [sd["conv_in.weight"].shape[0]]
+        for i in (1, 2):
+            k = f"down_blocks.{i}.resnets.0.conv1.weight"
+            if k in sd:
+                ch.append(sd[k].shape[0])
+    tl = get("transformer_layers_per_block")
+    if tl is None or isinstance(tl, int):
+        tl = []
+        for i in range(len(ch)):
+            n = 0
+            while f"down_blocks.{i}.attentions.0.transformer_blocks.{n}.norm1.weight" in sd:
+                n += 1
+            tl.append(n)
+    cross = get("cross_attention_dim")
+    if cross is None or isinstance(cross, (list, tuple)):
+        k = next(k for k in sd if k.endswith("attn2.to_k.weight"))
+        cross = sd[k].shape[1]
+    ad = get("addition_time_embed_dim", 256)
+    add_in = get("projection_class_embeddings_input_dim", None) or sd["add_embedding.linear_1.weight"].shape[1]
+    head = get("attention_head_dim", 64)
+    head = 64 if isinstance(head, (list, tuple)) else head           # SDXL: heads = C / 64 at every level
+    return make_config(block_out_channels=tuple(int(x) for x in ch), transformer_layers=tuple(int(x) for x in tl),
+                       layers_per_block=int(get("layers_per_block", 2)), cross_attention_dim=int(cross),
+                       addition_time_embed_dim=int(ad), pooled_dim=int(add_in) - 6 * int(ad),
+                       norm_num_groups=int(get("norm_num_groups", 32)), head_dim=64 if head in (5, 10, 20) else int(head))
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 

@@ -26,3 +26,14 @@ def test_two_ranks_one_device_gloo():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
     assert out["scaling"] == "weak" and out["value"] > 0 and out["steps"] == 1
     assert 0 < out["loss"] < 1000
+
+
+def test_zero1_update_bit_equal_to_unsharded():
+    """Row f3 (ZeRO-1): reduce-scatter -> norm on the slices + 1 float -> sharded fused AdamW -> all-gather gives the SAME BITS as
+    all-reduce + the full update, two ranks on one GPU over gloo (tests/_zero1_worker.py)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", str(ROOT / "tests" / "_zero1_worker.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ZERO1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
