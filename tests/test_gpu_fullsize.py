@@ -218,7 +218,8 @@ def test_ddpm_batch_decomposes(full):
     net = full
     B, H, W = 4, 128, 128
     x = _inputs(B, H, W, seed=808)
-    ts = torch.tensor([450, 613, 700, 930])        # moderate sigmas: every per-sample loss stays below the (non-linear) 1000 cap
+    ts = torch.tensor([450, 613, 700, 820])        # moderate sigmas: every per-sample loss stays below the (non-linear) 1000 cap
+                                                   # (t = 12: sigma ~ 1.8e4 blows the prediction up, t = 930: 1 / sigma^2 the target)
     sig = R.karras_sigmas()[ts]
     probe = "down_blocks.1.attentions.0.transformer_blocks.0.attn1.to_q.weight"
 
