@@ -141,6 +141,7 @@ def main():
                     help="N > 1: reduce-scatter of the gradient buckets (ZeRO-1, default) or all-reduce")
     ap.add_argument("--profile-steps", type=int, default=1, help="extra steps with per-launch GEMM event timing")
     ap.add_argument("--gemm-mode", type=int, default=None, help="A/B runs: sdxl_set_gemm_mode (0 = 128-row kernel only)")
+    ap.add_argument("--lib", default=None, help="A/B runs: another build of libsdxlstep.so (e.g. last round's) on the same box")
     args = ap.parse_args()
 
     import sdxl_amd  # noqa: F401
@@ -162,6 +163,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    if args.lib:                     # an older build may lack newer entry points: bind what it has
+        import ctypes
+        lib.LIB_PATH = Path(args.lib).resolve()
+        probe = ctypes.CDLL(str(lib.LIB_PATH))
+        lib.SIGNATURES = {k: v for k, v in lib.SIGNATURES.items() if hasattr(probe, k)}
     if args.gemm_mode is not None:
         lib.check(lib.load().sdxl_set_gemm_mode(args.gemm_mode))
     net = NU.NativeUNet(NU.make_config(), device=local_rank)

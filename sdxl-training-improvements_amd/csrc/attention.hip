@@ -14,6 +14,8 @@
 // Kernels: attn_fwd (O, LSE) ; attn_bwd_dq (also Delta = rowsum dO*O) ; attn_bwd_dkv (+ its split-query reduce).
 #include "kernels.h"
 
+#include <type_traits>
+
 #define HD 64
 #define SCALE 0.125f
 #define LOG2E 1.4426950408889634f
@@ -55,25 +57,73 @@ __device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
   o[4] = (bf16)b[0]; o[5] = (bf16)b[1]; o[6] = (bf16)b[2]; o[7] = (bf16)b[3];
   return o;
 }
-// LDS-DMA of a [64][64] bf16 tile (rows row0.., zero beyond nrows): 8 chunks of 1 KiB = 8 rows each, 2 per wave
-__device__ __forceinline__ void tile_dma(const bf16* base, long ld, int row0, int nrows, bf16* tile, int wave, int lane) {
+// LDS-DMA of [64][64] bf16 tiles (zero beyond nrows): 8 chunks of 1 KiB = 8 rows each, 2 per wave.  The per-lane source
+// pointers of tile 0 are computed once; a tile is then one 64-bit add per piece (the first version recomputed row * ld with
+// a 64-bit multiply and an out-of-range select for every piece of every tile: ~30 of the ~190 VALU instructions per tile of
+// kernels whose VALU pipe, not the matrix pipe, sets the pace).
+struct TileSrc {
+  const bf16* p[2];   // this lane's 16-byte vector of pieces 0 / 1 in tile 0
+  long step;          // elements per tile (64 rows)
+  int r[2];           // row of the lane's vector inside a tile
+};
+__device__ __forceinline__ TileSrc tile_src(const bf16* base, long ld, int wave, int lane) {
+  TileSrc s;
+  s.step = 64 * ld;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int c = wave * 2 + j;
-    const int r = c * 8 + (lane >> 3);
-    const int lv = (lane & 7) ^ (r & 7);
-    const int row = row0 + r;
-    const bf16* src = row < nrows ? base + (long)row * ld + lv * 8 : (const bf16*)g_attn_zero16;
-    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(tile + c * 512), 16, 0, 0);
+    const int r = (wave * 2 + j) * 8 + (lane >> 3);
+    s.r[j] = r;
+    s.p[j] = base + (long)r * ld + (((lane & 7) ^ (r & 7)) << 3);
+  }
+  return s;
+}
+__device__ __forceinline__ void tile_dma(const TileSrc& s, int t, int nrows, bf16* tile, int wave) {
+  const bool full = (t + 1) * 64 <= nrows;   // wave-uniform
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const bf16* src = s.p[j] + (long)t * s.step;
+    if (!full && t * 64 + s.r[j] >= nrows) src = (const bf16*)g_attn_zero16;
+    lds_dma16_global(src, lds_addr_of(tile + (wave * 2 + j) * 512));   // asm: see common.h
   }
 }
 
 #define TILE_ELEMS (64 * 64)
 
+// hipcc places the s_waitcnt vmcnt(0) for registers loaded before a loop at their first use INSIDE the loop body, where it
+// runs every iteration and drains the LDS-DMA pieces in flight.  Touching the registers here makes it wait here, once.
+__device__ __forceinline__ void landed(bf16x8& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void landed(float& v) { asm volatile("" : "+v"(v)); }
+
+// cross-row lane exchanges without the LDS crossbar (ds_bpermute + lgkmcnt wait): gfx950 v_permlane16_swap / v_permlane32_swap
+// trade 16-lane rows (odd rows of the first operand <-> even rows of the second) / wave halves between two registers; with
+// both operands holding x the pair afterwards holds x and x from the partner row / half in every lane.
+__device__ __forceinline__ void swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float max_over_g(float x) {   // max over the four lanes l16 + 16 g, g = 0..3 (same value in all four)
+  float a = x, b = x;
+  swap16(a, b);
+  x = fmaxf(a, b);
+  a = x; b = x;
+  swap32(a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float sum_over_g(float x) {
+  float a = x, b = x;
+  swap16(a, b);
+  x = a + b;
+  a = x; b = x;
+  swap32(a, b);
+  return a + b;
+}
+
 // ------------------------------------------------------------------------------------------------
-// forward: block = 128 queries (4 waves x 32), loop over 64-key tiles
+// forward: block = 128 queries (4 waves x 32), loop over 64-key tiles.
+// Per tile and wave: 8 K fragments (ds_read_b128) -> 16 MFMAs (S^T) -> the 8 V^T fragments are requested (16 transpose
+// reads, 32 VGPRs) BEFORE the softmax arithmetic so that their LDS latency hides under it -> 16 MFMAs (O^T) back to back.
+// (The first version read each V^T fragment right before its two MFMAs: ~100 cycles of exposed LDS latency eight times
+// per tile; PMC: 45 % of the wave cycles issue-stalled, profiles/r02d.)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
   __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE_ELEMS];  // K0 V0 K1 V1
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l16 = lane & 15, g = lane >> 4;
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
@@ -100,33 +150,48 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
   const float c = SCALE * LOG2E;
 
   const int ntiles = (p.Nk + 63) / 64;
-  tile_dma(Kb, p.ldk, 0, p.Nk, sm, wave, lane);
-  tile_dma(Vb, p.ldv, 0, p.Nk, sm + TILE_ELEMS, wave, lane);
+  const TileSrc ksrc = tile_src(Kb, p.ldk, wave, lane), vsrc = tile_src(Vb, p.ldv, wave, lane);
+  tile_dma(ksrc, 0, p.Nk, sm, wave);
+  tile_dma(vsrc, 0, p.Nk, sm + TILE_ELEMS, wave);
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) { landed(qf[qb][0]); landed(qf[qb][1]); }
   int buf = 0;
-  for (int t = 0; t < ntiles; ++t) {
-    __syncthreads();  // vmcnt(0) + barrier: tile t landed for every wave, everyone done with the other buffer
+  // one key tile; MASK: the tile holds keys beyond Nk (only the last tile of a ragged sequence)
+  auto tile = [&](int t, auto MASKC) {
+    constexpr bool MASK = decltype(MASKC)::value;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my DMA pieces of tile t have landed ...
+    __syncthreads();                                     // ... everyone's have; everyone is done with the other buffer
     if (t + 1 < ntiles) {
-      tile_dma(Kb, p.ldk, (t + 1) * 64, p.Nk, sm + ((buf ^ 1) * 2) * TILE_ELEMS, wave, lane);
-      tile_dma(Vb, p.ldv, (t + 1) * 64, p.Nk, sm + ((buf ^ 1) * 2 + 1) * TILE_ELEMS, wave, lane);
+      tile_dma(ksrc, t + 1, p.Nk, sm + ((buf ^ 1) * 2) * TILE_ELEMS, wave);
+      tile_dma(vsrc, t + 1, p.Nk, sm + ((buf ^ 1) * 2 + 1) * TILE_ELEMS, wave);
     }
     const bf16* Kt = sm + (buf * 2) * TILE_ELEMS;
     const bf16* Vt = Kt + TILE_ELEMS;
     // S^T[key][q] = K . Q^T
-    f32x4 st[4][2];
+    bf16x8 kf[4][2];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-      bf16x8 k0 = ld_frag(Kt, kb * 16 + l16, g * 8);
-      bf16x8 k1 = ld_frag(Kt, kb * 16 + l16, 32 + g * 8);
+      kf[kb][0] = ld_frag(Kt, kb * 16 + l16, g * 8);
+      kf[kb][1] = ld_frag(Kt, kb * 16 + l16, 32 + g * 8);
+    }
+    f32x4 st[4][2];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
         f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qb][0], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qb][1], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb][0], qf[qb][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb][1], qf[qb][1], a, 0, 0, 0);
         st[kb][qb] = a;
       }
-    }
-    // mask keys beyond Nk (last tile only)
-    if ((t + 1) * 64 > p.Nk) {
+    // V^T fragments for the second product: requested now, consumed after the softmax arithmetic
+    bf16x8 vfr[4][2];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) vfr[db][t2] = tr_frag(Vt, t2, db * 16, l16, g);
+    __builtin_amdgcn_sched_barrier(0);
+    if (MASK) {
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -144,8 +209,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kb][qb][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = max_over_g(mx);
       float mnew = fmaxf(mrow[qb], mx);
       float alpha = __builtin_amdgcn_exp2f((mrow[qb] - mnew) * c);
       mrow[qb] = mnew;
@@ -167,24 +231,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
       pf[0][qb] = pack8(st[0][qb], st[1][qb]);
       pf[1][qb] = pack8(st[2][qb], st[3][qb]);
     }
+    __builtin_amdgcn_sched_barrier(0);
     // O^T[d][q] += V^T . P^T
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        bf16x8 vf = tr_frag(Vt, t2, db * 16, l16, g);
+      for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
-          ot[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t2][qb], ot[db][qb], 0, 0, 0);
-      }
+          ot[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[db][t2], pf[t2][qb], ot[db][qb], 0, 0, 0);
     buf ^= 1;
-  }
+  };
+  const int nfull = p.Nk / 64;
+  for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
+  if (nfull < ntiles) tile(nfull, std::true_type{});
   // finalize
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
-    float l = lrow[qb];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    float l = sum_over_g(lrow[qb]);
     float inv = 1.f / l;
     int q = q0 + qb * 16 + l16;
     if (q < p.Nq) {
@@ -232,8 +296,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) dl += (float)df[qb][ks][e] * (float)of[e];
     }
-    dl += __shfl_xor(dl, 16, 64);
-    dl += __shfl_xor(dl, 32, 64);
+    dl = sum_over_g(dl);
     lse2[qb] = ok ? p.LSE[(long)bh * p.Nq + q] * LOG2E : 0.f;
     delta[qb] = dl;
     if (ok && g == 0) p.Delta[(long)bh * p.Nq + q] = dl;
@@ -246,59 +309,77 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   const float c = SCALE * LOG2E;
 
   const int ntiles = (p.Nk + 63) / 64;
-  tile_dma(Kb, p.ldk, 0, p.Nk, sm, wave, lane);
-  tile_dma(Vb, p.ldv, 0, p.Nk, sm + TILE_ELEMS, wave, lane);
+  const TileSrc ksrc = tile_src(Kb, p.ldk, wave, lane), vsrc = tile_src(Vb, p.ldv, wave, lane);
+  tile_dma(ksrc, 0, p.Nk, sm, wave);
+  tile_dma(vsrc, 0, p.Nk, sm + TILE_ELEMS, wave);
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) { landed(qf[qb][0]); landed(qf[qb][1]); landed(df[qb][0]); landed(df[qb][1]); landed(lse2[qb]); landed(delta[qb]); }
   int buf = 0;
-  for (int t = 0; t < ntiles; ++t) {
+  // one key tile.  Order: K, V fragments (16 b128 reads) -> 32 MFMAs (S^T, dP^T) -> the K^T transpose-read fragments of the third
+  // product are requested BEFORE the exp / dS arithmetic (their LDS latency hides under it) -> 16 MFMAs (dQ^T) back to back.
+  auto tile = [&](int t, auto MASKC) {
+    constexpr bool MASK = decltype(MASKC)::value;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t + 1 < ntiles) {
-      tile_dma(Kb, p.ldk, (t + 1) * 64, p.Nk, sm + ((buf ^ 1) * 2) * TILE_ELEMS, wave, lane);
-      tile_dma(Vb, p.ldv, (t + 1) * 64, p.Nk, sm + ((buf ^ 1) * 2 + 1) * TILE_ELEMS, wave, lane);
+      tile_dma(ksrc, t + 1, p.Nk, sm + ((buf ^ 1) * 2) * TILE_ELEMS, wave);
+      tile_dma(vsrc, t + 1, p.Nk, sm + ((buf ^ 1) * 2 + 1) * TILE_ELEMS, wave);
     }
     const bf16* Kt = sm + (buf * 2) * TILE_ELEMS;
     const bf16* Vt = Kt + TILE_ELEMS;
-    bf16x8 dsf[2][2];
-    f32x4 st[4][2], dp[4][2];
+    bf16x8 kf[4][2], vf[4][2];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-      bf16x8 k0 = ld_frag(Kt, kb * 16 + l16, g * 8), k1 = ld_frag(Kt, kb * 16 + l16, 32 + g * 8);
-      bf16x8 v0 = ld_frag(Vt, kb * 16 + l16, g * 8), v1 = ld_frag(Vt, kb * 16 + l16, 32 + g * 8);
+      kf[kb][0] = ld_frag(Kt, kb * 16 + l16, g * 8); kf[kb][1] = ld_frag(Kt, kb * 16 + l16, 32 + g * 8);
+      vf[kb][0] = ld_frag(Vt, kb * 16 + l16, g * 8); vf[kb][1] = ld_frag(Vt, kb * 16 + l16, 32 + g * 8);
+    }
+    f32x4 st[4][2], dp[4][2];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
         f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qb][0], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qb][1], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb][0], qf[qb][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb][1], qf[qb][1], a, 0, 0, 0);
         st[kb][qb] = a;
         f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
-        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, df[qb][0], d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, df[qb][1], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kb][0], df[qb][0], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kb][1], df[qb][1], d, 0, 0, 0);
         dp[kb][qb] = d;
       }
-    }
+    bf16x8 ktr[4][2];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) ktr[db][t2] = tr_frag(Kt, t2, db * 16, l16, g);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 dsf[2][2];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          int key = t * 64 + kb * 16 + g * 4 + r;
-          float pr = key < p.Nk ? __builtin_amdgcn_exp2f(st[kb][qb][r] * c - lse2[qb]) : 0.f;
-          st[kb][qb][r] = pr * (dp[kb][qb][r] - delta[qb]) * SCALE;
+          float pr = __builtin_amdgcn_exp2f(st[kb][qb][r] * c - lse2[qb]);
+          if (MASK) { if (t * 64 + kb * 16 + g * 4 + r >= p.Nk) pr = 0.f; }
+          st[kb][qb][r] = pr * (dp[kb][qb][r] - delta[qb]);      // (the softmax scale is applied once, to dQ, at the end)
         }
       dsf[0][qb] = pack8(st[0][qb], st[1][qb]);
       dsf[1][qb] = pack8(st[2][qb], st[3][qb]);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        bf16x8 kf = tr_frag(Kt, t2, db * 16, l16, g);
+      for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
-          dq[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf[t2][qb], dq[db][qb], 0, 0, 0);
-      }
+          dq[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr[db][t2], dsf[t2][qb], dq[db][qb], 0, 0, 0);
     buf ^= 1;
-  }
+  };
+  const int nfull = p.Nk / 64;
+  for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
+  if (nfull < ntiles) tile(nfull, std::true_type{});
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     int q = q0 + qb * 16 + l16;
@@ -307,7 +388,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         bf16x4 o;
-        o[0] = (bf16)dq[db][qb][0]; o[1] = (bf16)dq[db][qb][1]; o[2] = (bf16)dq[db][qb][2]; o[3] = (bf16)dq[db][qb][3];
+        o[0] = (bf16)(dq[db][qb][0] * SCALE); o[1] = (bf16)(dq[db][qb][1] * SCALE);
+        o[2] = (bf16)(dq[db][qb][2] * SCALE); o[3] = (bf16)(dq[db][qb][3] * SCALE);
         *(bf16x4*)(row + db * 16 + g * 4) = o;
       }
     }
@@ -356,61 +438,78 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
   const int per = (ntiles_all + p.qsplit - 1) / p.qsplit;
   const int t_begin = blockIdx.z * per;
   const int ntiles = min(ntiles_all, t_begin + per);
-  float rs = 0.f;
-  auto load_stats = [&](int t) {
-    if (tid < 128) {
-      int q = t * 64 + (tid & 63);
-      float v = 0.f;
-      if (q < p.Nq) v = tid < 64 ? p.LSE[(long)bh * p.Nq + q] * LOG2E : p.Delta[(long)bh * p.Nq + q];
-      rs = v;
+  // LSE / Delta of a query tile go to LDS by DMA as well (waves 0 / 1, 4 bytes per lane): no VGPR-destination load is in
+  // flight inside the tile loop, whose compiler-placed s_waitcnt vmcnt(0) would drain the tile DMAs
+  auto load_stats = [&](int t, int bufi) {
+    if (wave < 2) {
+      const int q = t * 64 + lane;
+      const float* src = (wave == 0 ? p.LSE : p.Delta) + (long)bh * p.Nq + q;
+      lds_dma4_global(q < p.Nq ? (const void*)src : (const void*)g_attn_zero16, lds_addr_of(&sstat[bufi][wave][0]));
     }
   };
-  tile_dma(Qb, p.ldq, t_begin * 64, p.Nq, sm, wave, lane);
-  tile_dma(dOb, p.lddo, t_begin * 64, p.Nq, sm + TILE_ELEMS, wave, lane);
-  load_stats(t_begin);
-  if (tid < 128) sstat[0][tid >> 6][tid & 63] = rs;
+  const TileSrc qsrc = tile_src(Qb, p.ldq, wave, lane), dsrc = tile_src(dOb, p.lddo, wave, lane);
+  tile_dma(qsrc, t_begin, p.Nq, sm, wave);
+  tile_dma(dsrc, t_begin, p.Nq, sm + TILE_ELEMS, wave);
+  load_stats(t_begin, 0);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) { landed(kf[kb][0]); landed(kf[kb][1]); landed(vf[kb][0]); landed(vf[kb][1]); }
   int buf = 0;
-  for (int t = t_begin; t < ntiles; ++t) {
+  // one query tile.  Order: Q, dO fragments (16 b128 reads) -> S, dP (16 KB MFMAs) -> the dO^T / Q^T transpose-read fragments
+  // of the first two d-blocks are requested BEFORE the exp / dS arithmetic -> dV, dK of those d-blocks while the fragments of
+  // the other two d-blocks arrive (their registers are the ones S / dP just vacated).
+  auto tile = [&](int t, auto MASKC) {
+    constexpr bool MASK = decltype(MASKC)::value;       // the tile holds query rows beyond Nq
     const bool more = t + 1 < ntiles;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // tile t (DMA) and its statistics landed; everyone done with the other buffer
     if (more) {
-      tile_dma(Qb, p.ldq, (t + 1) * 64, p.Nq, sm + ((buf ^ 1) * 2) * TILE_ELEMS, wave, lane);
-      tile_dma(dOb, p.lddo, (t + 1) * 64, p.Nq, sm + ((buf ^ 1) * 2 + 1) * TILE_ELEMS, wave, lane);
-      load_stats(t + 1);
+      tile_dma(qsrc, t + 1, p.Nq, sm + ((buf ^ 1) * 2) * TILE_ELEMS, wave);
+      tile_dma(dsrc, t + 1, p.Nq, sm + ((buf ^ 1) * 2 + 1) * TILE_ELEMS, wave);
+      load_stats(t + 1, buf ^ 1);
     }
     const bf16* Qt = sm + (buf * 2) * TILE_ELEMS;
     const bf16* Dt = Qt + TILE_ELEMS;
-    f32x4 s[KB][4], dp[KB][4];
+    bf16x8 qa[4][2], da[4][2];
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) {
-      bf16x8 a0 = ld_frag(Qt, qb * 16 + l16, g * 8), a1 = ld_frag(Qt, qb * 16 + l16, 32 + g * 8);
-      bf16x8 d0 = ld_frag(Dt, qb * 16 + l16, g * 8), d1 = ld_frag(Dt, qb * 16 + l16, 32 + g * 8);
+      qa[qb][0] = ld_frag(Qt, qb * 16 + l16, g * 8); qa[qb][1] = ld_frag(Qt, qb * 16 + l16, 32 + g * 8);
+      da[qb][0] = ld_frag(Dt, qb * 16 + l16, g * 8); da[qb][1] = ld_frag(Dt, qb * 16 + l16, 32 + g * 8);
+    }
+    f32x4 s[KB][4], dp[KB][4];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb)
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
         f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, kf[kb][0], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, kf[kb][1], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[qb][0], kf[kb][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[qb][1], kf[kb][1], a, 0, 0, 0);
         s[kb][qb] = a;
         f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
-        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, vf[kb][0], d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, vf[kb][1], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[qb][0], vf[kb][0], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[qb][1], vf[kb][1], d, 0, 0, 0);
         dp[kb][qb] = d;
       }
-    }
+    bf16x8 dot[2][2], qt[2][2];       // [d-block within the half][t2]
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) { dot[db][t2] = tr_frag(Dt, t2, db * 16, l16, g); qt[db][t2] = tr_frag(Qt, t2, db * 16, l16, g); }
+    __builtin_amdgcn_sched_barrier(0);
     bf16x8 pf[KB][2], dsf[KB][2];
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       f32x4 pr[4];
 #pragma unroll
       for (int qb = 0; qb < 4; ++qb) {
-        f32x4 l2 = *(const f32x4*)&sstat[buf][0][qb * 16 + g * 4];
+        f32x4 l2 = *(const f32x4*)&sstat[buf][0][qb * 16 + g * 4];      // natural-log LSE
         f32x4 dl = *(const f32x4*)&sstat[buf][1][qb * 16 + g * 4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          int q = t * 64 + qb * 16 + g * 4 + r;
-          float e = (q < p.Nq && kok[kb]) ? __builtin_amdgcn_exp2f(s[kb][qb][r] * c - l2[r]) : 0.f;
+          float e = __builtin_amdgcn_exp2f(s[kb][qb][r] * c - l2[r] * LOG2E);
+          if (MASK) { if (t * 64 + qb * 16 + g * 4 + r >= p.Nq) e = 0.f; }
+          if (!kok[kb]) e = 0.f;
           pr[qb][r] = e;
-          s[kb][qb][r] = e * (dp[kb][qb][r] - dl[r]) * SCALE;
+          s[kb][qb][r] = e * (dp[kb][qb][r] - dl[r]);          // (the softmax scale is applied once, to dK, at the end)
         }
       }
       pf[kb][0] = pack8(pr[0], pr[1]);
@@ -418,20 +517,39 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
       dsf[kb][0] = pack8(s[kb][0], s[kb][1]);
       dsf[kb][1] = pack8(s[kb][2], s[kb][3]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 dot2[2][2], qt2[2][2];     // d-blocks 2, 3: requested now, used after the first half's products
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        bf16x8 dot = tr_frag(Dt, t2, db * 16, l16, g);
-        bf16x8 qt = tr_frag(Qt, t2, db * 16, l16, g);
+      for (int t2 = 0; t2 < 2; ++t2) { dot2[db][t2] = tr_frag(Dt, t2, (db + 2) * 16, l16, g); qt2[db][t2] = tr_frag(Qt, t2, (db + 2) * 16, l16, g); }
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
-          dv[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf[kb][t2], dv[kb][db], 0, 0, 0);
-          dk[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf[kb][t2], dk[kb][db], 0, 0, 0);
+          dv[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot[db][t2], pf[kb][t2], dv[kb][db], 0, 0, 0);
+          dk[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt[db][t2], dsf[kb][t2], dk[kb][db], 0, 0, 0);
         }
-      }
-    if (more && tid < 128) sstat[buf ^ 1][tid >> 6][tid & 63] = rs;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          dv[kb][db + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot2[db][t2], pf[kb][t2], dv[kb][db + 2], 0, 0, 0);
+          dk[kb][db + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt2[db][t2], dsf[kb][t2], dk[kb][db + 2], 0, 0, 0);
+        }
     buf ^= 1;
+  };
+  {
+    const int nfull_q = p.Nq / 64;                      // tiles before this index hold 64 valid query rows
+    for (int t = t_begin; t < ntiles; ++t) {
+      if (t < nfull_q) tile(t, std::false_type{});
+      else tile(t, std::true_type{});
+    }
   }
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
@@ -441,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
       float* base = p.part + ((((long)blockIdx.z * gridDim.y + bh) * kvt * 64 + key) * 2) * 64;
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
-        *(f32x4*)(base + db * 16 + g * 4) = dk[kb][db];
+        *(f32x4*)(base + db * 16 + g * 4) = dk[kb][db] * SCALE;
         *(f32x4*)(base + 64 + db * 16 + g * 4) = dv[kb][db];
       }
     } else if (kok[kb]) {
@@ -451,7 +569,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
       for (int db = 0; db < 4; ++db) {
         bf16x4 a, c2;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { a[r] = (bf16)dk[kb][db][r]; c2[r] = (bf16)dv[kb][db][r]; }
+        for (int r = 0; r < 4; ++r) { a[r] = (bf16)(dk[kb][db][r] * SCALE); c2[r] = (bf16)dv[kb][db][r]; }
         *(bf16x4*)(kr + db * 16 + g * 4) = a;
         *(bf16x4*)(vr + db * 16 + g * 4) = c2;
       }

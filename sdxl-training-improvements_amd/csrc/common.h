@@ -39,6 +39,43 @@ void sdxl_set_error(const char* fmt, ...);
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 #ifdef __HIPCC__
+// ---- LDS-DMA (global / buffer -> LDS, 16 bytes per lane, lane-linear destination) issued from inline asm ----
+// hipcc treats the LDS-DMA builtins as stores to LDS that any later LDS read may alias: before the first
+// ds_read_b64_tr_b16 (builtin) after a DMA it inserts s_waitcnt vmcnt(0), which drains every DMA in flight -- in a pipeline
+// that keeps later tiles in flight on purpose that wait is the whole memory latency, every phase.  Issued from asm the DMA is
+// invisible to the compiler; completion is then the author's job everywhere (counted s_waitcnt vmcnt + barrier before the
+// data is read, vmcnt(0) before the workgroup ends).  M0 holds the wave-uniform LDS destination and is compiler-reserved:
+// it is saved, written and restored inside the one statement that uses it.
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ void lds_dma16_global(const void* gsrc, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+__device__ __forceinline__ void lds_dma4_global(const void* gsrc, unsigned lds_dst_uniform) {   // 4 bytes per lane
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+// raw buffer descriptor: 48-bit base, stride 0, num_records bytes, DST_SEL / format word of a raw dword buffer
+__device__ __forceinline__ i32x4 make_srd(const void* base, unsigned num_records) {
+  const unsigned long long a = (unsigned long long)base;
+  i32x4 r;
+  r[0] = (int)(unsigned)a;
+  r[1] = (int)(unsigned)((a >> 32) & 0xFFFFu);
+  r[2] = (int)num_records;
+  r[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void lds_dma16_buffer(i32x4 srd_uniform, unsigned voffset, unsigned soffset_uniform, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voffset), "s"(srd_uniform), "s"(soffset_uniform), "s"(lds_dst_uniform) : "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -88,9 +88,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmP p) {
   const int T = kt_end - kt_begin;
 
   // ---- LDS-DMA addressing: one per-lane byte offset per operand, scalar offsets per piece ----
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7FFFFFFF, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0x7FFFFFFF, 0x00020000);
+  const i32x4 ra = make_srd(p.A, 0x7FFFFFFFu), rb = make_srd(p.B, 0x7FFFFFFFu);   // wave-uniform (kernel arguments only)
   const int lda = (int)p.lda, ldb = (int)p.ldb;
+  const unsigned lds_base = lds_addr_of(smem);
   unsigned voA, voB;
   {
     const int kc_row = lane >> 3, kc_vec = (lane & 7) ^ kc_row;           // K-contiguous: 8 rows x 8 vectors per piece
@@ -113,9 +113,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmP p) {
     int so;
     if (R < 2) so = A_KC ? (m0 + 128 * h + 64 * ab + 8 * wave) * lda + k0 : (k0 + 4 * q) * lda + m0 + 64 * ab;
     else so = B_KC ? (n0 + cbase(2 * h + (wave >> 2), ab) + 8 * (wave & 3)) * ldb + k0 : (k0 + 4 * q) * ldb + n0 + 32 * ab;
-    char* dst = smem + buf * BUFB + R * REGION + q * 1024;   // (a dummy piece overwrites a region no K-tile will read again)
+    const unsigned dst = lds_base + buf * BUFB + R * REGION + q * 1024;   // (a dummy piece overwrites a region no K-tile will read again)
     const unsigned vo = live ? (R < 2 ? voA : voB) : OOB;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(R < 2 ? ra : rb, (lds_void*)dst, 16, (int)vo, live ? so * 2 : 0, 0, 0);
+    // issued from asm (common.h): the builtin form makes hipcc drain every DMA in flight (vmcnt(0)) before the first
+    // transpose read of each phase of the NN / TN forms
+    lds_dma16_buffer(R < 2 ? ra : rb, vo, live ? (unsigned)(so * 2) : 0u, dst);
   };
   auto stage = [&](auto REG, int tile, int buf) {
     piece(REG, 0, tile, buf);
