@@ -53,7 +53,7 @@ SHAPES = [("NT", 4096, 1280, 1280, 1), ("NT", 4096, 3840, 1280, 1), ("NT", 4096,
 if "--quick" in sys.argv:
     SHAPES = SHAPES[:4] + SHAPES[8:10] + SHAPES[15:18]
 
-print(f"{'shape':34s} {'hipBLASLt':>10s} {'k128':>10s} {'k256':>10s}   (TFLOP/s; err = max|d|/max|ref| of k256 vs fp32 matmul)")
+print(f"{'shape':34s} {'hipBLASLt':>10s} {'k128':>10s} {'k128/23':>10s} {'k256':>10s}   (TFLOP/s; k128/23 = split-K wave groups; err = max|d|/max|ref| of the last one vs hipBLASLt)")
 for form, M, N, K, sk in SHAPES:
     fl = 2.0 * M * N * K
     if form == "NT":
@@ -71,12 +71,12 @@ for form, M, N, K, sk in SHAPES:
     res = {}
     args = (FORMS[form], a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, None, None, 0, sk, st())   # built once: the
     fn = lambda: L.sdxl_op_gemm(*args)                                                                    # launch loop must not be host-bound
-    for mode in (0, 2):
+    for mode in (0, 92, 2):
         lib.check(L.sdxl_set_gemm_mode(mode))
         lib.check(fn())
         res[mode] = bench(fn)
     ref = ob.float()
     err = float((out.float() - ref).abs().max() / ref.abs().max())
-    print(f"{form} {M}x{N}x{K} sk{sk:<3d}".ljust(34) + f" {fl / t_blas / 1e9:10.1f} {fl / res[0] / 1e9:10.1f} {fl / res[2] / 1e9:10.1f}   err {err:.2e}",
+    print(f"{form} {M}x{N}x{K} sk{sk:<3d}".ljust(34) + f" {fl / t_blas / 1e9:10.1f} {fl / res[0] / 1e9:10.1f} {fl / res[92] / 1e9:10.1f} {fl / res[2] / 1e9:10.1f}   err {err:.2e}",
           flush=True)
 lib.check(L.sdxl_set_gemm_mode(1))

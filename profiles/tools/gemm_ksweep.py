@@ -18,7 +18,7 @@ args = [int(a) for a in sys.argv[1:] if a.isdigit()]
 form, M, N = args[:3] if len(args) >= 3 else (0, 4096, 3840)
 r = lambda *s: (torch.randn(*s, device=dev)).to(torch.bfloat16)
 print(f"form {form} M {M} N {N}: us per launch (20 back-to-back)")
-for mode in (0, 2):
+for mode in (0, 92, 2):
     lib.check(L.sdxl_set_gemm_mode(mode))
     row = []
     for K in (64, 128, 256, 512, 1024, 1280, 2560, 5120):
@@ -37,5 +37,5 @@ for mode in (0, 2):
         e1.record()
         torch.cuda.synchronize()
         row.append(f"K={K}: {e0.elapsed_time(e1) / 20 * 1e3:6.1f}")
-    print(f" kernel {'k128' if mode == 0 else 'k256'}: " + "  ".join(row))
+    print(" kernel " + {0: 'k128', 92: 'k128/23', 2: 'k256'}[mode] + ": " + "  ".join(row))
 lib.check(L.sdxl_set_gemm_mode(1))

@@ -48,14 +48,21 @@ static constexpr int gemm_occupancy(int BN, int S, int BK, int NW) {
 //        source is a running pointer (conv: fixed base + uniform offset + border predicate) advanced by a
 //        per-lane constant each K-step (0 for out-of-range rows, which keep pointing at the zero vector), and the DMA
 //        pieces are issued between groups of MFMAs so their issue cost hides under the matrix pipe.
-template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW>
+// KSP  : 8 waves as two GROUPS of 2 x 2 waves with 64 x (BN/2) wave tiles; group g multiplies the g-th 32-deep half of
+//        every K-step (intra-workgroup split-K) and runs one barrier behind group 0, so that on every SIMD one wave
+//        is in its MFMA section (20 MFMAs + the step's DMA pieces) while the other issues its 9 fragment reads and
+//        waits -- the matrix pipe and the LDS path alternate by construction (the 4 x 2 layout of the same tile has all
+//        eight waves read, wait and multiply in lockstep: 0.73 us per K-step of a 128x160 tile against 0.3 at the MFMA
+//        rate).  The two partial accumulator tiles are exchanged through LDS once, after the main loop.
+template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW, bool KSP = false>
 __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_kernel(const GemmP p) {
+  static_assert(!KSP || (NW == 8 && BK == 64 && FAST && S >= 3 && FORM != GEMM_TN), "split-K groups: 8 waves, BK 64, FAST staging, ring >= 3");
   constexpr int BMT = BM;
   constexpr int A_TILE_BYTES = BMT * BK * 2;      // [BMT][BK] or [BK][128] bf16
   constexpr int B_TILE_BYTES = BN * BK * 2;       // [BN][BK] or [BK][BN] bf16
   constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
   constexpr int RING_BYTES = S * STAGE_BYTES;     // followed by 1 KiB that absorbs the padding DMA pieces
-  constexpr int WGM = NW / 2;                     // wave grid WGM x 2
+  constexpr int WGM = KSP ? 2 : NW / 2;           // wave grid WGM x 2 (x 2 K-groups)
   constexpr int MI = BMT / (WGM * 16);            // A fragments per wave (4 or 2)
   constexpr int NJ = BN / 32;                     // B fragments per wave (wave tile (16 MI) x BN/2)
   constexpr int NCA = A_TILE_BYTES / 1024;        // 1 KiB DMA chunks of the A tile
@@ -73,7 +80,8 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int kg = KSP ? wave >> 2 : 0;             // K-group
+  const int wm = KSP ? (wave >> 1) & 1 : wave >> 1, wn = wave & 1;
   const int l16 = lane & 15, g = lane >> 4;
   int bx, by;
   xcd_tile_map(p.xcd_px, bx, by);   // XCD-aware tile order (gemm_tiles.h)
@@ -445,8 +453,8 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
         else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
       }
       if (FAST) {  // one DMA piece per MFMA group
-        constexpr int NSLOT = KS * MI;
-        const int slot = ks * MI + i;
+        constexpr int NSLOT = KSP ? MI : KS * MI;
+        const int slot = KSP ? i : ks * MI + i;
 #pragma unroll
         for (int pc = 0; pc < NL; ++pc)
           if (pc % NSLOT == slot) issue_piece(pc, wslot, live);
@@ -454,6 +462,32 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
     }
     if (!FAST) __builtin_amdgcn_s_setprio(0);
   };
+  if (KSP) {
+    // Global barrier sequence b_0, b_1, ...; group 0 reads its half of step t in the interval before b_2t and multiplies it
+    // between b_2t and b_2t+1, group 1 one interval later.  DMA of step t+S-1 rides in the MFMA section of step t (after
+    // that section's first barrier): its ring slot held step t-1, whose last fragment reads (group 1) were consumed before
+    // b_2t.  A wave's counted vmcnt before its first barrier of step t guarantees its pieces of step t+1 (at most the
+    // steps t+2 .. t+S-2 stay outstanding); every wave has passed such a wait before any wave reads step t+1.
+    wait_vmcnt<(S - 2) * NL>();                       // step 0 landed (mine)
+    __builtin_amdgcn_s_barrier();
+    if (kg == 1) __builtin_amdgcn_s_barrier();        // group 1 runs one barrier behind
+    for (int t = 0; t < T; ++t) {
+      FragK f;
+      read_ks(rd, kg, f);
+      wait_vmcnt<(S - 3) * NL>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+      mfma_ks(f, kg, wr, t + S - 1 < T);
+      __builtin_amdgcn_s_setprio(0);
+      advance();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      rd = rd + 1 == S ? 0 : rd + 1;
+      wr = wr + 1 == S ? 0 : wr + 1;
+    }
+    if (kg == 0) __builtin_amdgcn_s_barrier();        // both groups execute the same number of barriers
+  } else
   // (A register-prefetch variant -- fragments of step t + 1 read while the products of step t run, one ring slot
   // fewer in flight -- was measured on the S >= 3 configurations: 5-20 % slower, so the loop stays as it is.)
   for (int t = 0; t < T; ++t) {
@@ -475,6 +509,30 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
     wr = wr + 1 == S ? 0 : wr + 1;
   }
   wait_vmcnt<0>();   // padding / tail DMA pieces must not outlive the workgroup's LDS allocation
+  if (KSP) {
+    // the two K-groups hold partial sums of the same 64 x (BN/2) wave tiles: each hands the partner the half (two of the
+    // four 16-row fragment rows) the partner finalises, through the ring (now idle) as an fp32 [128][BN + 4] tile
+    __syncthreads();
+    float* X = (float*)smem;
+    // (static fragment indices + a wave-uniform predicate: a runtime index into acc[][] would put the accumulators in scratch)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      if ((i >> 1) == kg) continue;            // rows the partner finalises: give them away
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        *(f32x4*)(X + (wm * 64 + i * 16 + l16) * LDC + wn * (BN / 2) + j * 16 + g * 4) = acc[i][j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      if ((i >> 1) != kg) continue;            // rows this group keeps: add the partner's partial sums
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const f32x4 o = *(const f32x4*)(X + (wm * 64 + i * 16 + l16) * LDC + wn * (BN / 2) + j * 16 + g * 4);
+        acc[i][j][0] += o[0]; acc[i][j][1] += o[1]; acc[i][j][2] += o[2]; acc[i][j][3] += o[3];
+      }
+    }
+  }
   if (FORM == GEMM_TN && do_bias && l16 == 0) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -539,6 +597,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
     if (FORM != GEMM_TN) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // 24 wait states: MFMA results -> inline-asm VALU reads below (XDL write -> VALU read needs up to 18)
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+      if (KSP && (i >> 1) != kg) continue;      // split-K groups: each group finalises two of the four fragment rows
       const int m = m0 + wm * (MI * 16) + i * 16 + l16;
       if (FORM == GEMM_TN) {
         if (m >= p.M) continue;
@@ -593,10 +652,12 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
     const int wrow = wm * (MI * 16);           // this wave's first row in the tile
     if (wrow / 64 == half) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < MI; ++i) {
+        if (KSP && (i >> 1) != kg) continue;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
           *(f32x4*)(Cs + (wrow - half * 64 + i * 16 + l16) * LDC + wn * (BN / 2) + j * 16 + g * 4) = acc[i][j];
+      }
     }
     __syncthreads();
     if (FORM != GEMM_TN && (BN == 128 || BN == 160)) {
@@ -678,26 +739,27 @@ void gemm_defaults(GemmP* p) {
   p->rows_per_batch = 1;
 }
 
-template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW>
+template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW, bool KSP = false>
 static int launch_k(const GemmP& p, hipStream_t st) {
   static bool attr_set = false;
   constexpr int smem = gemm_smem_bytes(BN, S, BK, NW);
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW>,
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW, KSP>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
   dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), FORM == GEMM_TN ? p.taps * p.splitk : 1);
-  hipLaunchKernelGGL((gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW>), grid, dim3(NW * 64), smem, st, p);
+  hipLaunchKernelGGL((gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW, KSP>), grid, dim3(NW * 64), smem, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-template <int FORM, bool CONV, int BN, int S, int BK, int NW>
+template <int FORM, bool CONV, int BN, int S, int BK, int NW, bool KSP = false>
 static int launch_cfg(const GemmP& p, hipStream_t st) {
-  if (!CONV && p.K % BK == 0) return launch_k<FORM, false, BN, S, BK, true, NW>(p, st);
+  constexpr bool KS_OK = KSP && FORM != GEMM_TN;     // (the split-K groups exist for the FAST staging of the NT / NN forms)
+  if (!CONV && p.K % BK == 0) return launch_k<FORM, false, BN, S, BK, true, NW, KS_OK>(p, st);
   // same-size stride-1 3x3 convolutions (all but the two downsamplers, their transposed dgrads and conv_in)
   if (CONV && p.taps == 9 && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws && p.K % BK == 0)
-    return launch_k<FORM, true, BN, S, BK, true, NW>(p, st);
+    return launch_k<FORM, true, BN, S, BK, true, NW, KS_OK>(p, st);
   return launch_k<FORM, CONV, BN, S, BK, false, NW>(p, st);
 }
 
@@ -733,14 +795,21 @@ static int launch_one(const GemmP& p, hipStream_t st) {
   // convs): the 8-wave, 4-deep-ring configuration keeps 3 K-steps of DMA in flight and wins +15..30 % there.  Not for
   // dgrad / wgrad: a one-per-CU workgroup on one stream starves the other stream's kernels of LDS (168 vs 152 ms/step).
   if (FORM == GEMM_NT && n160 && t160 <= 256) cfg = 3;
+  // the same tile with the eight waves as two staggered split-K groups (configuration 23): 10-15 % less time per K-step,
+  // +1.6 us per launch for the exchange of the partial tiles -- long reductions that fit one round
+  // (forward only: in the backward a 145 KiB workgroup evicts the other stream from its CU -- dgrads on it: GEMM family
+  //  -2 ms, step +2.4 ms, profiles/r02c)
+  if (FORM == GEMM_NT && n160 && t160 <= 256 && (long)p.K * p.taps >= 2560) cfg = 23;
   if (g_force_cfg > 0) cfg = g_force_cfg;
-  if (p.geglu && !g80 && (cfg == 3 || cfg == 13)) cfg = 1;   // group-64 packing needs 128-column tiles
-  if (g80 && cfg != 3 && cfg != 13) cfg = 13;                // group-80 packing needs 160-column tiles
-  if ((cfg == 3 || cfg == 13) && p.N % 160 != 0) cfg = 1;
+  if (p.geglu && !g80 && (cfg == 3 || cfg == 13 || cfg == 23)) cfg = 1;   // group-64 packing needs 128-column tiles
+  if (g80 && cfg != 3 && cfg != 13 && cfg != 23) cfg = 13;                 // group-80 packing needs 160-column tiles
+  if ((cfg == 3 || cfg == 13 || cfg == 23) && p.N % 160 != 0) cfg = 1;
+  if (cfg == 23 && FORM == GEMM_TN) cfg = 13;
   if (p.geglu && cfg == 2) cfg = 1;                           // the BK = 32 configuration has no room for the GEGLU staging tile
   switch (cfg) {
     case 2: return launch_cfg<FORM, CONV, 128, 2, 32, 4>(p, st);
     case 3: return launch_cfg<FORM, CONV, 160, 4, 64, 8>(p, st);
+    case 23: return launch_cfg<FORM, CONV, 160, 4, 64, 8, true>(p, st);   // split-K wave groups
     case 13: return launch_cfg<FORM, CONV, 160, 2, 64, 4>(p, st);
     default: return launch_cfg<FORM, CONV, 128, 2, 64, 4>(p, st);
   }

@@ -163,6 +163,37 @@ def test_gemm256_tn_wgrad_bias(g256, M, N, K, splitk):
     report("gemm256 tn =", out, ref, 2e-5 * math.sqrt(K) + 1e-5)
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 160, 64), (128, 160, 128), (256, 320, 192), (4096, 1280, 1280), (1000, 640, 2560), (308, 1280, 2048)])
+def test_gemm_splitk_groups_nt_nn(L, M, N, K):
+    """configuration 23 (8 waves = two K-groups of 2 x 2 waves, staggered by one barrier, partial tiles exchanged through
+    LDS): 1, 2, 3 K-steps exercise the pipeline's prologue / dummy-tail arithmetic; ragged M exercises the row predicates."""
+    lib.check(L.sdxl_set_gemm_mode(4 * 23))
+    try:
+        a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+        bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+        lib.check(L.sdxl_op_gemm(0, ptr(a), ptr(w), ptr(out), M, N, K, ptr(bias), ptr(res), 0, 1, stream()))
+        report(f"gemm cfg23 nt {M}x{N}x{K}", out, a.float() @ w.float().t() + bias.float() + res.float(), 6e-3)
+        wn = rnd(K, N, seed=6, scale=K ** -0.5)
+        base = rnd(M, N, seed=7)
+        out2 = base.clone()
+        lib.check(L.sdxl_op_gemm(1, ptr(a), ptr(wn), ptr(out2), M, N, K, None, None, 1, 1, stream()))
+        report(f"gemm cfg23 nn+= {M}x{N}x{K}", out2, a.float() @ wn.float() + base.float(), 6e-3)
+    finally:
+        lib.check(L.sdxl_set_gemm_mode(1))
+
+
+def test_conv_and_geglu_through_splitk_groups(L):
+    lib.check(L.sdxl_set_gemm_mode(4 * 23))
+    try:
+        test_conv3x3_fwd_dgrad_wgrad(L, 2, 16, 12, 320, 640, 1)
+        test_conv3x3_fwd_dgrad_wgrad(L, 1, 32, 32, 960, 320, 1)
+        _ff_geglu_case(L, 308, 320, 1280, 80)
+        _ff_geglu_case(L, 4096, 1280, 5120, 80)
+    finally:
+        lib.check(L.sdxl_set_gemm_mode(1))
+
+
 def _conv_ref(x_nhwc, w_native, bias, stride):
     """x [B,H,W,Cin], w [Cout][9][Cin] -> y [B,Ho,Wo,Cout] via F.conv2d fp32."""
     cout, _, cin = w_native.shape
