@@ -655,7 +655,7 @@ int sdxl_debug_act_checksums(sdxl_handle* h, unsigned long long* out_host, int c
   for (int i = 0; i < n; ++i) {
     Act* a = p.acts[i].get();
     const bf16* src = grads ? p.G(a) : p.P(a);
-    if (!src) continue;
+    if (!src || a->parent) continue;     // (column-slice views are covered by their parent)
     long cnt = a->rows * a->cols;
     hipLaunchKernelGGL(checksum_kernel, dim3(64), dim3(256), 0, 0, (const unsigned short*)src, cnt, d + i);
   }

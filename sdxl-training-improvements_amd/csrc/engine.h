@@ -24,6 +24,11 @@ struct Act {           // bf16 activation [rows][cols] in the workspace
   long rows = 0;
   int cols = 0;
   bool need_grad = true;
+  // column-slice view of a wider tensor (one block's K | V columns of the grouped cross-attention projection):
+  // data / gradient live inside the parent's buffers, row stride = the parent's width
+  Act* parent = nullptr;
+  int col0 = 0;
+  long ld() const { return parent ? parent->cols : cols; }
 };
 
 struct PRef {  // native parameter: element offset into the bf16 weight arena and the fp32 grad arena
@@ -71,6 +76,7 @@ struct Plan {
   size_t apart_off = NONE, apart_floats = 0;  // query-split partials of the cross-attention dK/dV kernel (main stream)
 
   Act* new_act(long rows, int cols, bool need_grad = true);
+  Act* view(Act* parent, int col0, int cols);   // columns [col0, col0 + cols) of parent
   size_t alloc(size_t bytes);
   // reverse planning.  Gradient buffers are WRITE-ONCE: the first writer of a tensor's gradient gets a fresh buffer,
   // every later writer gets another fresh buffer plus the previous one as addend (out = addend + contribution), so a

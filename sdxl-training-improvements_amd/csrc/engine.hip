@@ -41,8 +41,26 @@ Act* Plan::new_act(long rows, int cols, bool need_grad) {
   acts.emplace_back(a);
   return a;
 }
+Act* Plan::view(Act* parent, int col0, int cols) {
+  Act* a = new Act();
+  a->rows = parent->rows;
+  a->cols = cols;
+  a->need_grad = parent->need_grad;
+  a->parent = parent;
+  a->col0 = col0;
+  a->off = parent->off + (size_t)col0 * sizeof(bf16);
+  acts.emplace_back(a);
+  return a;
+}
 Plan::GradDst Plan::grad_dst(Act* a) {
   GradDst d;
+  if (a->parent) {   // slice of the parent's gradient tensor (allocated by the first slice that asks): written once, by one op
+    if (a->parent->goff == NONE) a->parent->goff = alloc((size_t)a->parent->rows * a->parent->cols * sizeof(bf16));
+    d.addend = a->goff;
+    a->goff = a->parent->goff + (size_t)a->col0 * sizeof(bf16);
+    d.out = a->goff;
+    return d;
+  }
   d.addend = a->goff;
   a->goff = alloc((size_t)a->rows * a->cols * sizeof(bf16));
   d.out = a->goff;
@@ -312,7 +330,7 @@ struct AttnOp : Op {
       a.ldq = a.ldk = a.ldv = 3L * C;
     } else {
       a.Q = p.P(q); a.ldq = C;
-      a.K = p.P(kv); a.V = p.P(kv) + C; a.ldk = a.ldv = 2L * C;
+      a.K = p.P(kv); a.V = p.P(kv) + C; a.ldk = a.ldv = kv->ld();   // (a column slice of the grouped K | V projection)
     }
     a.O = p.P(o); a.ldo = C;
     a.LSE = p.F(lse_off);
@@ -326,7 +344,7 @@ struct AttnOp : Op {
         a.lddq = a.lddk = a.lddv = 3L * C;
       } else {
         a.dQ = p.GP(dq.out); a.lddq = C;
-        a.dK = p.GP(dkv.out); a.dV = a.dK + C; a.lddk = a.lddv = 2L * C;
+        a.dK = p.GP(dkv.out); a.dV = a.dK + C; a.lddk = a.lddv = kv->ld();
       }
     }
   }
@@ -456,6 +474,8 @@ struct Builder {
   int B, H, W, ctx;
   int last_seg = 0;
   Act* emb_act = nullptr;
+  Act* kv_all = nullptr;                     // [B*ctx][sum 2C]: cross-attention K | V of every transformer block
+  std::map<std::string, int> kv_col;        // transformer block prefix -> first column in kv_all
   explicit Builder(Engine& e_, Plan* p_) : e(e_), pl(p_) {
     if (pl) { B = pl->B; H = pl->H; W = pl->W; ctx = pl->ctx; } else { B = H = W = ctx = 0; }
   }
@@ -553,8 +573,9 @@ struct Builder {
     Act* x1 = linear(b + ".attn1.to_out.0", a1, C, C, true, x);
     Act* l2 = layernorm(b + ".norm2", x1, C);
     Act* q = linear(b + ".attn2.to_q", l2, C, C, false, nullptr);
-    Act* kv = linear_fused({b + ".attn2.to_k", b + ".attn2.to_v"}, ehs, cross, C);
-    if (pl) pl->ops.back()->hoist_fwd = true;
+    // K | V of the prompt embeddings: this block's 2C columns of the grouped projection (one GEMM for all blocks, run())
+    Act* kv = pl ? pl->view(kv_all, kv_col.at(b), 2 * C) : nullptr;
+    (void)cross;
     Act* a2 = nullptr;
     if (pl) {
       a2 = pl->new_act(x->rows, C);
@@ -596,6 +617,40 @@ struct Builder {
       pl->tid_off = pl->alloc(sizeof(float) * B * 6);
       pl->loss_off = pl->alloc(sizeof(float) * 8);
       tagseg(pl->add<EmbedInOp>(), PRef());
+    }
+    {
+      // Cross-attention K / V projections of ALL transformer blocks as ONE GEMM: they share the A operand (the prompt
+      // embeddings, [B*77][2048]) and depend on nothing else, so the 70 per-block launches (M = 308 rows: 119 TFLOP/s each)
+      // become one [308] x [sum 2C = 166 400] x [2048] problem on the side stream at the start of the forward, and their 70
+      // weight-gradient launches one TN GEMM at the end of the backward.  The weights are therefore registered first,
+      // contiguously (the arena's first segment); every block's attention reads / writes its column slice of the result.
+      std::vector<std::pair<std::string, int>> blocks;
+      auto add_tf = [&](const std::string& p, int C, int depth) {
+        for (int k = 0; k < depth; ++k) blocks.emplace_back(p + ".transformer_blocks." + std::to_string(k), C);
+      };
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < c.layers_per_block; ++j)
+          if (c.transformer_layers[i] > 0) add_tf("down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), ch[i], c.transformer_layers[i]);
+      add_tf("mid_block.attentions.0", ch[2], c.transformer_layers[2]);
+      for (int ui = 0; ui < 3; ++ui)
+        for (int j = 0; j < c.layers_per_block + 1; ++j)
+          if (c.transformer_layers[2 - ui] > 0) add_tf("up_blocks." + std::to_string(ui) + ".attentions." + std::to_string(j), ch[2 - ui], c.transformer_layers[2 - ui]);
+      long ntot = 0;
+      for (auto& b : blocks) ntot += 2L * b.second;
+      const int cross = c.cross_attention_dim;
+      PRef wkv = e.param((size_t)ntot * cross);
+      long col = 0;
+      for (auto& b : blocks) {
+        e.map_src(b.first + ".attn2.to_k.weight", {b.second, cross}, wkv, 0, (size_t)col * cross, 0);
+        e.map_src(b.first + ".attn2.to_v.weight", {b.second, cross}, wkv, 0, (size_t)(col + b.second) * cross, 0);
+        kv_col[b.first] = (int)col;
+        col += 2L * b.second;
+      }
+      if (pl) {
+        kv_all = pl->new_act((long)B * ctx, (int)ntot);
+        LinearOp* op = tagseg(pl->add<LinearOp>(ehs, kv_all, wkv, PRef(), cross, (int)ntot, nullptr), wkv);
+        op->hoist_fwd = true;
+      }
     }
     Act* t1 = linear("time_embedding.linear_1", te_sin, ch[0], temb, true, nullptr);
     Act* t1s = silu(t1);
