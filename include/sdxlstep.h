@@ -108,6 +108,13 @@ int sdxl_set_join_mode(sdxl_handle* h, int last_only);
 /* convenience: forward + all backward segments */
 int sdxl_loss_fwd_bwd(sdxl_handle* h, const sdxl_loss_config* lc, const sdxl_batch* b, float grad_scale,
                       int first_micro, void* stream);
+/* every backward segment in one call (what a caller without a per-segment gradient exchange uses: one captured graph) */
+int sdxl_backward_all(sdxl_handle* h, float grad_scale, int first_micro, void* stream);
+/* hipGraph replay of forward / backward (default OFF: measured slower than eager two-stream launches on ROCm 7.2, see
+ * DESIGN.md): the second call with a given (plan, loss configuration, first_micro,
+ * grad_scale) captures the launch sequence of both streams, later calls replay it with one hipGraphLaunch.  0 = launch
+ * kernel by kernel.  Inputs are staged at fixed addresses inside the plan, so the caller's tensors may move between steps. */
+int sdxl_set_graph_mode(sdxl_handle* h, int on);
 /* synchronises `stream`; out[0]=loss out[1]=sum w*(pred-target)^2 out[2]=sum|pred| out[3]=sum pred^2
  * out[4]=sum|noise| out[5]=sum noise^2 (x0) out[6]=sum latents^2 (x1) out[7]=gradient gate */
 int sdxl_read_loss(sdxl_handle* h, float out[8], void* stream);

@@ -1,6 +1,7 @@
 // extern "C" surface of libsdxlstep (see include/sdxlstep.h for the contract of every entry point).
 #include <math.h>
 #include "engine.h"
+#include <functional>
 
 #include <stdlib.h>
 
@@ -64,6 +65,9 @@ int sdxl_create(const sdxl_unet_config* cfg, int device, sdxl_handle** out) {
   h->e.use_side = !(ns && ns[0] == '1');              // durations for the serialized rocprof summaries under profiles/)
   if (h->e.use_side) {
     HIP_CHECK_RET(hipStreamCreateWithFlags(&h->e.side, hipStreamNonBlocking));   // (stream priorities: measured, neutral)
+    HIP_CHECK_RET(hipStreamCreateWithFlags(&h->e.gstream, hipStreamNonBlocking));
+    HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_gin, hipEventDisableTiming));
+    HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_gout, hipEventDisableTiming));
     HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_join, hipEventDisableTiming));
     HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_hoist, hipEventDisableTiming));
   }
@@ -76,6 +80,10 @@ int sdxl_destroy(sdxl_handle* h) {
   if (h->e.own_weights && h->e.weights) (void)hipFree(h->e.weights);
   if (h->e.own_grads && h->e.grads) (void)hipFree(h->e.grads);
   if (h->e.own_ws && h->e.ws) (void)hipFree(h->e.ws);
+  h->e.clear_graphs();
+  if (h->e.gstream) (void)hipStreamDestroy(h->e.gstream);
+  if (h->e.ev_gin) (void)hipEventDestroy(h->e.ev_gin);
+  if (h->e.ev_gout) (void)hipEventDestroy(h->e.ev_gout);
   for (hipEvent_t ev : h->e.ev_pool) (void)hipEventDestroy(ev);
   if (h->e.ev_join) (void)hipEventDestroy(h->e.ev_join);
   if (h->e.ev_hoist) (void)hipEventDestroy(h->e.ev_hoist);
@@ -95,6 +103,7 @@ int sdxl_param_bytes(sdxl_handle* h, size_t* wb, size_t* gb) {
 int sdxl_bind_params(sdxl_handle* h, void* w, void* g) {
   H_CHECK(h);
   Engine& e = h->e;
+  e.clear_graphs();                                   // captured kernels hold the old arena addresses
   if (w) { e.weights = (bf16*)w; e.own_weights = false; }
   else {
     HIP_CHECK_RET(hipMalloc((void**)&e.weights, e.param_elems * sizeof(bf16)));
@@ -174,12 +183,15 @@ int sdxl_bind_workspace(sdxl_handle* h, void* ws, size_t bytes) {
   H_CHECK(h);
   Engine& e = h->e;
   if (ws) {
+    if (ws == (void*)e.ws && bytes == e.ws_cap) return 0;     // unchanged: captured graphs stay valid
+    e.clear_graphs();
     if (e.own_ws && e.ws) (void)hipFree(e.ws);
     e.ws = (char*)ws; e.ws_cap = bytes; e.own_ws = false;
   } else {
     size_t need = bytes;
     for (auto& kv : e.plans) if (kv.second->ws_bytes > need) need = kv.second->ws_bytes;
     if (e.own_ws && e.ws && e.ws_cap >= need) return 0;
+    e.clear_graphs();
     if (e.own_ws && e.ws) (void)hipFree(e.ws);
     HIP_CHECK_RET(hipMalloc((void**)&e.ws, need));
     e.ws_cap = need; e.own_ws = true;
@@ -256,6 +268,44 @@ static void fill_loss(Engine& e, const sdxl_loss_config* lc, const sdxl_batch* b
 }
 
 
+// run `body(stream)` once eagerly (first call for a key: one-time function attributes), capture it on the second call, replay
+// the instantiated graph from then on; everything on the engine's graph stream, fenced against the caller's stream
+static int run_graphed(Engine& e, Engine::GraphKey key, hipStream_t user, const std::function<int(hipStream_t)>& body) {
+  if (!e.use_graphs || !e.gstream || gemm_profiling()) return body(user);
+  Engine::GraphEntry& g = e.graphs[key];
+  hipStream_t gs = e.gstream;
+  HIP_CHECK_RET(hipEventRecord(e.ev_gin, user));
+  HIP_CHECK_RET(hipStreamWaitEvent(gs, e.ev_gin, 0));
+  if (g.exec) {
+    HIP_CHECK_RET(hipGraphLaunch(g.exec, gs));
+  } else if (g.seen++ == 0) {
+    CHK(body(gs));
+  } else {
+    HIP_CHECK_RET(hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal));
+    const int rc = body(gs);
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(gs, &graph);
+    if (rc || ce != hipSuccess) {
+      if (graph) (void)hipGraphDestroy(graph);
+      if (rc) return rc;
+      sdxl_set_error("hipStreamEndCapture: %s", hipGetErrorString(ce));
+      return 2;
+    }
+    HIP_CHECK_RET(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    HIP_CHECK_RET(hipGraphLaunch(g.exec, gs));
+  }
+  HIP_CHECK_RET(hipEventRecord(e.ev_gout, gs));
+  HIP_CHECK_RET(hipStreamWaitEvent(user, e.ev_gout, 0));
+  return 0;
+}
+static unsigned loss_cfg_bits(const sdxl_loss_config& lc, bool tag) {
+  unsigned g;
+  memcpy(&g, &lc.min_snr_gamma, 4);
+  return (unsigned)lc.method | ((unsigned)lc.prediction_type << 2) | ((unsigned)lc.use_min_snr << 4) | ((unsigned)lc.use_ztsnr << 5) |
+         ((unsigned)tag << 6) | (g << 7);
+}
+
 static int run_forward_ops(Engine& e, hipStream_t st) {
   Plan& p = *e.cur;
   const bool side = e.use_side && e.side && !gemm_profiling();
@@ -287,12 +337,29 @@ int sdxl_forward_loss(sdxl_handle* h, const sdxl_loss_config* lc, const sdxl_bat
   CHK(check_batch(e, b));
   ARG_CHECK(b->latents && b->noise && b->sigma_or_t, "batch is missing latents/noise/sigma");
   CHK(upload_cond(e, b, st));
+  // the step's inputs are staged at fixed addresses inside the plan (the caller's tensors move from step to step; the captured
+  // kernels must not)
+  Plan& p = *e.cur;
+  sdxl_batch sb = *b;
+  if (e.use_graphs) {
+    const size_t nlat = sizeof(float) * (size_t)p.B * 4 * p.H * p.W;
+    HIP_CHECK_RET(hipMemcpyAsync(p.F(p.in_lat_off), b->latents, nlat, hipMemcpyDeviceToDevice, st));
+    HIP_CHECK_RET(hipMemcpyAsync(p.F(p.in_noise_off), b->noise, nlat, hipMemcpyDeviceToDevice, st));
+    HIP_CHECK_RET(hipMemcpyAsync(p.F(p.in_sig_off), b->sigma_or_t, sizeof(float) * p.B, hipMemcpyDeviceToDevice, st));
+    if (b->tag_weights) HIP_CHECK_RET(hipMemcpyAsync(p.F(p.in_tag_off), b->tag_weights, sizeof(float) * p.B, hipMemcpyDeviceToDevice, st));
+    sb.latents = p.F(p.in_lat_off); sb.noise = p.F(p.in_noise_off); sb.sigma_or_t = p.F(p.in_sig_off);
+    sb.tag_weights = b->tag_weights ? p.F(p.in_tag_off) : nullptr;
+  }
   LossP L;
-  fill_loss(e, lc, b, 1.f, L);
-  CHK(launch_loss_prepare(L, st));
-  CHK(run_forward_ops(e, st));
-  CHK(launch_loss_fwd(L, st));
-  h->step.lc = *lc; h->step.b = *b; h->step.valid = true;
+  fill_loss(e, lc, &sb, 1.f, L);
+  Engine::GraphKey key{&p, 0, 0, 0, 0, 0u, loss_cfg_bits(*lc, b->tag_weights != nullptr)};
+  CHK(run_graphed(e, key, st, [&](hipStream_t s) -> int {
+    CHK(launch_loss_prepare(L, s));
+    CHK(run_forward_ops(e, s));
+    CHK(launch_loss_fwd(L, s));
+    return 0;
+  }));
+  h->step.lc = *lc; h->step.b = sb; h->step.valid = true;
   return 0;
 }
 
@@ -320,9 +387,10 @@ static int run_backward_segment(Engine& e, int k, bool first, hipStream_t st) {
   // the segment's weight gradients are complete once `st` passes this point -- unless the caller declared (sdxl_set_join_mode)
   // that it only needs that of the whole backward (no per-segment gradient exchange): then the side stream runs free
   // until the last segment (nothing on the main stream reads a weight gradient, and no gradient buffer is reused)
-  if (e.use_side && e.side && !(e.join_last_only && k != e.nseg - 1)) {
+  if (e.side_dirty && !(e.join_last_only && k != e.nseg - 1)) {
     HIP_CHECK_RET(hipEventRecord(e.ev_join, e.side));
     HIP_CHECK_RET(hipStreamWaitEvent(st, e.ev_join, 0));
+    e.side_dirty = false;
   }
   return 0;
 }
@@ -333,20 +401,51 @@ int sdxl_backward_segment(sdxl_handle* h, int k, float grad_scale, int first_mic
   hipStream_t st = (hipStream_t)stp;
   CHK(ready(e));
   ARG_CHECK(k >= 0 && k < e.nseg, "segment %d out of range", k);
-  if (k == 0) {
-    ARG_CHECK(h->step.valid, "sdxl_backward_segment(0) needs a preceding sdxl_forward_loss");
+  if (k == 0) ARG_CHECK(h->step.valid, "sdxl_backward_segment(0) needs a preceding sdxl_forward_loss");
+  auto body = [&](hipStream_t s) -> int {
+    if (k == 0) {
+      LossP L;
+      fill_loss(e, &h->step.lc, &h->step.b, grad_scale, L);
+      CHK(launch_loss_bwd(L, s));
+    }
+    return run_backward_segment(e, k, first_micro != 0, s);
+  };
+  // a segment can only be captured on its own when it ends with the side stream joined (per-segment join mode, or the last one)
+  if (e.join_last_only) return body(st);
+  unsigned sbits;
+  memcpy(&sbits, &grad_scale, 4);
+  Engine::GraphKey key{e.cur, 1, k, first_micro != 0, 0, sbits, loss_cfg_bits(h->step.lc, h->step.b.tag_weights != nullptr)};
+  return run_graphed(e, key, st, body);
+}
+
+int sdxl_backward_all(sdxl_handle* h, float grad_scale, int first_micro, void* stp) {
+  H_CHECK(h);
+  Engine& e = h->e;
+  hipStream_t st = (hipStream_t)stp;
+  CHK(ready(e));
+  ARG_CHECK(h->step.valid, "sdxl_backward_all needs a preceding sdxl_forward_loss");
+  unsigned sbits;
+  memcpy(&sbits, &grad_scale, 4);
+  Engine::GraphKey key{e.cur, 2, 0, first_micro != 0, e.join_last_only, sbits, loss_cfg_bits(h->step.lc, h->step.b.tag_weights != nullptr)};
+  return run_graphed(e, key, st, [&](hipStream_t s) -> int {
     LossP L;
     fill_loss(e, &h->step.lc, &h->step.b, grad_scale, L);
-    CHK(launch_loss_bwd(L, st));
-  }
-  return run_backward_segment(e, k, first_micro != 0, st);
+    CHK(launch_loss_bwd(L, s));
+    for (int k = 0; k < e.nseg; ++k) CHK(run_backward_segment(e, k, first_micro != 0, s));
+    return 0;
+  });
+}
+int sdxl_set_graph_mode(sdxl_handle* h, int on) {
+  H_CHECK(h);
+  h->e.use_graphs = on != 0 && h->e.use_side;
+  if (!h->e.use_graphs) h->e.clear_graphs();
+  return 0;
 }
 
 int sdxl_loss_fwd_bwd(sdxl_handle* h, const sdxl_loss_config* lc, const sdxl_batch* b, float grad_scale,
                       int first_micro, void* st) {
   CHK(sdxl_forward_loss(h, lc, b, st));
-  for (int k = 0; k < h->e.nseg; ++k) CHK(sdxl_backward_segment(h, k, grad_scale, first_micro, st));
-  return 0;
+  return sdxl_backward_all(h, grad_scale, first_micro, st);
 }
 
 int sdxl_read_loss(sdxl_handle* h, float out[8], void* stp) {

@@ -85,6 +85,7 @@ static int on_side(Plan& p, hipStream_t main, F&& fn) {
   if (!ev) { sdxl_set_error("hipEventCreate failed"); return 2; }
   HIP_CHECK_RET(hipEventRecord(ev, main));
   HIP_CHECK_RET(hipStreamWaitEvent(e.side, ev, 0));
+  e.side_dirty = true;
   return fn(e.side);
 }
 bool Plan::grad_alias(Act* x, Act* y) {
@@ -616,6 +617,10 @@ struct Builder {
       pl->t_off = pl->alloc(sizeof(float) * B);
       pl->tid_off = pl->alloc(sizeof(float) * B * 6);
       pl->loss_off = pl->alloc(sizeof(float) * 8);
+      pl->in_lat_off = pl->alloc(sizeof(float) * (size_t)B * 4 * H * W);
+      pl->in_noise_off = pl->alloc(sizeof(float) * (size_t)B * 4 * H * W);
+      pl->in_sig_off = pl->alloc(sizeof(float) * B);
+      pl->in_tag_off = pl->alloc(sizeof(float) * B);
       tagseg(pl->add<EmbedInOp>(), PRef());
     }
     {

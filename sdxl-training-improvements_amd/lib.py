@@ -63,6 +63,8 @@ SIGNATURES = {
     "sdxl_segment_range": [_vp, _i, _P(_sz), _P(_sz)],
     "sdxl_backward_segment": [_vp, _i, _f, _i, _vp],
     "sdxl_loss_fwd_bwd": [_vp, _P(LossConfig), _P(Batch), _f, _i, _vp],
+    "sdxl_backward_all": [_vp, _f, _i, _vp],
+    "sdxl_set_graph_mode": [_vp, _i],
     "sdxl_read_loss": [_vp, _P(_f), _vp],
     "sdxl_unet_forward": [_vp, _vp, _P(Batch), _vp, _vp],
     "sdxl_unet_backward": [_vp, _vp, _i, _vp],

@@ -219,11 +219,18 @@ class NativeUNet:
         """All backward segments in reverse execution order; `on_segment(k, offset, count)` is called after segment
         k's kernels are enqueued (used to start that bucket's gradient all-reduce under the rest of backward)."""
         lib.check(self.L.sdxl_set_join_mode(self.h, 0 if on_segment is not None else 1))   # per-segment results needed?
+        if on_segment is None and hasattr(self.L, "sdxl_backward_all"):     # no per-segment exchange: one call for the whole backward
+            lib.check(self.L.sdxl_backward_all(self.h, float(grad_scale), int(first_micro), _stream()), "backward")
+            return
         for k in range(self.num_segments):
             lib.check(self.L.sdxl_backward_segment(self.h, k, float(grad_scale), int(first_micro), _stream()),
                       f"backward segment {k}")
             if on_segment is not None:
                 on_segment(k, *self.segment_range(k))
+
+    def set_graph_mode(self, on: bool) -> None:
+        """hipGraph replay of forward / backward (default off: eager two-stream launches measured faster on ROCm 7.2)."""
+        lib.check(self.L.sdxl_set_graph_mode(self.h, int(bool(on))))
 
     def read_loss(self):
         out = (C.c_float * 8)()

@@ -190,3 +190,36 @@ def test_forward_is_bitwise_reproducible(tiny):
     t = torch.tensor([3.0, 900.0])
     outs = [net.unet_forward(x["lat"], t, x["ehs"], x["pooled"], x["tid"]) for _ in range(3)]
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_graph_replay_equals_eager_launches(tiny):
+    """The captured step (hipGraph of both streams; first call eager, second captured, third replayed) gives the bits of the
+    kernel-by-kernel launch sequence, for inputs that change (and move) from step to step, whole-backward and per-segment."""
+    cfg, w, net = tiny
+    B, H, W = 2, 16, 24
+    ts = torch.tensor([250, 770])
+    sig = R.karras_sigmas()[ts]
+    names = ["down_blocks.1.attentions.0.transformer_blocks.0.attn2.to_k.weight", "mid_block.resnets.0.conv1.weight",
+             "conv_in.weight", "up_blocks.1.resnets.0.conv2.bias", "time_embedding.linear_1.weight"]
+    xs = [make_inputs(cfg, B, H, W, seed=50 + i) for i in range(4)]
+
+    def run(per_segment):
+        out = []
+        for x in xs:
+            net.zero_grads()
+            net.forward_loss("ddpm", x["lat"].clone(), x["noise"].clone(), sig.clone(), ts.float(), x["ehs"], x["pooled"], x["tid"])
+            net.backward(1.0, True, on_segment=(lambda k, off, n: None) if per_segment else None)
+            out.append((net.read_loss()[0], {k: net.export(k, grad=True) for k in names}))
+        return out
+
+    for per_segment in (False, True):
+        net.set_graph_mode(False)
+        eager = run(per_segment)
+        net.set_graph_mode(True)
+        graphed = run(per_segment)
+        net.set_graph_mode(False)
+        for (le, ge), (lg, gg) in zip(eager, graphed):
+            assert abs(le - lg) <= 1e-6 * abs(le)        # the loss sum's cross-block fp32 atomics
+            for k in names:       # split-K fp32 atomics may reorder the last bits of a weight gradient, nothing else
+                assert float((ge[k] - gg[k]).norm() / ge[k].norm()) <= 1e-5, k
+    assert len({l for l, _ in graphed}) == len(xs)      # the replays did see the new inputs
