@@ -387,6 +387,7 @@ static int run_backward_segment(Engine& e, int k, bool first, hipStream_t st) {
   // the segment's weight gradients are complete once `st` passes this point -- unless the caller declared (sdxl_set_join_mode)
   // that it only needs that of the whole backward (no per-segment gradient exchange): then the side stream runs free
   // until the last segment (nothing on the main stream reads a weight gradient, and no gradient buffer is reused)
+  CHK(e.flush_ln_params(p, st));
   if (e.side_dirty && !(e.join_last_only && k != e.nseg - 1)) {
     HIP_CHECK_RET(hipEventRecord(e.ev_join, e.side));
     HIP_CHECK_RET(hipStreamWaitEvent(st, e.ev_join, 0));
@@ -628,8 +629,18 @@ int sdxl_op_layernorm_fwd(const void* x, void* y, const void* gamma, const void*
 }
 int sdxl_op_layernorm_bwd(const void* x, const void* dy, const void* gamma, const float* stats, void* dx, float* dgamma,
                           float* dbeta, int M, int C, int accumulate, void* st) {
-  return launch_layernorm_bwd((const bf16*)x, (const bf16*)dy, (const bf16*)gamma, stats, (bf16*)dx,
-                              accumulate ? (const bf16*)dx : nullptr, dgamma, dbeta, M, C, (hipStream_t)st);
+  if (!dgamma)
+    return launch_layernorm_bwd((const bf16*)x, (const bf16*)dy, (const bf16*)gamma, stats, (bf16*)dx,
+                                accumulate ? (const bf16*)dx : nullptr, nullptr, nullptr, M, C, (hipStream_t)st);
+  ARG_CHECK(dbeta, "layernorm bwd: dgamma and dbeta go together");
+  LnRedBatch b;
+  b.n = 1;
+  float* part;
+  CHK(test_slab(layernorm_bwd_part_floats(M, C), &part));
+  b.e[0].part = part; b.e[0].dgamma = dgamma; b.e[0].dbeta = dbeta; b.e[0].C = C;
+  CHK(launch_layernorm_bwd((const bf16*)x, (const bf16*)dy, (const bf16*)gamma, stats, (bf16*)dx,
+                           accumulate ? (const bf16*)dx : nullptr, part, &b.e[0].nblk, M, C, (hipStream_t)st));
+  return launch_ln_param_reduce(b, (hipStream_t)st);
 }
 int sdxl_op_ff_geglu_fwd(const void* x, const void* w1, const void* b1, void* u, void* g, int M, int K, int C4, int group,
                          void* st) {

@@ -124,6 +124,8 @@ struct Engine {
   bool use_side = true;
   bool join_last_only = false;   // sdxl_set_join_mode: main waits for the side stream at the last segment only
   hipEvent_t next_event();
+  std::vector<LnRedEntry> ln_pending;     // LayerNorm backward launches whose dgamma | dbeta partials are not reduced yet
+  int flush_ln_params(Plan& p, hipStream_t main);
   bool side_dirty = false;       // the side stream has work the caller's stream has not joined yet
   // hipGraph replay of the step (sdxl_set_graph_mode, OFF by default): forward (+ loss) and backward are captured once per
   // (plan, configuration) -- both streams, every event edge -- and replayed with one hipGraphLaunch, on an engine-owned

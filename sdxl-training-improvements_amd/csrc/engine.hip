@@ -88,6 +88,18 @@ static int on_side(Plan& p, hipStream_t main, F&& fn) {
   e.side_dirty = true;
   return fn(e.side);
 }
+// dgamma / dbeta of the LayerNorms since the last call: one reduce launch per LN_RED_MAX of them, on the side stream
+int Engine::flush_ln_params(Plan& p, hipStream_t main) {
+  size_t i = 0;
+  while (i < ln_pending.size()) {
+    LnRedBatch b;
+    b.n = 0;
+    while (i < ln_pending.size() && b.n < LN_RED_MAX) b.e[b.n++] = ln_pending[i++];
+    CHK(on_side(p, main, [&b](hipStream_t s2) -> int { return launch_ln_param_reduce(b, s2); }));
+  }
+  ln_pending.clear();
+  return 0;
+}
 bool Plan::grad_alias(Act* x, Act* y) {
   if (x->goff == NONE) {
     x->goff = y->goff;
@@ -291,7 +303,7 @@ struct LayerNormOp : Op {
   PRef gm, bt;
   int C;
   float eps;
-  size_t stats_off;
+  size_t stats_off, part_off = NONE;
   size_t dy_off = NONE;
   Plan::GradDst dx;
   LayerNormOp(Plan& p, Act* x_, Act* y_, PRef g_, PRef b_, int C_, float eps_) : x(x_), y(y_), gm(g_), bt(b_), C(C_), eps(eps_) {
@@ -300,11 +312,20 @@ struct LayerNormOp : Op {
   int fwd(Plan& p, hipStream_t st) override {
     return launch_layernorm_fwd(p.P(x), p.P(y), p.eng->Wp(gm), p.eng->Wp(bt), p.F(stats_off), (int)x->rows, C, eps, st);
   }
-  void plan_bwd(Plan& p) override { dy_off = y->goff; dx = p.grad_dst(x); }
+  void plan_bwd(Plan& p) override {
+    dy_off = y->goff;
+    dx = p.grad_dst(x);
+    part_off = p.alloc(sizeof(float) * layernorm_bwd_part_floats((int)x->rows, C));   // own buffer: reduced at the segment's end
+  }
   int bwd(Plan& p, hipStream_t st, bool) override {
-    // dx and the dgamma / dbeta column sums in one pass (norm.hip)
-    return launch_layernorm_bwd(p.P(x), p.GP(dy_off), p.eng->Wp(gm), p.F(stats_off), p.GP(dx.out), p.GP(dx.addend),
-                                p.eng->Gp(gm), p.eng->Gp(bt), (int)x->rows, C, st);
+    // dx and the per-block dgamma | dbeta partial sums in one pass (norm.hip); the partials of all LayerNorms of the segment
+    // are folded into the gradients by one launch at its end (Engine::flush_ln_params)
+    LnRedEntry r;
+    r.part = p.F(part_off); r.dgamma = p.eng->Gp(gm); r.dbeta = p.eng->Gp(bt); r.C = C;
+    CHK(launch_layernorm_bwd(p.P(x), p.GP(dy_off), p.eng->Wp(gm), p.F(stats_off), p.GP(dx.out), p.GP(dx.addend),
+                             p.F(part_off), &r.nblk, (int)x->rows, C, st));
+    p.eng->ln_pending.push_back(r);
+    return 0;
   }
 };
 

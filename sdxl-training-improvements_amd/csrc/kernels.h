@@ -115,13 +115,15 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const
 // LayerNorm over rows of [M][C]; stats [M][2] = mean, rstd
 int launch_layernorm_fwd(const bf16* x, bf16* y, const bf16* gamma, const bf16* beta, float* stats, int M,
                          int C, float eps, hipStream_t st);
+// dx = (addend ? addend : 0) + grad; with `part` (layernorm_bwd_part_floats(M, C) floats) also the per-block partial sums of
+// dgamma | dbeta, which launch_ln_param_reduce folds into the fp32 gradients (+=) for a whole batch of LayerNorms at once
+size_t layernorm_bwd_part_floats(int M, int C);
 int launch_layernorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const float* stats, bf16* dx,
-                         const bf16* addend, float* dgamma, float* dbeta, int M, int C, hipStream_t st);
-// the two halves of the above: dx on the critical path, the parameter gradients (a leaf) wherever there is room
-int launch_layernorm_bwd_dx(const bf16* x, const bf16* dy, const bf16* gamma, const float* stats, bf16* dx,
-                            const bf16* addend, int M, int C, hipStream_t st);
-int launch_layernorm_bwd_params(const bf16* x, const bf16* dy, const float* stats, float* dgamma, float* dbeta, int M,
-                                int C, hipStream_t st);
+                         const bf16* addend, float* part, int* nblk_out, int M, int C, hipStream_t st);
+#define LN_RED_MAX 64
+struct LnRedEntry { const float* part; float* dgamma; float* dbeta; int nblk, C; };
+struct LnRedBatch { LnRedEntry e[LN_RED_MAX]; int n; };   // passed by value as the kernel argument (2 KiB)
+int launch_ln_param_reduce(const LnRedBatch& b, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
 // elementwise / small (elementwise.hip)

@@ -421,13 +421,15 @@ int launch_layernorm_fwd(const bf16* x, bf16* y, const bf16* gamma, const bf16* 
 // backward: dx (same geometry as forward, whole row in registers) and -- PARAMS -- the dgamma / dbeta column sums of the
 // rows this block handles, from the values it already holds (the separate column-sum pass re-read x and dy: 2.8 ms per
 // step).  A block walks ITER groups of 256 / LPR rows; per 8-column vector the per-row products are summed over the rows of
-// a wave with lane shuffles, over the 4 waves through LDS, and one fp32 atomicAdd per column and block goes to dgamma / dbeta
-// (these small-parameter gradients are accumulated with atomics everywhere and zeroed per cycle, sdxl_zero_grads).
+// a wave with lane shuffles, over the 4 waves through LDS, and the block stores its 2 x C partial sums to part[block]
+// (plain coalesced stores).  ln_param_reduce_kernel folds the partials of many LayerNorms into dgamma / dbeta later, off
+// the critical path.  (One fp32 atomicAdd per column and block straight to dgamma / dbeta -- 655k device-scope atomics per
+// launch at M = 4096, C = 1280, each a fabric transaction -- cost more than the whole dx pass: 16.3 us vs 7.0 us, r02
+// profiles/tools/ln_bench.py.)
 template <int NV, int LPR, bool ACC, bool PARAMS>
 __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                  const bf16* __restrict__ gamma, const float* __restrict__ stats,
-                                 bf16* dx, const bf16* addend, float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
-                                 int iters) {
+                                 bf16* dx, const bf16* addend, float* __restrict__ part, int M, int iters) {
   constexpr int C = NV * LPR * 8;
   constexpr int RPB = 256 / LPR;                     // rows per block and iteration
   __shared__ float red[PARAMS ? 4 : 1][2][PARAMS ? C : 8];
@@ -511,10 +513,31 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16* __restrict__
   }
   if (!PARAMS) return;
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    atomicAdd(dgamma + c, red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c]);
-    atomicAdd(dbeta + c, red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c]);
+  float* out = part + (size_t)blockIdx.x * 2 * C;          // [dgamma partial | dbeta partial]
+  const float* r0 = &red[0][0][0];
+  for (int c = threadIdx.x * 4; c < 2 * C; c += 1024) {
+    f32x4 a = *(const f32x4*)(r0 + c), b = *(const f32x4*)(r0 + 2 * C + c), cc = *(const f32x4*)(r0 + 4 * C + c),
+          d = *(const f32x4*)(r0 + 6 * C + c);
+    *(f32x4*)(out + c) = (a + b) + (cc + d);
   }
+}
+
+// dgamma / dbeta += the block partials of up to LN_RED_MAX LayerNorm backward launches.  grid (column chunk of 256 over
+// [dgamma | dbeta], row chunk, entry): a thread sums its chunk of partials of one column and adds the result with one atomic.
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const LnRedBatch b) {
+  const LnRedEntry e = b.e[blockIdx.z];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= 2 * e.C) return;
+  const int per = (e.nblk + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = min(e.nblk, r0 + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const float* p = e.part + (size_t)r0 * 2 * e.C + c;
+  int r = r0;
+  for (; r + 4 <= r1; r += 4, p += (size_t)8 * e.C) {
+    s0 += p[0]; s1 += p[(size_t)2 * e.C]; s2 += p[(size_t)4 * e.C]; s3 += p[(size_t)6 * e.C];
+  }
+  for (; r < r1; ++r, p += (size_t)2 * e.C) s0 += p[0];
+  if (r1 > r0) atomicAdd((c < e.C ? e.dgamma : e.dbeta - e.C) + c, (s0 + s1) + (s2 + s3));
 }
 
 // backward, dgamma/dbeta: column-oriented (thread = fixed 8-column vector, 8 row lanes per block,
@@ -572,27 +595,41 @@ static void col_reduce_geom(int M, int C, dim3* grid, int* rows_per_chunk) {
   *grid = dim3(colblocks, cdiv(M, *rows_per_chunk));
 }
 
-static int ln_bwd_launch(const bf16* x, const bf16* dy, const bf16* gamma, const float* stats, bf16* dx, const bf16* addend,
-                         float* dgamma, float* dbeta, int M, int C, hipStream_t st) {
+// row groups of 256 / LPR rows per block: >= 512 blocks where the tensor allows (the partial sums are cheap to store)
+static void ln_bwd_geometry(int M, int C, int* lpr, int* iters, int* nblk) {
+  *lpr = (C % 256 == 0 && C >= 1024) ? 32 : 16;
+  const int rpb = 256 / *lpr;
+  int it = M / (rpb * 512);
+  it = it < 1 ? 1 : (it > 4 ? 4 : it);
+  *iters = it;
+  *nblk = cdiv(M, rpb * it);
+}
+size_t layernorm_bwd_part_floats(int M, int C) {
+  int lpr, iters, nblk;
+  ln_bwd_geometry(M, C, &lpr, &iters, &nblk);
+  return (size_t)nblk * 2 * C;
+}
+// dx, and with `part` the per-block dgamma | dbeta partial sums (part[nblk][2][C], *nblk returned) in the same pass
+int launch_layernorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const float* stats, bf16* dx, const bf16* addend,
+                         float* part, int* nblk_out, int M, int C, hipStream_t st) {
   ARG_CHECK(C % 128 == 0, "layernorm bwd: C=%d must be a multiple of 128", C);
-  const bool accumulate = addend != nullptr, params = dgamma != nullptr;
-  ARG_CHECK(!params || dbeta, "layernorm bwd: dgamma and dbeta go together");
-  dim3 blk(256);
-  // with the column sums: several row groups per block (fewer atomics), keeping >= 256 blocks
+  const bool accumulate = addend != nullptr, params = part != nullptr;
+  int lpr, iters, nblk;
+  ln_bwd_geometry(M, C, &lpr, &iters, &nblk);
+  if (!params) { iters = 1; nblk = cdiv(M, 256 / lpr); }
+  if (nblk_out) *nblk_out = nblk;
+  dim3 blk(256), grid(nblk);
 #define LN_LAUNCH(NV, LPR)                                                                                               \
   {                                                                                                                      \
-    int iters = 1;                                                                                                       \
-    if (params) { iters = M / ((256 / LPR) * 256); iters = iters < 1 ? 1 : (iters > 4 ? 4 : iters); }                    \
-    dim3 grid(cdiv(M, (256 / LPR) * iters));                                                                             \
     if (params) {                                                                                                        \
-      if (accumulate) hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, LPR, true, true>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, dgamma, dbeta, M, iters); \
-      else hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, LPR, false, true>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, dgamma, dbeta, M, iters);          \
+      if (accumulate) hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, LPR, true, true>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, part, M, iters); \
+      else hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, LPR, false, true>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, part, M, iters);          \
     } else {                                                                                                             \
-      if (accumulate) hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, LPR, true, false>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, dgamma, dbeta, M, iters); \
-      else hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, LPR, false, false>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, dgamma, dbeta, M, iters);          \
+      if (accumulate) hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, LPR, true, false>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, part, M, iters); \
+      else hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, LPR, false, false>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, part, M, iters);          \
     }                                                                                                                    \
   }
-  if (C % 256 == 0 && C >= 1024) {
+  if (lpr == 32) {
     switch (C / 256) {
       case 4: LN_LAUNCH(4, 32) break;
       case 5: LN_LAUNCH(5, 32) break;
@@ -616,20 +653,12 @@ static int ln_bwd_launch(const bf16* x, const bf16* dy, const bf16* gamma, const
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-// dx and dgamma / dbeta (+=) in one pass over x and dy
-int launch_layernorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const float* stats, bf16* dx,
-                         const bf16* addend, float* dgamma, float* dbeta, int M, int C, hipStream_t st) {
-  return ln_bwd_launch(x, dy, gamma, stats, dx, addend, dgamma, dbeta, M, C, st);
-}
-int launch_layernorm_bwd_dx(const bf16* x, const bf16* dy, const bf16* gamma, const float* stats, bf16* dx,
-                            const bf16* addend, int M, int C, hipStream_t st) {
-  return ln_bwd_launch(x, dy, gamma, stats, dx, addend, nullptr, nullptr, M, C, st);
-}
-int launch_layernorm_bwd_params(const bf16* x, const bf16* dy, const float* stats, float* dgamma, float* dbeta, int M,
-                                int C, hipStream_t st) {
-  dim3 g2; int rpc;
-  col_reduce_geom(M, C, &g2, &rpc);
-  hipLaunchKernelGGL(col_reduce_kernel, g2, dim3(256), 0, st, x, dy, (long)C, stats, dgamma, dbeta, M, C, rpc);
+int launch_ln_param_reduce(const LnRedBatch& b, hipStream_t st) {
+  if (b.n <= 0) return 0;
+  ARG_CHECK(b.n <= LN_RED_MAX, "ln_param_reduce: %d entries", b.n);
+  int cmax = 0;
+  for (int i = 0; i < b.n; ++i) cmax = b.e[i].C > cmax ? b.e[i].C : cmax;
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * cmax, 256), 16, b.n), dim3(256), 0, st, b);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
