@@ -140,6 +140,10 @@ int sdxl_clip_coef(const float* sumsq_dev, float max_norm, float* coef_dev, void
  * form 2 (wgrad): `bias`, when given, is the fp32 bias-GRADIENT accumulator float[M]: += column sums of A. */
 int sdxl_op_gemm(int form, const void* A, const void* B, void* C, int M, int N, int K, const void* bias,
                  const void* resid, int accumulate, int splitk, void* stream);
+/* n (<= 4) weight gradients of one shape in one launch, as the plan groups them: dw[i][Mo][No] (+)= dy[i]^T . x[i] with
+ * dy[i] [rows][Mo], x[i] [rows][No] bf16; dbias (may be NULL, entries may be NULL): dbias[i][Mo] += column sums of dy[i]. */
+int sdxl_op_wgrad_group(int n, const void* const* dy, const void* const* x, float* const* dw, float* const* dbias, int Mo,
+                        int No, int rows, int accumulate, void* stream);
 /* 3x3 conv, pad 1, token-major: x [B,H,W,Cin], w [Cout][9][Cin] ; y [B,Ho,Wo,Cout] */
 int sdxl_op_conv3x3_fwd(const void* x, const void* w, const void* bias, void* y, int B, int H, int W, int Cin,
                         int Cout, int stride, void* stream);

@@ -68,8 +68,8 @@ int sdxl_create(const sdxl_unet_config* cfg, int device, sdxl_handle** out) {
     HIP_CHECK_RET(hipStreamCreateWithFlags(&h->e.gstream, hipStreamNonBlocking));
     HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_gin, hipEventDisableTiming));
     HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_gout, hipEventDisableTiming));
-    HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_join, hipEventDisableTiming));
-    HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_hoist, hipEventDisableTiming));
+    HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_hoist, hipEventDisableTiming | hipEventDisableSystemFence));
   }
   *out = h;
   return 0;
@@ -383,10 +383,17 @@ static int run_backward_segment(Engine& e, int k, bool first, hipStream_t st) {
   Plan& p = *e.cur;
   int s = e.nseg - 1 - k;
   e.ev_used = 0;   // per-op events are consumed in order; a segment's waits are all enqueued before the pool is reused
-  for (int i = p.seg_last_op[s]; i >= p.seg_first_op[s] && i >= 0; --i) CHK(p.ops[i]->bwd(p, st, first));
+  for (int i = p.seg_last_op[s]; i >= p.seg_first_op[s] && i >= 0; --i) {
+    if (p.early_bwd_after >= 0 && p.ops[i]->hoist_fwd) continue;       // already issued, see below
+    CHK(p.ops[i]->bwd(p, st, first));
+    if (i == p.early_bwd_after)   // the hoisted projections' output gradient is complete: their weight gradient goes out now, under the
+      for (auto& op : p.ops)      // rest of the backward, not alone at its end
+        if (op->hoist_fwd) CHK(op->bwd(p, st, first));
+  }
   // the segment's weight gradients are complete once `st` passes this point -- unless the caller declared (sdxl_set_join_mode)
   // that it only needs that of the whole backward (no per-segment gradient exchange): then the side stream runs free
   // until the last segment (nothing on the main stream reads a weight gradient, and no gradient buffer is reused)
+  CHK(e.flush_wgrads(p, st));
   CHK(e.flush_ln_params(p, st));
   if (e.side_dirty && !(e.join_last_only && k != e.nseg - 1)) {
     HIP_CHECK_RET(hipEventRecord(e.ev_join, e.side));
@@ -543,6 +550,24 @@ int sdxl_op_gemm(int form, const void* A, const void* B, void* C, int M, int N, 
   else g.bias = (const bf16*)bias;
   if (resid) { g.resid = (const bf16*)resid; g.ldr = N; }
   g.accumulate = accumulate;
+  return launch_gemm(g, (hipStream_t)st);
+}
+
+int sdxl_op_wgrad_group(int n, const void* const* dy, const void* const* x, float* const* dw, float* const* dbias, int Mo, int No,
+                        int rows, int accumulate, void* st) {
+  ARG_CHECK(n >= 1 && n <= GEMM_MAX_GROUP, "wgrad group of %d (1..%d)", n, GEMM_MAX_GROUP);
+  GemmP g;
+  gemm_defaults(&g);
+  g.form = GEMM_TN;
+  g.M = Mo; g.N = No; g.K = rows;
+  g.lda = Mo; g.ldb = No; g.ldc = No;
+  g.out_f32 = 1;
+  g.accumulate = accumulate;
+  g.A = (const bf16*)dy[0]; g.B = (const bf16*)x[0]; g.C = dw[0]; g.bias_grad = dbias ? dbias[0] : nullptr;
+  g.group = n;
+  for (int i = 0; i < n; ++i) {
+    g.gA[i] = (const bf16*)dy[i]; g.gB[i] = (const bf16*)x[i]; g.gC[i] = dw[i]; g.gbias_grad[i] = dbias ? dbias[i] : nullptr;
+  }
   return launch_gemm(g, (hipStream_t)st);
 }
 

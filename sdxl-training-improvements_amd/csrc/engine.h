@@ -23,6 +23,8 @@ struct Act {           // bf16 activation [rows][cols] in the workspace
   size_t goff = NONE;  // byte offset of gradient (assigned in reverse planning)
   long rows = 0;
   int cols = 0;
+  int pad_rows = 0;    // rows allocated beyond `rows` in the data and the gradient buffer (a weight-gradient GEMM over the rows can
+                       // then run a whole number of 64-row reduction steps: the op zeroes them before it reads them)
   bool need_grad = true;
   // column-slice view of a wider tensor (one block's K | V columns of the grouped cross-attention projection):
   // data / gradient live inside the parent's buffers, row stride = the parent's width
@@ -68,6 +70,8 @@ struct Plan {
   std::vector<std::unique_ptr<Act>> acts;
   std::vector<std::unique_ptr<Op>> ops;
   std::vector<int> seg_first_op, seg_last_op;  // op index ranges per segment (forward order)
+  int early_bwd_after = -1;   // the backward of the hoisted ops (whose forward index is ~0: they would run last, alone) is issued
+                              // right after the backward of this op, the last writer of their output gradient
   // well-known buffers
   Act *x_in = nullptr, *pred = nullptr, *ehs = nullptr, *aug_in = nullptr, *te_sin = nullptr, *tid_emb = nullptr;
   size_t t_off = NONE, tid_off = NONE, loss_off = NONE;
@@ -77,7 +81,7 @@ struct Plan {
   size_t slab_off = NONE, slab_floats = 0;    // split-K partial slabs of the wgrad GEMMs (shared, stream-ordered)
   size_t apart_off = NONE, apart_floats = 0;  // query-split partials of the cross-attention dK/dV kernel (main stream)
 
-  Act* new_act(long rows, int cols, bool need_grad = true);
+  Act* new_act(long rows, int cols, bool need_grad = true, int pad_rows = 0);
   Act* view(Act* parent, int col0, int cols);   // columns [col0, col0 + cols) of parent
   size_t alloc(size_t bytes);
   // reverse planning.  Gradient buffers are WRITE-ONCE: the first writer of a tensor's gradient gets a fresh buffer,
@@ -124,6 +128,9 @@ struct Engine {
   bool use_side = true;
   bool join_last_only = false;   // sdxl_set_join_mode: main waits for the side stream at the last segment only
   hipEvent_t next_event();
+  std::vector<std::vector<GemmP>> wg_pending;   // weight gradients waiting for a grouped launch, one bucket per shape
+  int defer_wgrad(Plan& p, hipStream_t main, const GemmP& g, int grp);
+  int flush_wgrads(Plan& p, hipStream_t main);
   std::vector<LnRedEntry> ln_pending;     // LayerNorm backward launches whose dgamma | dbeta partials are not reduced yet
   int flush_ln_params(Plan& p, hipStream_t main);
   bool side_dirty = false;       // the side stream has work the caller's stream has not joined yet

@@ -32,12 +32,13 @@ size_t Plan::alloc(size_t bytes) {
   ws_bytes = cursor;
   return off;
 }
-Act* Plan::new_act(long rows, int cols, bool need_grad) {
+Act* Plan::new_act(long rows, int cols, bool need_grad, int pad_rows) {
   Act* a = new Act();
   a->rows = rows;
   a->cols = cols;
+  a->pad_rows = pad_rows;
   a->need_grad = need_grad;
-  a->off = alloc((size_t)rows * cols * sizeof(bf16));
+  a->off = alloc((size_t)(rows + pad_rows) * cols * sizeof(bf16));
   acts.emplace_back(a);
   return a;
 }
@@ -55,7 +56,7 @@ Act* Plan::view(Act* parent, int col0, int cols) {
 Plan::GradDst Plan::grad_dst(Act* a) {
   GradDst d;
   if (a->parent) {   // slice of the parent's gradient tensor (allocated by the first slice that asks): written once, by one op
-    if (a->parent->goff == NONE) a->parent->goff = alloc((size_t)a->parent->rows * a->parent->cols * sizeof(bf16));
+    if (a->parent->goff == NONE) a->parent->goff = alloc((size_t)(a->parent->rows + a->parent->pad_rows) * a->parent->cols * sizeof(bf16));
     d.addend = a->goff;
     a->goff = a->parent->goff + (size_t)a->col0 * sizeof(bf16);
     d.out = a->goff;
@@ -69,7 +70,8 @@ Plan::GradDst Plan::grad_dst(Act* a) {
 hipEvent_t Engine::next_event() {
   if (ev_used == ev_pool.size()) {
     hipEvent_t e;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    // device-to-device ordering only (the host never waits on these): no system-scope fence at the marker (-0.7 ms per step)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) return nullptr;
     ev_pool.push_back(e);
   }
   return ev_pool[ev_used++];
@@ -87,6 +89,37 @@ static int on_side(Plan& p, hipStream_t main, F&& fn) {
   HIP_CHECK_RET(hipStreamWaitEvent(e.side, ev, 0));
   e.side_dirty = true;
   return fn(e.side);
+}
+// weight gradients of one shape wait here until `grp` of them fill a launch (GemmP::group); flush_wgrads() at the end of a
+// backward segment launches the stragglers (their dY / X operands are write-once buffers of the plan, nothing reuses them)
+static int launch_wgrad_bucket(Plan& p, hipStream_t main, std::vector<GemmP>& v) {
+  if (v.empty()) return 0;
+  GemmP g = v[0];
+  if (v.size() > 1) {
+    g.splitk = 1;
+    g.group = (int)v.size();
+    for (size_t i = 0; i < v.size(); ++i) {
+      g.gA[i] = v[i].A; g.gB[i] = v[i].B; g.gC[i] = (float*)v[i].C; g.gbias_grad[i] = v[i].bias_grad;
+    }
+  }
+  v.clear();
+  return on_side(p, main, [&g](hipStream_t s2) -> int { return launch_gemm(g, s2); });
+}
+int Engine::defer_wgrad(Plan& p, hipStream_t main, const GemmP& g, int grp) {
+  for (auto& b : wg_pending) {
+    if (b.empty() || (b[0].M == g.M && b[0].N == g.N && b[0].K == g.K && b[0].accumulate == g.accumulate)) {
+      b.push_back(g);
+      if ((int)b.size() >= grp) return launch_wgrad_bucket(p, main, b);
+      return 0;
+    }
+  }
+  wg_pending.emplace_back(1, g);
+  if (grp <= 1) return launch_wgrad_bucket(p, main, wg_pending.back());
+  return 0;
+}
+int Engine::flush_wgrads(Plan& p, hipStream_t main) {
+  for (auto& b : wg_pending) CHK(launch_wgrad_bucket(p, main, b));
+  return 0;
 }
 // dgamma / dbeta of the LayerNorms since the last call: one reduce launch per LN_RED_MAX of them, on the side stream
 int Engine::flush_ln_params(Plan& p, hipStream_t main) {
@@ -117,11 +150,13 @@ static void want_slab(Plan& p, int M, int N, int taps, int splitk) {
   if (need > p.slab_floats) p.slab_floats = need;
 }
 
+static int kv_pad_rows(int B, int ctx) { return (int)((64 - ((long)B * ctx) % 64) % 64); }   // B * 77 prompt tokens -> multiple of 64
+
 struct LinearOp : Op {
   Act *x, *y, *resid;
   PRef w, b;
   int K, N;
-  int resid_alias = 0, splitk = 1;
+  int resid_alias = 0, splitk = 1, wgroup = 1;
   size_t dy_off = NONE;
   Plan::GradDst dx, dres;
   // GEGLU feed-forward pair (GemmP::geglu): the first projection (y = u, interleaved value | gate columns) also
@@ -151,6 +186,7 @@ struct LinearOp : Op {
     if (gu) dx = p.grad_dst(gu);           // the activation itself gets no gradient buffer: dgrad emits dU
     else if (x->need_grad) dx = p.grad_dst(x);
     splitk = pick_splitk(N, K, 1, x->rows);
+    wgroup = gemm_pick_group(N, K, 1, x->rows, splitk);
     want_slab(p, N, K, 1, splitk);
   }
   int bwd(Plan& p, hipStream_t st, bool first) override {
@@ -158,7 +194,7 @@ struct LinearOp : Op {
     const int M = (int)x->rows;
     if (gu && dx.addend != NONE) { sdxl_set_error("geglu: pre-activation gradient has another writer"); return 3; }
     if (resid && !resid_alias) CHK(launch_add(p.GP(dres.addend), dy, p.GP(dres.out), (long)M * N, st));
-    CHK(on_side(p, st, [&](hipStream_t s2) -> int {
+    {
       GemmP g;
       gemm_defaults(&g);
       g.form = GEMM_TN;
@@ -170,9 +206,21 @@ struct LinearOp : Op {
       g.slab = p.F(p.slab_off);
       g.accumulate = first ? 0 : 1;
       g.bias_grad = b.off != NONE ? p.eng->Gp(b) : nullptr;   // column sums of dY ride along on the matrix pipe
-      CHK(launch_gemm(g, s2));
-      return 0;
-    }));
+      const int pad = x->pad_rows < y->pad_rows ? x->pad_rows : y->pad_rows;
+      if (pad > 0 && (M + pad) % 64 == 0) {     // zero rows appended to both operands: every reduction step is a full one
+        g.K = M + pad;
+        bf16* dyp = p.GP(dy_off) + (size_t)M * N;
+        bf16* xp = p.P(x) + (size_t)M * K;
+        const size_t nb_dy = (size_t)pad * N * sizeof(bf16), nb_x = (size_t)pad * K * sizeof(bf16);
+        CHK(on_side(p, st, [=](hipStream_t s2) -> int {
+          HIP_CHECK_RET(hipMemsetAsync(dyp, 0, nb_dy, s2));
+          HIP_CHECK_RET(hipMemsetAsync(xp, 0, nb_x, s2));
+          return launch_gemm(g, s2);
+        }));
+      } else
+      if (wgroup > 1 && p.eng->use_side && p.eng->side && !gemm_profiling()) CHK(p.eng->defer_wgrad(p, st, g, wgroup));
+      else CHK(on_side(p, st, [&](hipStream_t s2) -> int { return launch_gemm(g, s2); }));
+    }
     if (x->need_grad) {
       GemmP g;
       gemm_defaults(&g);
@@ -631,7 +679,7 @@ struct Builder {
     Act *x_in = nullptr, *ehs = nullptr, *te_sin = nullptr, *aug_in = nullptr;
     if (pl) {
       pl->x_in = x_in = pl->new_act((long)B * H * W, 8, false);
-      pl->ehs = ehs = pl->new_act((long)B * ctx, c.cross_attention_dim, false);
+      pl->ehs = ehs = pl->new_act((long)B * ctx, c.cross_attention_dim, false, kv_pad_rows(B, ctx));
       pl->te_sin = te_sin = pl->new_act(B, ch[0], false);
       pl->tid_emb = pl->new_act((long)B * 6, c.addition_time_embed_dim, false);
       pl->aug_in = aug_in = pl->new_act(B, add_in, false);
@@ -673,7 +721,7 @@ struct Builder {
         col += 2L * b.second;
       }
       if (pl) {
-        kv_all = pl->new_act((long)B * ctx, (int)ntot);
+        kv_all = pl->new_act((long)B * ctx, (int)ntot, true, kv_pad_rows(B, ctx));
         LinearOp* op = tagseg(pl->add<LinearOp>(ehs, kv_all, wkv, PRef(), cross, (int)ntot, nullptr), wkv);
         op->hoist_fwd = true;
       }
@@ -774,6 +822,8 @@ void Engine::build(Plan* plan) {
     plan->apart_off = plan->alloc(sizeof(float) * (plan->apart_floats ? plan->apart_floats : 4));
     plan->seg_first_op.assign(nseg, -1);
     plan->seg_last_op.assign(nseg, -2);
+    for (int i = (int)plan->ops.size() - 1; i >= 0; --i)
+      if (plan->ops[i]->needs_hoisted) plan->early_bwd_after = i;
     for (int i = 0; i < (int)plan->ops.size(); ++i) {
       int s = plan->ops[i]->seg;
       if (plan->seg_first_op[s] < 0) plan->seg_first_op[s] = i;

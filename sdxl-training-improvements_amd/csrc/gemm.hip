@@ -55,7 +55,12 @@ static constexpr int gemm_occupancy(int BN, int S, int BK, int NW) {
 //        eight waves read, wait and multiply in lockstep: 0.73 us per K-step of a 128x160 tile against 0.3 at the MFMA
 //        rate).  The two partial accumulator tiles are exchanged through LDS once, after the main loop.
 template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW, bool KSP = false>
-__global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_kernel(const GemmP p) {
+__global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_kernel(const GemmP pin) {
+  GemmP p = pin;
+  if (FORM == GEMM_TN && pin.group > 1) {          // grouped launch: this workgroup's problem
+    const int gi = blockIdx.z;
+    p.A = pin.gA[gi]; p.B = pin.gB[gi]; p.C = pin.gC[gi]; p.bias_grad = pin.gbias_grad[gi];
+  }
   static_assert(!KSP || (NW == 8 && BK == 64 && FAST && S >= 3 && FORM != GEMM_TN), "split-K groups: 8 waves, BK 64, FAST staging, ring >= 3");
   constexpr int BMT = BM;
   constexpr int A_TILE_BYTES = BMT * BK * 2;      // [BMT][BK] or [BK][128] bf16
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
 
   // reduction schedule
   int tap_fixed = 0, split = 0;
-  if (FORM == GEMM_TN) {
+  if (FORM == GEMM_TN && p.group <= 1) {
     tap_fixed = blockIdx.z / p.splitk;
     split = blockIdx.z - tap_fixed * p.splitk;
   }
@@ -748,7 +753,7 @@ static int launch_k(const GemmP& p, hipStream_t st) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), FORM == GEMM_TN ? p.taps * p.splitk : 1);
+  dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), FORM == GEMM_TN ? (p.group > 1 ? p.group : p.taps * p.splitk) : 1);
   hipLaunchKernelGGL((gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW, KSP>), grid, dim3(NW * 64), smem, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
@@ -895,6 +900,16 @@ int gemm_pick_splitk(int M, int N, int taps, long red) {
   if (s > 32) s = 32;
   return (int)s;
 }
+// weight gradients whose tile count fills a third or a quarter of the chip are launched 3 or 4 at a time (GemmP::group)
+// instead of alone with split-K slabs + a reduce pass each: 1280 x 1280 x 4096 (192 per step at B=4 1024^2) took
+// 43 us + 6 us of reduce each, three of them in one grid take the time of one 3840 x 1280 x 4096 product (~90 us)
+int gemm_pick_group(int M, int N, int taps, long red, int splitk) {
+  if (taps != 1 || splitk < 2 || red > 8192 || red % 64) return 1;
+  const long tiles = (long)cdiv(M, 128) * cdiv(N, 160);
+  if (tiles < 64 || tiles > 128) return 1;
+  const int g = (int)(256 / tiles);
+  return g < 2 ? 1 : (g > GEMM_MAX_GROUP ? GEMM_MAX_GROUP : g);
+}
 void gemm_set_mode(int mode) { g_mode256 = mode & 3; g_force_cfg = mode >> 2; }
 static int launch_gemm_impl(const GemmP& pin, hipStream_t st);
 int launch_gemm(const GemmP& p, hipStream_t st) {
@@ -908,7 +923,7 @@ int launch_gemm(const GemmP& p, hipStream_t st) {
   int rc = launch_gemm_impl(p, st);
   HIP_CHECK_RET(hipEventRecord(g_prof.ev[g_prof.used + 1], st));
   g_prof.used += 2;
-  g_prof.flops.push_back(2.0 * (double)p.M * (double)p.N * (double)p.K * (double)p.taps);
+  g_prof.flops.push_back(2.0 * (double)p.M * (double)p.N * (double)p.K * (double)p.taps * (p.group > 1 ? p.group : 1));
   g_prof.recs.push_back({p.form, p.taps, p.M, p.N, p.K, p.splitk});
   return rc;
 }
@@ -944,6 +959,16 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
     ARG_CHECK(!p.geglu, "gemm TN: no geglu epilogue");
   }
   if (p.splitk < 1) p.splitk = 1;
+  if (p.group > 1) {
+    ARG_CHECK(p.form == GEMM_TN && p.taps == 1 && p.splitk == 1 && p.group <= GEMM_MAX_GROUP,
+              "gemm: grouped launches are TN, one tap, no split-K, at most %d problems", GEMM_MAX_GROUP);
+    for (int i = 0; i < p.group; ++i)
+      ARG_CHECK(p.gA[i] && p.gB[i] && p.gC[i] && (((uintptr_t)p.gA[i] | (uintptr_t)p.gB[i] | (uintptr_t)p.gC[i]) & 15) == 0,
+                "gemm: grouped operands must be set and 16-byte aligned");
+    p.A = p.gA[0]; p.B = p.gB[0]; p.C = p.gC[0]; p.bias_grad = p.gbias_grad[0];
+  } else {
+    p.group = 0;
+  }
   {
     p.xcd_px = 0;
     {   // px x (8/px) XCD grid over (n, m) tiles minimising per-XCD operand footprint ~ N/px + M/py
@@ -965,7 +990,7 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
   const bool conv = p.taps == 9;
   int rc;
   {   // 256 x 256 kernel (gemm256.hip)
-    if (g_mode256 && gemm256_applicable(p)) {
+    if (g_mode256 && p.group <= 1 && gemm256_applicable(p)) {
       if (g_mode256 == 2 || gemm_use256(p.form, p.M, p.N, p.K, p.splitk)) {
         rc = launch_gemm256(p, st);
         if (rc == 0 && p.splitk > 1) {

@@ -13,6 +13,7 @@
 // ------------------------------------------------------------------------------------------------
 enum { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
 
+#define GEMM_MAX_GROUP 4
 struct GemmP {
   int form;
   const bf16* A;
@@ -56,7 +57,16 @@ struct GemmP {
   float* bias_grad;  // TN only, optional: bias_grad[m] += sum_k A(k, m)  (column sums of dY, computed on the matrix pipe
                      // by the n-tile-0 / tap-0 workgroups with an all-ones B fragment; fp32 atomics, 128 per workgroup)
   int xcd_px;      // set by the launcher: XCD grid width over n-tiles (0 = identity order; SDXL_GEMM_XCD=0 disables)
+  // grouped launch (TN, taps == 1, splitk == 1): `group` > 1 problems of one shape in one grid (blockIdx.z = problem i, which
+  // uses gA[i], gB[i], gC[i], gbias_grad[i] in place of A, B, C, bias_grad).  Small weight gradients (1280 x 1280: 80 tiles)
+  // fill the chip three at a time instead of each being cut into split-K slabs and reduced.
+  int group;
+  const bf16* gA[GEMM_MAX_GROUP];
+  const bf16* gB[GEMM_MAX_GROUP];
+  float* gC[GEMM_MAX_GROUP];
+  float* gbias_grad[GEMM_MAX_GROUP];
 };
+int gemm_pick_group(int M, int N, int taps, long red, int splitk);   // problems per grouped wgrad launch (1 = launch alone)
 size_t gemm_slab_floats(int M, int N, int taps, int splitk);
 void gemm_defaults(GemmP* p);
 int launch_gemm(const GemmP& p, hipStream_t st);

@@ -71,6 +71,7 @@ SIGNATURES = {
     "sdxl_grads_to_bf16": [_vp, _sz, _sz, _vp, _f, _vp],
     "sdxl_grad_sumsq": [_vp, _vp, _vp],
     "sdxl_op_gemm": [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp],
+    "sdxl_op_wgrad_group": [_i, _P(_vp), _P(_vp), _P(_vp), _P(_vp), _i, _i, _i, _i, _vp],
     "sdxl_op_conv3x3_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "sdxl_op_conv3x3_dgrad": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "sdxl_op_conv3x3_wgrad": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],

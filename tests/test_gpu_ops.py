@@ -163,6 +163,28 @@ def test_gemm256_tn_wgrad_bias(g256, M, N, K, splitk):
     report("gemm256 tn =", out, ref, 2e-5 * math.sqrt(K) + 1e-5)
 
 
+@pytest.mark.parametrize("n,Mo,No,rows", [(3, 1280, 1280, 4096), (2, 320, 640, 1000), (4, 128, 160, 64), (1, 640, 320, 512)])
+def test_wgrad_group(L, n, Mo, No, rows):
+    """Grouped weight-gradient launch (GemmP::group): n problems of one shape in one grid, each with its own operands,
+    fp32 destination and optional bias-gradient accumulator; overwrite and += ."""
+    import ctypes as C
+    dys = [rnd(rows, Mo, seed=20 + i) for i in range(n)]
+    xs = [rnd(rows, No, seed=30 + i) for i in range(n)]
+    dws = [torch.full((Mo, No), 7.0, dtype=torch.float32, device=dev()) for _ in range(n)]
+    dbs = [torch.zeros(Mo, dtype=torch.float32, device=dev()) if i != 1 else None for i in range(n)]
+    arr = lambda ts: (C.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
+    tol = 2e-5 * math.sqrt(rows) + 1e-5
+    lib.check(L.sdxl_op_wgrad_group(n, arr(dys), arr(xs), arr(dws), arr(dbs), Mo, No, rows, 0, stream()))
+    for i in range(n):
+        ref = dys[i].float().t() @ xs[i].float()
+        report(f"wgrad group {n}x {Mo}x{No}x{rows} [{i}] =", dws[i], ref, tol)
+        if dbs[i] is not None:
+            report(f"wgrad group bias grad [{i}]", dbs[i], dys[i].float().sum(0), tol)
+    lib.check(L.sdxl_op_wgrad_group(n, arr(dys), arr(xs), arr(dws), None, Mo, No, rows, 1, stream()))
+    for i in range(n):
+        report(f"wgrad group [{i}] +=", dws[i], 2 * (dys[i].float().t() @ xs[i].float()), tol)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 160, 64), (128, 160, 128), (256, 320, 192), (4096, 1280, 1280), (1000, 640, 2560), (308, 1280, 2048)])
 def test_gemm_splitk_groups_nt_nn(L, M, N, K):
     """configuration 23 (8 waves = two K-groups of 2 x 2 waves, staggered by one barrier, partial tiles exchanged through
