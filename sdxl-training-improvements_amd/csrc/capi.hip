@@ -383,6 +383,7 @@ static int run_backward_segment(Engine& e, int k, bool first, hipStream_t st) {
   Plan& p = *e.cur;
   int s = e.nseg - 1 - k;
   e.ev_used = 0;   // per-op events are consumed in order; a segment's waits are all enqueued before the pool is reused
+  if (k == 0 && p.tp32_off != NONE) HIP_CHECK_RET(hipMemsetAsync(p.F(p.tp32_off), 0, p.tp32_bytes, st));
   for (int i = p.seg_last_op[s]; i >= p.seg_first_op[s] && i >= 0; --i) {
     if (p.early_bwd_after >= 0 && p.ops[i]->hoist_fwd) continue;       // already issued, see below
     CHK(p.ops[i]->bwd(p, st, first));

@@ -157,6 +157,7 @@ struct LinearOp : Op {
   PRef w, b;
   int K, N;
   int resid_alias = 0, splitk = 1, wgroup = 1;
+  size_t dy32_off = NONE;   // the output gradient arrives as fp32 sums (grouped time-embedding projection): cast first
   size_t dy_off = NONE;
   Plan::GradDst dx, dres;
   // GEGLU feed-forward pair (GemmP::geglu): the first projection (y = u, interleaved value | gate columns) also
@@ -192,6 +193,7 @@ struct LinearOp : Op {
   int bwd(Plan& p, hipStream_t st, bool first) override {
     const bf16* dy = p.GP(dy_off);
     const int M = (int)x->rows;
+    if (dy32_off != NONE) CHK(launch_f32_to_bf16(p.F(dy32_off), p.GP(dy_off), (long)M * N, 1.f, st));
     if (gu && dx.addend != NONE) { sdxl_set_error("geglu: pre-activation gradient has another writer"); return 3; }
     if (resid && !resid_alias) CHK(launch_add(p.GP(dres.addend), dy, p.GP(dres.out), (long)M * N, st));
     {
@@ -241,7 +243,8 @@ struct ConvOp : Op {
   PRef w, b;
   int Bn, H, W, Cin, Cout, stride, Ho, Wo;
   int resid_alias = 0, splitk = 1;
-  size_t tmp_off = NONE;  // fp32 [B][Cout] for the rowvec gradient
+  size_t rv32_off = NONE;  // rowvec gradient: this conv's column slice of the plan's fp32 [B][sum Cout] buffer
+  long rv32_ld = 0;
   size_t dy_off = NONE;
   Plan::GradDst dx, dres, drv;
   ConvOp(Act* x_, Act* y_, PRef w_, PRef b_, int B_, int H_, int W_, int Cin_, int Cout_, int stride_, Act* resid_,
@@ -262,7 +265,7 @@ struct ConvOp : Op {
     g.b_tap_stride = Cin;
     g.bias = p.eng->Wp(b);
     if (resid) { g.resid = p.P(resid); g.ldr = Cout; }
-    if (rowvec) { g.rowvec = p.P(rowvec); g.ldv = Cout; g.rows_per_batch = Ho * Wo; }
+    if (rowvec) { g.rowvec = p.P(rowvec); g.ldv = rowvec->ld(); g.rows_per_batch = Ho * Wo; }
     return launch_gemm(g, st);
   }
   void plan_bwd(Plan& p) override {
@@ -271,7 +274,11 @@ struct ConvOp : Op {
       resid_alias = p.grad_alias(resid, y) ? 1 : 0;
       if (!resid_alias) dres = p.grad_dst(resid);
     }
-    if (rowvec) { drv = p.grad_dst(rowvec); tmp_off = p.alloc(sizeof(float) * Bn * Cout); }
+    if (rowvec) {
+      drv = p.grad_dst(rowvec);     // (allocates the grouped projection's bf16 output gradient; written by its cast, not here)
+      rv32_off = p.tp32_off + (size_t)rowvec->col0 * sizeof(float);
+      rv32_ld = rowvec->ld();
+    }
     if (x->need_grad) dx = p.grad_dst(x);
     splitk = pick_splitk(Cout, Cin, 9, (long)Bn * Ho * Wo);
     want_slab(p, Cout, Cin, 9, splitk);
@@ -297,13 +304,9 @@ struct ConvOp : Op {
       CHK(launch_gemm(g, s2));
       return 0;
     }));
-    if (rowvec) {
+    if (rowvec) {   // d(time-embedding projection)[b][c] = sum over the pixels of sample b of dy: one launch, into the fp32 slice
       if (drv.addend != NONE) { sdxl_set_error("conv: time-embedding row vector has another gradient writer"); return 3; }
-      float* tmp = p.F(tmp_off);
-      HIP_CHECK_RET(hipMemsetAsync(tmp, 0, sizeof(float) * Bn * Cout, st));
-      for (int bi = 0; bi < Bn; ++bi)
-        CHK(launch_colsum_f32(dy + (long)bi * Ho * Wo * Cout, tmp + (long)bi * Cout, Ho * Wo, Cout, Cout, st));
-      CHK(launch_f32_to_bf16(tmp, p.GP(drv.out), (long)Bn * Cout, 1.f, st));
+      CHK(launch_colsum_f32_batched(dy, p.F(rv32_off), Bn, Ho * Wo, Cout, Cout, rv32_ld, st));
     }
     if (x->need_grad) {
       GemmP g;
@@ -544,6 +547,10 @@ struct Builder {
   int B, H, W, ctx;
   int last_seg = 0;
   Act* emb_act = nullptr;
+  Act* tp_all = nullptr;                     // [B][sum Cout]: time-embedding projection of every resnet
+  std::map<std::string, int> tp_col;        // resnet prefix -> first column in tp_all
+  long tp_total = 0;
+  PRef wtp, btp;
   Act* kv_all = nullptr;                     // [B*ctx][sum 2C]: cross-attention K | V of every transformer block
   std::map<std::string, int> kv_col;        // transformer block prefix -> first column in kv_all
   explicit Builder(Engine& e_, Plan* p_) : e(e_), pl(p_) {
@@ -624,7 +631,8 @@ struct Builder {
     Act* n1 = groupnorm(p + ".norm1", x, h * w_, cin, e.cfg.resnet_eps, 1);
     // diffusers key order: norm1, conv1, time_emb_proj, norm2, conv2, conv_shortcut.  The time projection must
     // run before conv1 consumes it, so parameters are registered in execution order instead.
-    Act* tp = linear(p + ".time_emb_proj", emb_act, e.cfg.block_out_channels[0] * 4, cout, true, nullptr);
+    // this resnet's columns of the grouped time-embedding projection (one GEMM for all 17 resnets, run())
+    Act* tp = pl ? pl->view(tp_all, tp_col.at(p), cout) : nullptr;
     Act* c1 = conv(p + ".conv1", n1, h, w_, cin, cout, 1, nullptr, tp);
     Act* n2 = groupnorm(p + ".norm2", c1, h * w_, cout, e.cfg.resnet_eps, 1);
     Act* sc = x;
@@ -726,6 +734,29 @@ struct Builder {
         op->hoist_fwd = true;
       }
     }
+    {
+      // The 17 resnets' time_emb_proj (Linear(silu(emb)) [B][1280] -> [B][Cout]) as ONE GEMM: rows of all of them contiguous
+      // in the arena (first segment, like the K | V weight: its gradient completes last), each resnet's conv1 reads its
+      // column slice as the per-sample row vector of its epilogue and adds its gradient into the fp32 [B][sum Cout] buffer.
+      std::vector<std::pair<std::string, int>> rs;
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < c.layers_per_block; ++j) rs.emplace_back("down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), ch[i]);
+      rs.emplace_back("mid_block.resnets.0", ch[2]);
+      rs.emplace_back("mid_block.resnets.1", ch[2]);
+      for (int ui = 0; ui < 3; ++ui)
+        for (int j = 0; j < c.layers_per_block + 1; ++j) rs.emplace_back("up_blocks." + std::to_string(ui) + ".resnets." + std::to_string(j), ch[2 - ui]);
+      tp_total = 0;
+      for (auto& r : rs) tp_total += r.second;
+      wtp = e.param((size_t)tp_total * temb);
+      btp = e.param((size_t)tp_total, true);
+      long col = 0;
+      for (auto& r : rs) {
+        e.map_src(r.first + ".time_emb_proj.weight", {r.second, temb}, wtp, 0, (size_t)col * temb, 0);
+        e.map_src(r.first + ".time_emb_proj.bias", {r.second}, btp, 0, (size_t)col, 0);
+        tp_col[r.first] = (int)col;
+        col += r.second;
+      }
+    }
     Act* t1 = linear("time_embedding.linear_1", te_sin, ch[0], temb, true, nullptr);
     Act* t1s = silu(t1);
     Act* t2 = linear("time_embedding.linear_2", t1s, temb, temb, true, nullptr);
@@ -733,6 +764,13 @@ struct Builder {
     Act* a1s = silu(a1);
     Act* emb = linear("add_embedding.linear_2", a1s, temb, temb, true, t2);
     emb_act = silu(emb);
+    if (pl) {
+      tp_all = pl->new_act(B, (int)tp_total);
+      pl->tp32_bytes = sizeof(float) * (size_t)B * tp_total;
+      pl->tp32_off = pl->alloc(pl->tp32_bytes);
+      LinearOp* op = tagseg(pl->add<LinearOp>(emb_act, tp_all, wtp, btp, temb, (int)tp_total, nullptr), wtp);
+      op->dy32_off = pl->tp32_off;
+    }
 
     Act* x = conv("conv_in", x_in, H, W, 8, ch[0], 1, nullptr, nullptr, c.in_channels, ch[0]);
     struct Skip { Act* a; int c; };

@@ -141,7 +141,8 @@ int launch_ln_param_reduce(const LnRedBatch& b, hipStream_t st);
 int launch_silu_fwd(const bf16* x, bf16* y, long n, hipStream_t st);
 int launch_silu_bwd(const bf16* x, const bf16* dy, bf16* dx, const bf16* addend, long n, hipStream_t st);
 int launch_add(const bf16* a, const bf16* b, bf16* o, long n, hipStream_t st);           // o = a + b
-int launch_colsum_f32(const bf16* x, float* out, int M, int N, long ldx, hipStream_t st);  // out[n] += sum_m
+int launch_colsum_f32(const bf16* x, float* out, int M, int N, long ldx, hipStream_t st);
+int launch_colsum_f32_batched(const bf16* x, float* out, int batches, int rows, int N, long ldx, long ld_out, hipStream_t st);  // out[n] += sum_m
 int launch_concat(const bf16* a, int Ca, const bf16* b, int Cb, bf16* o, long rows, hipStream_t st);
 int launch_split_add(const bf16* g, bf16* ga, int Ca, const bf16* add_a, bf16* gb, int Cb, const bf16* add_b,
                      long rows, hipStream_t st);                                                  // concat backward

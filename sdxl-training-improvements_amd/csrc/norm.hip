@@ -545,8 +545,11 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const LnRedBatch b
 // With x == nullptr this is a plain column sum (bias gradients): out_b[n] += sum_m dy[m][n].
 __global__ __launch_bounds__(256) void col_reduce_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, long ld,
                                   const float* __restrict__ stats, float* __restrict__ out_g,
-                                  float* __restrict__ out_b, int M, int C, int rows_per_chunk) {
+                                  float* __restrict__ out_b, int M, int C, int rows_per_chunk, long batch_stride,
+                                  long out_ld) {
   __shared__ float sred[2][8][256 + 8];
+  dy += blockIdx.z * batch_stride;       // batched plain column sums (x == nullptr): batch z = rows [z*M, z*M + M) -> out_b + z*out_ld
+  out_b += blockIdx.z * out_ld;
   const int cv = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c0 = blockIdx.x * 256 + cv * 8;
   const bool cok = c0 < C;
@@ -668,7 +671,22 @@ int launch_colsum_f32(const bf16* x, float* out, int M, int N, long ldx, hipStre
   dim3 g2; int rpc;
   col_reduce_geom(M, N, &g2, &rpc);
   hipLaunchKernelGGL(col_reduce_kernel, g2, dim3(256), 0, st, (const bf16*)nullptr, x, ldx, (const float*)nullptr,
-                     (float*)nullptr, out, M, N, rpc);
+                     (float*)nullptr, out, M, N, rpc, 0L, 0L);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+// out[b][n] += sum over the rows of batch b of x[b*rows + r][n], all batches in one launch (out row stride ld_out)
+int launch_colsum_f32_batched(const bf16* x, float* out, int batches, int rows, int N, long ldx, long ld_out, hipStream_t st) {
+  ARG_CHECK(N % 8 == 0 && ldx % 8 == 0, "colsum: N=%d ld=%ld must be multiples of 8", N, ldx);
+  dim3 g2; int rpc;
+  col_reduce_geom(rows, N, &g2, &rpc);
+  if (batches > 1 && g2.y >= 2u * batches) {          // keep the total number of blocks
+    rpc *= batches;
+    g2.y = cdiv(rows, rpc);
+  }
+  g2.z = batches;
+  hipLaunchKernelGGL(col_reduce_kernel, g2, dim3(256), 0, st, (const bf16*)nullptr, x, ldx, (const float*)nullptr,
+                     (float*)nullptr, out, rows, N, rpc, (long)rows * ldx, ld_out);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
