@@ -51,6 +51,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int t, int col0, int
   u.s[1] = hi;
   return u.v;
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
   bf16x8 o;
   o[0] = (bf16)a[0]; o[1] = (bf16)a[1]; o[2] = (bf16)a[2]; o[3] = (bf16)a[3];
@@ -210,24 +211,33 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kb][qb][r]);
       mx = max_over_g(mx);
-      float mnew = fmaxf(mrow[qb], mx);
-      float alpha = __builtin_amdgcn_exp2f((mrow[qb] - mnew) * c);
-      mrow[qb] = mnew;
-      float ls = 0.f;
-      float mc = mnew * c;
+      // lazy rescaling: the running reference mrow only moves when some query's tile maximum exceeds it by more than
+      // 2^8 in the exponent (p <= 256 until then: exact in fp32 sums, same relative precision in bf16); after the first
+      // tiles that is rare, and the accumulator rescale (alpha, 16 two-wide multiplies) is skipped wave-uniformly
+      if (__builtin_amdgcn_ballot_w64((mx - mrow[qb]) * c > 8.f) != 0) {
+        const float mnew2 = fmaxf(mrow[qb], mx);
+        const float alpha2 = __builtin_amdgcn_exp2f((mrow[qb] - mnew2) * c);
+        mrow[qb] = mnew2;
+        lrow[qb] *= alpha2;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          ot[db][qb][0] *= alpha2; ot[db][qb][1] *= alpha2; ot[db][qb][2] *= alpha2; ot[db][qb][3] *= alpha2;
+        }
+      }
+      const float mnew = mrow[qb];
+      const f32x2 nmc = (f32x2){-mnew * c, -mnew * c};
+      f32x2 ls2 = (f32x2){0.f, 0.f};
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float e = __builtin_amdgcn_exp2f(st[kb][qb][r] * c - mc);
-          st[kb][qb][r] = e;
-          ls += e;
+        for (int hh = 0; hh < 2; ++hh) {      // two-wide fp32 arithmetic on the register pairs of the MFMA results
+          const f32x2 arg = (f32x2){st[kb][qb][2 * hh], st[kb][qb][2 * hh + 1]} * c + nmc;
+          const f32x2 e = (f32x2){__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+          st[kb][qb][2 * hh] = e[0]; st[kb][qb][2 * hh + 1] = e[1];
+          ls2 += e;
         }
-      lrow[qb] = lrow[qb] * alpha + ls;  // per-lane partial (reduced over g at the end)
-#pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        ot[db][qb][0] *= alpha; ot[db][qb][1] *= alpha; ot[db][qb][2] *= alpha; ot[db][qb][3] *= alpha;
-      }
+      const float ls = ls2[0] + ls2[1];
+      lrow[qb] += ls;  // per-lane partial (reduced over g at the end)
       pf[0][qb] = pack8(st[0][qb], st[1][qb]);
       pf[1][qb] = pack8(st[2][qb], st[3][qb]);
     }
@@ -356,13 +366,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
     bf16x8 dsf[2][2];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
+      // two-wide fp32 arithmetic (v_pk_fma / v_pk_add / v_pk_mul) on the register pairs of the MFMA results
+      const f32x2 nl2 = (f32x2){-lse2[qb], -lse2[qb]}, ndl = (f32x2){-delta[qb], -delta[qb]};
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float pr = __builtin_amdgcn_exp2f(st[kb][qb][r] * c - lse2[qb]);
-          if (MASK) { if (t * 64 + kb * 16 + g * 4 + r >= p.Nk) pr = 0.f; }
-          st[kb][qb][r] = pr * (dp[kb][qb][r] - delta[qb]);      // (the softmax scale is applied once, to dQ, at the end)
+        for (int hh = 0; hh < 2; ++hh) {
+          const f32x2 arg = (f32x2){st[kb][qb][2 * hh], st[kb][qb][2 * hh + 1]} * c + nl2;
+          f32x2 pr = (f32x2){__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+          if (MASK) {
+            if (t * 64 + kb * 16 + g * 4 + 2 * hh >= p.Nk) pr[0] = 0.f;
+            if (t * 64 + kb * 16 + g * 4 + 2 * hh + 1 >= p.Nk) pr[1] = 0.f;
+          }
+          const f32x2 ds = pr * ((f32x2){dp[kb][qb][2 * hh], dp[kb][qb][2 * hh + 1]} + ndl);   // (softmax scale: once, on dQ, at the end)
+          st[kb][qb][2 * hh] = ds[0]; st[kb][qb][2 * hh + 1] = ds[1];
         }
       dsf[0][qb] = pack8(st[0][qb], st[1][qb]);
       dsf[1][qb] = pack8(st[2][qb], st[3][qb]);
@@ -496,20 +513,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
       for (int t2 = 0; t2 < 2; ++t2) { dot[db][t2] = tr_frag(Dt, t2, db * 16, l16, g); qt[db][t2] = tr_frag(Qt, t2, db * 16, l16, g); }
     __builtin_amdgcn_sched_barrier(0);
     bf16x8 pf[KB][2], dsf[KB][2];
+    // P = exp2(c S - log2e LSE), dS = P (dP - Delta): two-wide fp32 operations (v_pk_fma / v_pk_add / v_pk_mul) on the
+    // register pairs the MFMA results arrive in.  Keys beyond Nk need no masking here: their K / V fragments are zero and
+    // their P / dS ROWS only feed their own dK / dV rows, which are never stored.
+    f32x2 l2s[4][2], dls[4][2];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      const f32x4 l2 = *(const f32x4*)&sstat[buf][0][qb * 16 + g * 4];      // natural-log LSE
+      const f32x4 dl = *(const f32x4*)&sstat[buf][1][qb * 16 + g * 4];
+      l2s[qb][0] = (f32x2){l2[0], l2[1]} * LOG2E; l2s[qb][1] = (f32x2){l2[2], l2[3]} * LOG2E;
+      dls[qb][0] = (f32x2){-dl[0], -dl[1]}; dls[qb][1] = (f32x2){-dl[2], -dl[3]};     // negated: dP - Delta as a two-wide add
+    }
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       f32x4 pr[4];
 #pragma unroll
       for (int qb = 0; qb < 4; ++qb) {
-        f32x4 l2 = *(const f32x4*)&sstat[buf][0][qb * 16 + g * 4];      // natural-log LSE
-        f32x4 dl = *(const f32x4*)&sstat[buf][1][qb * 16 + g * 4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float e = __builtin_amdgcn_exp2f(s[kb][qb][r] * c - l2[r] * LOG2E);
-          if (MASK) { if (t * 64 + qb * 16 + g * 4 + r >= p.Nq) e = 0.f; }
-          if (!kok[kb]) e = 0.f;
-          pr[qb][r] = e;
-          s[kb][qb][r] = e * (dp[kb][qb][r] - dl[r]);          // (the softmax scale is applied once, to dK, at the end)
+        for (int hh = 0; hh < 2; ++hh) {
+          const f32x2 sv = (f32x2){s[kb][qb][2 * hh], s[kb][qb][2 * hh + 1]};
+          const f32x2 arg = sv * c - l2s[qb][hh];
+          f32x2 e = (f32x2){__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+          if (MASK) {
+            if (t * 64 + qb * 16 + g * 4 + 2 * hh >= p.Nq) e[0] = 0.f;
+            if (t * 64 + qb * 16 + g * 4 + 2 * hh + 1 >= p.Nq) e[1] = 0.f;
+          }
+          const f32x2 dpv = (f32x2){dp[kb][qb][2 * hh], dp[kb][qb][2 * hh + 1]};
+          const f32x2 dsv = e * (dpv + dls[qb][hh]);          // (the softmax scale is applied once, to dK, at the end)
+          pr[qb][2 * hh] = e[0]; pr[qb][2 * hh + 1] = e[1];
+          s[kb][qb][2 * hh] = dsv[0]; s[kb][qb][2 * hh + 1] = dsv[1];
         }
       }
       pf[kb][0] = pack8(pr[0], pr[1]);
