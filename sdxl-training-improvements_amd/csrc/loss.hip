@@ -127,7 +127,8 @@ __global__ void loss_bwd_kernel(const LossP p) {
     long idx = ((long)b * 4 + c) * p.HW + hw;
     float tg, w;
     loss_target(p, b, p.latents[idx], p.noise[idx], sg, &tg, &w);
-    o[c] = (bf16)(k * w * ((float)pv[c] - tg));
+    // guard taken (non-finite or clamped loss, out[7] == 0): an exact zero gradient, also where pred - target is inf / nan
+    o[c] = k == 0.f ? (bf16)0.f : (bf16)(k * w * ((float)pv[c] - tg));
     o[c + 4] = (bf16)0.f;
   }
   *(bf16x8*)(p.dpred + i * 8) = o;

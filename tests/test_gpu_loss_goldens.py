@@ -187,7 +187,10 @@ def test_ddpm_training_step_cases(L, golden):
         oracle = float(R.ddpm_loss(pred.to(torch.bfloat16).float(), lat, noise, ts))
         print(f"[parity] {k} t={int(ts[0])}: hip {o[0]:.6e} oracle(bf16 pred) {oracle:.6e} reference(fp32 pred) {want:.6e}")
         assert abs(o[0] - oracle) <= 1e-5 * abs(oracle) + 1e-9, (k, o[0], oracle)
-        assert abs(o[0] - want) <= 1e-3 * abs(want), (k, o[0], want)
+        # the golden was produced with an fp32 stand-in prediction; the device kernel (like the reference's bf16 UNet) consumes
+        # a bf16 prediction.  At t = 0 (sigma = 2e4) the loss is min(snr, 5) * pred^2 with |pred| ~ 1e4: the rounding of the
+        # prediction alone moves it by up to one bf16 epsilon (2^-8); the arithmetic itself is pinned by the line above.
+        assert abs(o[0] - want) <= 4e-3 * abs(want), (k, o[0], want)
         assert abs(o[4] / lat.numel() - float(golden[f"{k}_m_noise_scale"])) <= 1e-5 * float(golden[f"{k}_m_noise_scale"])
         assert abs(o[2] / lat.numel() - float(golden[f"{k}_m_pred_scale"])) <= 2e-3 * float(golden[f"{k}_m_pred_scale"])
 
