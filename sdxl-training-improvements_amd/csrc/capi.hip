@@ -384,13 +384,7 @@ static int run_backward_segment(Engine& e, int k, bool first, hipStream_t st) {
   int s = e.nseg - 1 - k;
   e.ev_used = 0;   // per-op events are consumed in order; a segment's waits are all enqueued before the pool is reused
   if (k == 0 && p.tp32_off != NONE) HIP_CHECK_RET(hipMemsetAsync(p.F(p.tp32_off), 0, p.tp32_bytes, st));
-  for (int i = p.seg_last_op[s]; i >= p.seg_first_op[s] && i >= 0; --i) {
-    if (p.early_bwd_after >= 0 && p.ops[i]->hoist_fwd) continue;       // already issued, see below
-    CHK(p.ops[i]->bwd(p, st, first));
-    if (i == p.early_bwd_after)   // the hoisted projections' output gradient is complete: their weight gradient goes out now, under the
-      for (auto& op : p.ops)      // rest of the backward, not alone at its end
-        if (op->hoist_fwd) CHK(op->bwd(p, st, first));
-  }
+  for (int i = p.seg_last_op[s]; i >= p.seg_first_op[s] && i >= 0; --i) CHK(p.ops[i]->bwd(p, st, first));
   // the segment's weight gradients are complete once `st` passes this point -- unless the caller declared (sdxl_set_join_mode)
   // that it only needs that of the whole backward (no per-segment gradient exchange): then the side stream runs free
   // until the last segment (nothing on the main stream reads a weight gradient, and no gradient buffer is reused)

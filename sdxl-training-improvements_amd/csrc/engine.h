@@ -72,8 +72,6 @@ struct Plan {
   std::vector<int> seg_first_op, seg_last_op;  // op index ranges per segment (forward order)
   size_t tp32_off = NONE, tp32_bytes = 0;   // fp32 [B][sum Cout] time-embedding-projection gradient (zeroed at the start of a backward;
                                             // every resnet's conv1 backward adds its per-sample column sums into its slice)
-  int early_bwd_after = -1;   // the backward of the hoisted ops (whose forward index is ~0: they would run last, alone) is issued
-                              // right after the backward of this op, the last writer of their output gradient
   // well-known buffers
   Act *x_in = nullptr, *pred = nullptr, *ehs = nullptr, *aug_in = nullptr, *te_sin = nullptr, *tid_emb = nullptr;
   size_t t_off = NONE, tid_off = NONE, loss_off = NONE;

@@ -700,12 +700,14 @@ struct Builder {
       pl->in_tag_off = pl->alloc(sizeof(float) * B);
       tagseg(pl->add<EmbedInOp>(), PRef());
     }
-    {
+    auto register_kv = [&]() {
       // Cross-attention K / V projections of ALL transformer blocks as ONE GEMM: they share the A operand (the prompt
       // embeddings, [B*77][2048]) and depend on nothing else, so the 70 per-block launches (M = 308 rows: 119 TFLOP/s each)
       // become one [308] x [sum 2C = 166 400] x [2048] problem on the side stream at the start of the forward, and their 70
-      // weight-gradient launches one TN GEMM at the end of the backward.  The weights are therefore registered first,
-      // contiguously (the arena's first segment); every block's attention reads / writes its column slice of the result.
+      // weight-gradient launches one TN GEMM.  The weight is registered (and the op placed) right before the first transformer
+      // block: in the backward its gradient is then complete -- and, a segment of its own (Engine::build), exchanged -- as soon
+      // as the last cross-attention backward has run, under the remaining ~25 ms of the backward, not after its end.
+      // Every block's attention reads / writes its column slice of the result.
       std::vector<std::pair<std::string, int>> blocks;
       auto add_tf = [&](const std::string& p, int C, int depth) {
         for (int k = 0; k < depth; ++k) blocks.emplace_back(p + ".transformer_blocks." + std::to_string(k), C);
@@ -733,7 +735,7 @@ struct Builder {
         LinearOp* op = tagseg(pl->add<LinearOp>(ehs, kv_all, wkv, PRef(), cross, (int)ntot, nullptr), wkv);
         op->hoist_fwd = true;
       }
-    }
+    };
     {
       // The 17 resnets' time_emb_proj (Linear(silu(emb)) [B][1280] -> [B][Cout]) as ONE GEMM: rows of all of them contiguous
       // in the arena (first segment, like the K | V weight: its gradient completes last), each resnet's conv1 reads its
@@ -782,8 +784,10 @@ struct Builder {
         std::string p = "down_blocks." + std::to_string(i);
         x = resnet(p + ".resnets." + std::to_string(j), x, h, w, prev, ch[i]);
         prev = ch[i];
-        if (c.transformer_layers[i] > 0)
+        if (c.transformer_layers[i] > 0) {
+          if (kv_col.empty()) register_kv();
           x = transformer(p + ".attentions." + std::to_string(j), x, ehs, h, w, ch[i], c.transformer_layers[i]);
+        }
         skips.push_back({x, prev});
       }
       if (i < 2) {
@@ -794,6 +798,7 @@ struct Builder {
       }
     }
     x = resnet("mid_block.resnets.0", x, h, w, prev, prev);
+    if (kv_col.empty()) register_kv();
     x = transformer("mid_block.attentions.0", x, ehs, h, w, prev, c.transformer_layers[2]);
     x = resnet("mid_block.resnets.1", x, h, w, prev, prev);
     for (int ui = 0; ui < 3; ++ui) {
@@ -843,6 +848,11 @@ void Engine::build(Plan* plan) {
     size_t start = 0;
     for (size_t i = 0; i < natives.size(); ++i) {
       size_t end = i + 1 < natives.size() ? natives[i + 1].off : param_elems;
+      if (natives[i].numel >= target && natives[i].off > start) {   // a parameter larger than the target (the grouped K | V
+        seg_begin.push_back(start);                                  // weight) gets a segment of its own: close the open one
+        seg_end.push_back(natives[i].off);
+        start = natives[i].off;
+      }
       if (end - start >= target || i + 1 == natives.size()) {
         seg_begin.push_back(start);
         seg_end.push_back(end);
@@ -860,8 +870,6 @@ void Engine::build(Plan* plan) {
     plan->apart_off = plan->alloc(sizeof(float) * (plan->apart_floats ? plan->apart_floats : 4));
     plan->seg_first_op.assign(nseg, -1);
     plan->seg_last_op.assign(nseg, -2);
-    for (int i = (int)plan->ops.size() - 1; i >= 0; --i)
-      if (plan->ops[i]->needs_hoisted) plan->early_bwd_after = i;
     for (int i = 0; i < (int)plan->ops.size(); ++i) {
       int s = plan->ops[i]->seg;
       if (plan->seg_first_op[s] < 0) plan->seg_first_op[s] = i;
