@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, nargs="*", default=None, help="thread counts of the CPU baseline (default: one socket's cores, 8)")
     ap.add_argument("--exchange", default="zero1", choices=["zero1", "allreduce"],
                     help="N > 1: reduce-scatter of the gradient buckets (ZeRO-1, default) or all-reduce")
+    ap.add_argument("--no-emit", action="store_true", help="N > 1 A/B: cast the fp32 gradient arena per bucket instead of bf16 wgrad epilogues")
     ap.add_argument("--profile-steps", type=int, default=1, help="extra steps with per-launch GEMM event timing")
     ap.add_argument("--gemm-mode", type=int, default=None, help="A/B runs: sdxl_set_gemm_mode (0 = 128-row kernel only)")
     ap.add_argument("--lib", default=None, help="A/B runs: another build of libsdxlstep.so (e.g. last round's) on the same box")
@@ -176,7 +177,12 @@ def main():
     b = make_batch(wl, rank, dev)
     L = net.L
 
+    emit = world > 1 and not args.no_emit and hasattr(L, "sdxl_set_grad_emit")
+
     def cast(off, n, dst):
+        if emit:           # the wgrad GEMMs write bf16 into the exchange arena themselves: only biases / norm parameters are cast
+            net.cast_small(off, n, dst)
+            return
         lib.check(L.sdxl_grads_to_bf16(net.h, off, n, C.c_void_p(dst.data_ptr()), 1.0,
                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
@@ -187,11 +193,13 @@ def main():
     Sync = D.ShardedGradSync if args.exchange == "zero1" else D.GradSync
     sync = Sync(net.param_elems, cast, torch.bfloat16, dev)
     scale = 1.0 / world
+    if emit:
+        net.set_grad_emit(sync.comm, 1.0)
 
     def step():
         net.zero_grads()
         net.forward_loss(wl["method"], b["lat"], b["noise"], b["sigma_or_t"], b["timestep"], b["ehs"], b["pooled"], b["tid"])
-        net.backward(scale, True, on_segment=sync.on_segment if world > 1 else None)
+        net.backward(scale, True, on_segment=sync.on_segment if world > 1 else None, segment_stream=True)
         sync.finish()
 
     for _ in range(args.warmup):

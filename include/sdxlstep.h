@@ -103,8 +103,13 @@ int sdxl_backward_segment(sdxl_handle* h, int seg, float grad_scale, int first_m
 /* By default the stream waits, at the end of every segment, for that segment's weight gradients (they run on an internal
  * side stream), so a caller can hand the segment to the gradient exchange.  A caller that consumes gradients only after
  * the whole backward (single GPU, or accumulation micro-steps without exchange) may set last_only = 1: the wait then
- * happens once, in the last segment (sdxl_loss_fwd_bwd always ends with it). */
-int sdxl_set_join_mode(sdxl_handle* h, int last_only);
+ * happens once, in the last segment (sdxl_loss_fwd_bwd always ends with it).
+ * mode 2: as 1, and at every segment end the SIDE stream (sdxl_side_stream) waits for the caller's stream instead: a
+ * caller that enqueues the segment's cast (sdxl_grads_to_bf16) and collective on the side stream gets the exchange
+ * started without the caller's stream -- the critical path of the backward -- ever waiting or running the casts. */
+int sdxl_set_join_mode(sdxl_handle* h, int mode);
+/* the engine's side stream (hipStream_t; NULL when the serialized measurement mode is on) */
+int sdxl_side_stream(sdxl_handle* h, void** stream);
 /* convenience: forward + all backward segments */
 int sdxl_loss_fwd_bwd(sdxl_handle* h, const sdxl_loss_config* lc, const sdxl_batch* b, float grad_scale,
                       int first_micro, void* stream);
@@ -127,6 +132,13 @@ int sdxl_unet_backward(sdxl_handle* h, const void* dpred_nhwc8, int first_micro,
 
 /* fp32 grads -> bf16 (scaled) for the gradient exchange; global L2 norm of the fp32 grads */
 int sdxl_grads_to_bf16(sdxl_handle* h, size_t elem_offset, size_t elems, void* dst_bf16, float scale, void* stream);
+/* Exchange micro-step without the cast pass: with a bf16 arena set (element offsets = the gradient arena's; NULL turns it
+ * off), every weight-gradient GEMM of the following backward calls writes its FINAL value (including what earlier
+ * micro-steps accumulated in fp32) x scale as bf16 there and leaves the fp32 arena alone; sdxl_small_grads_to_bf16 then
+ * casts what the GEMMs do not produce (biases, norm parameters) for a segment range.  The fp32 arena is NOT the step's
+ * gradient afterwards: use this only when the bf16 arena is what the exchange / optimizer consume. */
+int sdxl_set_grad_emit(sdxl_handle* h, void* bf16_arena, float scale);
+int sdxl_small_grads_to_bf16(sdxl_handle* h, size_t elem_offset, size_t elems, void* dst_bf16, float scale, void* stream);
 int sdxl_grad_sumsq(sdxl_handle* h, float* out_dev, void* stream);
 /* row f3 pieces: squared L2 norm of any fp32 (dtype 0) / bf16 (1) device array -- e.g. the all-reduced bf16 gradient
  * arena -- and torch.nn.utils.clip_grad_norm_'s coefficient min(1, max_norm / (norm + 1e-6)) computed on the device;

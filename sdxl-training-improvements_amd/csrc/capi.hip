@@ -69,6 +69,7 @@ int sdxl_create(const sdxl_unet_config* cfg, int device, sdxl_handle** out) {
     HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_gin, hipEventDisableTiming));
     HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_gout, hipEventDisableTiming));
     HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_seg, hipEventDisableTiming | hipEventDisableSystemFence));
     HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_hoist, hipEventDisableTiming | hipEventDisableSystemFence));
   }
   *out = h;
@@ -86,6 +87,7 @@ int sdxl_destroy(sdxl_handle* h) {
   if (h->e.ev_gout) (void)hipEventDestroy(h->e.ev_gout);
   for (hipEvent_t ev : h->e.ev_pool) (void)hipEventDestroy(ev);
   if (h->e.ev_join) (void)hipEventDestroy(h->e.ev_join);
+  if (h->e.ev_seg) (void)hipEventDestroy(h->e.ev_seg);
   if (h->e.ev_hoist) (void)hipEventDestroy(h->e.ev_hoist);
   if (h->e.side) (void)hipStreamDestroy(h->e.side);
   if (h->e.small_ranges_dev) (void)hipFree(h->e.small_ranges_dev);
@@ -212,6 +214,7 @@ static int ready(Engine& e) {
 
 // zero the gradient ranges that are accumulated with atomics (bias / norm vectors: ~2.6 M of the 2.57 G elements);
 // the weight matrices are overwritten by the first micro-step's wgrad GEMMs (first_micro) and need no zeroing
+static int small_ranges_on_device(Engine& e);
 __global__ void zero_ranges_kernel(float* __restrict__ g, const unsigned long long* __restrict__ ranges) {
   const unsigned long long off = ranges[2 * blockIdx.x], n = ranges[2 * blockIdx.x + 1];
   for (unsigned long long i = threadIdx.x; i < n; i += blockDim.x) g[off + i] = 0.f;
@@ -221,12 +224,7 @@ int sdxl_zero_grads(sdxl_handle* h, void* st) {
   H_CHECK(h);
   Engine& e = h->e;
   ARG_CHECK(e.grads, "grads are not bound");
-  if (!e.small_ranges_dev) {
-    std::vector<unsigned long long> flat;
-    for (auto& r : e.small_ranges) { flat.push_back(r.first); flat.push_back(r.second); }
-    HIP_CHECK_RET(hipMalloc((void**)&e.small_ranges_dev, flat.size() * sizeof(unsigned long long)));
-    HIP_CHECK_RET(hipMemcpy(e.small_ranges_dev, flat.data(), flat.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
-  }
+  CHK(small_ranges_on_device(e));
   hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)e.small_ranges.size()), dim3(256), 0, (hipStream_t)st, e.grads,
                      e.small_ranges_dev);
   HIP_CHECK_RET(hipGetLastError());
@@ -364,9 +362,17 @@ int sdxl_forward_loss(sdxl_handle* h, const sdxl_loss_config* lc, const sdxl_bat
 }
 
 int sdxl_num_segments(sdxl_handle* h) { return h ? h->e.nseg : -1; }
-int sdxl_set_join_mode(sdxl_handle* h, int last_only) {
+int sdxl_set_join_mode(sdxl_handle* h, int mode) {
   H_CHECK(h);
-  h->e.join_last_only = last_only != 0;
+  ARG_CHECK(mode >= 0 && mode <= 2, "join mode %d (0, 1, 2)", mode);
+  h->e.join_last_only = mode != 0;
+  h->e.seg_on_side = mode == 2 && h->e.use_side && h->e.side;
+  return 0;
+}
+int sdxl_side_stream(sdxl_handle* h, void** stream) {
+  H_CHECK(h);
+  ARG_CHECK(stream, "null output");
+  *stream = h->e.use_side ? (void*)h->e.side : nullptr;
   return 0;
 }
 
@@ -390,6 +396,11 @@ static int run_backward_segment(Engine& e, int k, bool first, hipStream_t st) {
   // until the last segment (nothing on the main stream reads a weight gradient, and no gradient buffer is reused)
   CHK(e.flush_wgrads(p, st));
   CHK(e.flush_ln_params(p, st));
+  if (e.seg_on_side && !gemm_profiling()) {   // the side stream sees the segment's main-stream gradients (norm parameters, ...)
+    HIP_CHECK_RET(hipEventRecord(e.ev_seg, st));
+    HIP_CHECK_RET(hipStreamWaitEvent(e.side, e.ev_seg, 0));
+    e.side_dirty = true;                       // (the caller's cast + collective follow on the side stream)
+  }
   if (e.side_dirty && !(e.join_last_only && k != e.nseg - 1)) {
     HIP_CHECK_RET(hipEventRecord(e.ev_join, e.side));
     HIP_CHECK_RET(hipStreamWaitEvent(st, e.ev_join, 0));
@@ -491,6 +502,42 @@ int sdxl_grads_to_bf16(sdxl_handle* h, size_t off, size_t n, void* dst, float sc
   H_CHECK(h);
   ARG_CHECK(h->e.grads && off + n <= h->e.param_elems, "range out of bounds");
   return launch_f32_to_bf16(h->e.grads + off, (bf16*)dst, (long)n, scale, (hipStream_t)st);
+}
+
+// bf16 cast of the SMALL parameter ranges (biases, norm weights: the fp32-atomic accumulators) inside [off, off + n): what is
+// left to cast when the weight-gradient GEMMs emit bf16 themselves (sdxl_set_grad_emit)
+__global__ void cast_small_ranges_kernel(const float* __restrict__ g, bf16* __restrict__ dst, const unsigned long long* __restrict__ ranges,
+                                         unsigned long long lo, unsigned long long hi, float scale) {
+  const unsigned long long off = ranges[2 * blockIdx.x], n = ranges[2 * blockIdx.x + 1];
+  if (off < lo || off + n > hi) return;
+  for (unsigned long long i = threadIdx.x; i < n; i += blockDim.x) dst[off - lo + i] = (bf16)(g[off + i] * scale);
+}
+static int small_ranges_on_device(Engine& e) {
+  if (!e.small_ranges_dev) {
+    std::vector<unsigned long long> flat;
+    for (auto& r : e.small_ranges) { flat.push_back(r.first); flat.push_back(r.second); }
+    HIP_CHECK_RET(hipMalloc((void**)&e.small_ranges_dev, flat.size() * sizeof(unsigned long long)));
+    HIP_CHECK_RET(hipMemcpy(e.small_ranges_dev, flat.data(), flat.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+int sdxl_small_grads_to_bf16(sdxl_handle* h, size_t off, size_t n, void* dst, float scale, void* st) {
+  H_CHECK(h);
+  Engine& e = h->e;
+  ARG_CHECK(e.grads && off + n <= e.param_elems && dst, "range out of bounds");
+  CHK(small_ranges_on_device(e));
+  if (e.small_ranges.empty()) return 0;
+  hipLaunchKernelGGL(cast_small_ranges_kernel, dim3((unsigned)e.small_ranges.size()), dim3(256), 0, (hipStream_t)st, e.grads, (bf16*)dst,
+                     e.small_ranges_dev, (unsigned long long)off, (unsigned long long)(off + n), scale);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int sdxl_set_grad_emit(sdxl_handle* h, void* bf16_arena, float scale) {
+  H_CHECK(h);
+  ARG_CHECK(((uintptr_t)bf16_arena & 15) == 0, "bf16 gradient arena must be 16-byte aligned");
+  h->e.emit_base = (bf16*)bf16_arena;
+  h->e.emit_scale = scale;
+  return 0;
 }
 
 int sdxl_grad_sumsq(sdxl_handle* h, float* out, void* st) {

@@ -126,7 +126,12 @@ struct Engine {
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
   bool use_side = true;
-  bool join_last_only = false;   // sdxl_set_join_mode: main waits for the side stream at the last segment only
+  bf16* emit_base = nullptr;     // sdxl_set_grad_emit: weight-gradient GEMMs write their final value as bf16 into this arena (same
+  float emit_scale = 1.f;        // element offsets as `grads`) instead of the fp32 arena -- the exchange micro-step under data parallelism
+  bool join_last_only = false;   // sdxl_set_join_mode 1 / 2: main waits for the side stream at the last segment only
+  bool seg_on_side = false;      // sdxl_set_join_mode 2: at every segment end the SIDE stream waits for main instead; the caller
+                                 // enqueues the segment's cast + collective on the side stream (sdxl_side_stream)
+  hipEvent_t ev_seg = nullptr;
   hipEvent_t next_event();
   std::vector<std::vector<GemmP>> wg_pending;   // weight gradients waiting for a grouped launch, one bucket per shape
   int defer_wgrad(Plan& p, hipStream_t main, const GemmP& g, int grp);

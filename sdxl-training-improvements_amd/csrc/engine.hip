@@ -99,7 +99,7 @@ static int launch_wgrad_bucket(Plan& p, hipStream_t main, std::vector<GemmP>& v)
     g.splitk = 1;
     g.group = (int)v.size();
     for (size_t i = 0; i < v.size(); ++i) {
-      g.gA[i] = v[i].A; g.gB[i] = v[i].B; g.gC[i] = (float*)v[i].C; g.gbias_grad[i] = v[i].bias_grad;
+      g.gA[i] = v[i].A; g.gB[i] = v[i].B; g.gC[i] = (float*)v[i].C; g.gbias_grad[i] = v[i].bias_grad; g.gCb[i] = v[i].Cb;
     }
   }
   v.clear();
@@ -208,6 +208,7 @@ struct LinearOp : Op {
       g.slab = p.F(p.slab_off);
       g.accumulate = first ? 0 : 1;
       g.bias_grad = b.off != NONE ? p.eng->Gp(b) : nullptr;   // column sums of dY ride along on the matrix pipe
+      if (p.eng->emit_base) { g.Cb = p.eng->emit_base + w.off; g.cb_scale = p.eng->emit_scale; }
       const int pad = x->pad_rows < y->pad_rows ? x->pad_rows : y->pad_rows;
       if (pad > 0 && (M + pad) % 64 == 0) {     // zero rows appended to both operands: every reduction step is a full one
         g.K = M + pad;
@@ -301,6 +302,7 @@ struct ConvOp : Op {
       g.slab = p.F(p.slab_off);
       g.accumulate = first ? 0 : 1;
       g.bias_grad = p.eng->Gp(b);
+      if (p.eng->emit_base) { g.Cb = p.eng->emit_base + w.off; g.cb_scale = p.eng->emit_scale; }
       CHK(launch_gemm(g, s2));
       return 0;
     }));

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
   GemmP p = pin;
   if (FORM == GEMM_TN && pin.group > 1) {          // grouped launch: this workgroup's problem
     const int gi = blockIdx.z;
-    p.A = pin.gA[gi]; p.B = pin.gB[gi]; p.C = pin.gC[gi]; p.bias_grad = pin.gbias_grad[gi];
+    p.A = pin.gA[gi]; p.B = pin.gB[gi]; p.C = pin.gC[gi]; p.bias_grad = pin.gbias_grad[gi]; p.Cb = pin.gCb[gi];
   }
   static_assert(!KSP || (NW == 8 && BK == 64 && FAST && S >= 3 && FORM != GEMM_TN), "split-K groups: 8 waves, BK 64, FAST staging, ring >= 3");
   constexpr int BMT = BM;
@@ -614,6 +614,15 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
           float* c = (float*)p.C + (long)m * p.ldc + (long)tap_fixed * p.c_tap_stride + n;
           if (p.splitk > 1) {   // deterministic split-K: partial tile to this split's slab, summed by splitk_reduce_kernel
             *(f32x4*)(p.slab + ((long)split * p.M + m) * p.slab_ld + (long)tap_fixed * p.c_tap_stride + n) = x;
+          } else if (p.Cb) {    // final value straight to the bf16 exchange arena (C is read for the sum, not written)
+            if (p.accumulate) {
+              const f32x4 a = *(const f32x4*)c;
+              x[0] += a[0]; x[1] += a[1]; x[2] += a[2]; x[3] += a[3];
+            }
+            bf16x4 o;
+            o[0] = (bf16)(x[0] * p.cb_scale); o[1] = (bf16)(x[1] * p.cb_scale);
+            o[2] = (bf16)(x[2] * p.cb_scale); o[3] = (bf16)(x[3] * p.cb_scale);
+            *(bf16x4*)(p.Cb + (long)m * p.ldc + (long)tap_fixed * p.c_tap_stride + n) = o;
           } else if (p.accumulate) {
             f32x4 a = *(f32x4*)c;
             a[0] += x[0]; a[1] += x[1]; a[2] += x[2]; a[3] += x[3];
@@ -719,7 +728,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
 
 // C[m][0..cols) (+)= sum_s slab[s][m][0..cols)   (fixed summation order)
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, int M, int cols, long ldc,
-                                     long slab_ld, int splitk, int accumulate) {
+                                     long slab_ld, int splitk, int accumulate, bf16* __restrict__ Cb, float cb_scale) {
   const int vpr = cols / 4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)M * vpr; i += (long)gridDim.x * blockDim.x) {
     long m = i / vpr;
@@ -729,7 +738,13 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __re
       f32x4 v = *(const f32x4*)(slab + ((long)s * M + m) * slab_ld + c);
       a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
     }
-    *(f32x4*)(C + m * ldc + c) = a;
+    if (Cb) {     // GemmP::Cb: the final value as bf16 to the exchange arena, C untouched
+      bf16x4 o;
+      o[0] = (bf16)(a[0] * cb_scale); o[1] = (bf16)(a[1] * cb_scale); o[2] = (bf16)(a[2] * cb_scale); o[3] = (bf16)(a[3] * cb_scale);
+      *(bf16x4*)(Cb + m * ldc + c) = o;
+    } else {
+      *(f32x4*)(C + m * ldc + c) = a;
+    }
   }
 }
 
@@ -957,6 +972,9 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
   }
   if (p.form == GEMM_TN) {
     ARG_CHECK(!p.geglu, "gemm TN: no geglu epilogue");
+    ARG_CHECK(!p.Cb || (((uintptr_t)p.Cb & 7) == 0), "gemm TN: bf16 destination must be 8-byte aligned");
+  } else {
+    ARG_CHECK(!p.Cb, "gemm: the bf16 gradient destination is a TN (wgrad) option");
   }
   if (p.splitk < 1) p.splitk = 1;
   if (p.group > 1) {
@@ -965,7 +983,7 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
     for (int i = 0; i < p.group; ++i)
       ARG_CHECK(p.gA[i] && p.gB[i] && p.gC[i] && (((uintptr_t)p.gA[i] | (uintptr_t)p.gB[i] | (uintptr_t)p.gC[i]) & 15) == 0,
                 "gemm: grouped operands must be set and 16-byte aligned");
-    p.A = p.gA[0]; p.B = p.gB[0]; p.C = p.gC[0]; p.bias_grad = p.gbias_grad[0];
+    p.A = p.gA[0]; p.B = p.gB[0]; p.C = p.gC[0]; p.bias_grad = p.gbias_grad[0]; p.Cb = p.gCb[0];
   } else {
     p.group = 0;
   }
@@ -990,7 +1008,7 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
   const bool conv = p.taps == 9;
   int rc;
   {   // 256 x 256 kernel (gemm256.hip)
-    if (g_mode256 && p.group <= 1 && gemm256_applicable(p)) {
+    if (g_mode256 && p.group <= 1 && !p.Cb && gemm256_applicable(p)) {
       if (g_mode256 == 2 || gemm_use256(p.form, p.M, p.N, p.K, p.splitk)) {
         rc = launch_gemm256(p, st);
         if (rc == 0 && p.splitk > 1) {
@@ -998,7 +1016,7 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
           int g = (int)((nv + 255) / 256);
           if (g > 2048) g = 2048;
           hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, st, p.slab, (float*)p.C, p.M, p.N, p.ldc, p.slab_ld,
-                             p.splitk, p.accumulate);
+                             p.splitk, p.accumulate, p.Cb, p.cb_scale);
           HIP_CHECK_RET(hipGetLastError());
         }
         return rc;
@@ -1016,7 +1034,7 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
         int g = (int)((nv + 255) / 256);
         if (g > 2048) g = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, st, p.slab, (float*)p.C, p.M, cols, p.ldc,
-                           p.slab_ld, p.splitk, p.accumulate);
+                           p.slab_ld, p.splitk, p.accumulate, p.Cb, p.cb_scale);
         HIP_CHECK_RET(hipGetLastError());
       }
       return rc;

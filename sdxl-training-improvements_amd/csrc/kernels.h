@@ -54,6 +54,11 @@ struct GemmP {
   int splitk;
   float* slab;     // splitk * M * N * taps floats
   long slab_ld;    // set by the launcher
+  // TN only, optional: the FINAL value (acc [+ C when accumulate]) * cb_scale goes out as bf16 to Cb (same [M][ldc] geometry as C)
+  // and C itself is not written -- the gradient-exchange micro-step under data parallelism wants the bf16 comm arena, and
+  // a separate cast pass over the 10 GB fp32 arena costs 3.4 ms per step (grouped launches: gCb[i])
+  bf16* Cb;
+  float cb_scale;
   float* bias_grad;  // TN only, optional: bias_grad[m] += sum_k A(k, m)  (column sums of dY, computed on the matrix pipe
                      // by the n-tile-0 / tap-0 workgroups with an all-ones B fragment; fp32 atomics, 128 per workgroup)
   int xcd_px;      // set by the launcher: XCD grid width over n-tiles (0 = identity order; SDXL_GEMM_XCD=0 disables)
@@ -65,6 +70,7 @@ struct GemmP {
   const bf16* gB[GEMM_MAX_GROUP];
   float* gC[GEMM_MAX_GROUP];
   float* gbias_grad[GEMM_MAX_GROUP];
+  bf16* gCb[GEMM_MAX_GROUP];
 };
 int gemm_pick_group(int M, int N, int taps, long red, int splitk);   // problems per grouped wgrad launch (1 = launch alone)
 size_t gemm_slab_floats(int M, int N, int taps, int splitk);

@@ -69,6 +69,8 @@ SIGNATURES = {
     "sdxl_unet_forward": [_vp, _vp, _P(Batch), _vp, _vp],
     "sdxl_unet_backward": [_vp, _vp, _i, _vp],
     "sdxl_grads_to_bf16": [_vp, _sz, _sz, _vp, _f, _vp],
+    "sdxl_set_grad_emit": [_vp, _vp, _f],
+    "sdxl_small_grads_to_bf16": [_vp, _sz, _sz, _vp, _f, _vp],
     "sdxl_grad_sumsq": [_vp, _vp, _vp],
     "sdxl_op_gemm": [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp],
     "sdxl_op_wgrad_group": [_i, _P(_vp), _P(_vp), _P(_vp), _P(_vp), _i, _i, _i, _i, _vp],
@@ -82,6 +84,7 @@ SIGNATURES = {
     "sdxl_op_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "sdxl_op_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sdxl_set_join_mode": [_vp, _i],
+    "sdxl_side_stream": [_vp, _P(_vp)],
     "sdxl_sumsq": [_vp, _i, _sz, _vp, _vp],
     "sdxl_clip_coef": [_vp, _f, _vp, _vp],
     "sdxl_param_range": [_vp, _i, _P(_sz), _P(_sz)],

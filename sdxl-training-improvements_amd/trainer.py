@@ -115,6 +115,11 @@ class NativeSDXLTrainer:
 
     # -------------------------------------------------------------------------------- loss
     def _cast(self, off, n, dst):
+        # the exchange micro-step's weight-gradient GEMMs wrote bf16 into the comm arena themselves (set_grad_emit): what is
+        # left to cast per bucket are the biases / norm parameters (fp32 atomic accumulators)
+        if getattr(self, "_emit", False):
+            self.net.cast_small(off, n, dst)
+            return
         lib.check(self.net.L.sdxl_grads_to_bf16(self.net.h, off, n, C.c_void_p(dst.data_ptr()), 1.0,
                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
@@ -189,7 +194,17 @@ class NativeSDXLTrainer:
         exchange = self._exchange and world > 1
         self.sync.enabled = exchange
         # per-segment joins (side stream -> caller's stream) only on the micro-step that exchanges gradients
-        self.net.backward(grad_scale / world, first, on_segment=self.sync.on_segment if exchange else None)
+        if exchange:    # bucket casts + collectives ride the engine's side stream, behind the segment's weight gradients
+            self._emit = hasattr(self.net, "set_grad_emit") and self.sync.comm is not None
+            if self._emit:
+                self.net.set_grad_emit(self.sync.comm, 1.0)
+            try:
+                self.net.backward(grad_scale / world, first, on_segment=self.sync.on_segment, segment_stream=True)
+            finally:
+                if self._emit:
+                    self.net.set_grad_emit(None)
+        else:
+            self.net.backward(grad_scale / world, first)
         self._micro += 1
         self._zeroed = False
 

@@ -215,10 +215,15 @@ class NativeUNet:
         b = self._batch(latents, noise, sigma_or_t, timestep, prompt_embeds, pooled, time_ids, tag_weights)
         lib.check(self.L.sdxl_forward_loss(self.h, C.byref(lc), C.byref(b), _stream()), "sdxl_forward_loss")
 
-    def backward(self, grad_scale: float = 1.0, first_micro: bool = True, on_segment=None) -> None:
+    def backward(self, grad_scale: float = 1.0, first_micro: bool = True, on_segment=None, segment_stream: bool = False) -> None:
         """All backward segments in reverse execution order; `on_segment(k, offset, count)` is called after segment
-        k's kernels are enqueued (used to start that bucket's gradient all-reduce under the rest of backward)."""
-        lib.check(self.L.sdxl_set_join_mode(self.h, 0 if on_segment is not None else 1))   # per-segment results needed?
+        k's kernels are enqueued (used to start that bucket's gradient exchange under the rest of backward).
+        segment_stream: the callbacks run with the engine's SIDE stream as torch's current stream (join mode 2): the
+        bucket's cast and collective are ordered behind the segment's weight gradients there, and the caller's stream --
+        the backward's critical path -- neither waits for the side stream nor runs the casts (3.5 ms of them per step)."""
+        side = self._side_stream() if (segment_stream and on_segment is not None) else None
+        lib.check(self.L.sdxl_set_join_mode(self.h, 0 if on_segment is not None else 1) if side is None
+                  else self.L.sdxl_set_join_mode(self.h, 2))
         if on_segment is None and hasattr(self.L, "sdxl_backward_all"):     # no per-segment exchange: one call for the whole backward
             lib.check(self.L.sdxl_backward_all(self.h, float(grad_scale), int(first_micro), _stream()), "backward")
             return
@@ -226,7 +231,31 @@ class NativeUNet:
             lib.check(self.L.sdxl_backward_segment(self.h, k, float(grad_scale), int(first_micro), _stream()),
                       f"backward segment {k}")
             if on_segment is not None:
-                on_segment(k, *self.segment_range(k))
+                if side is None:
+                    on_segment(k, *self.segment_range(k))
+                else:
+                    with torch.cuda.stream(side):
+                        on_segment(k, *self.segment_range(k))
+        if side is not None:      # whatever the callbacks left on the side stream (the last cast; host-staged copies of the
+            torch.cuda.current_stream().wait_stream(side)      # gloo test transport) is ordered before the caller's next work
+
+    def set_grad_emit(self, arena: Optional[torch.Tensor], scale: float = 1.0) -> None:
+        """Exchange micro-step without the cast pass: the weight-gradient GEMMs of the next backward write their final
+        value x scale as bf16 into `arena` (param_elems bf16, the exchange arena) and leave the fp32 arena alone; None = off.
+        `cast_small` then covers the biases / norm parameters of a segment."""
+        if arena is not None:
+            assert arena.dtype == torch.bfloat16 and arena.numel() >= self.param_elems and arena.is_contiguous()
+        lib.check(self.L.sdxl_set_grad_emit(self.h, None if arena is None else _ptr(arena), float(scale)))
+
+    def cast_small(self, off: int, n: int, dst: torch.Tensor, scale: float = 1.0) -> None:
+        lib.check(self.L.sdxl_small_grads_to_bf16(self.h, off, n, _ptr(dst), float(scale), _stream()))
+
+    def _side_stream(self):
+        if getattr(self, "_side_ext", None) is None:
+            p = C.c_void_p()
+            lib.check(self.L.sdxl_side_stream(self.h, C.byref(p)))
+            self._side_ext = torch.cuda.ExternalStream(p.value, device=self.device) if p.value else False
+        return self._side_ext or None
 
     def set_graph_mode(self, on: bool) -> None:
         """hipGraph replay of forward / backward (default off: eager two-stream launches measured faster on ROCm 7.2)."""
