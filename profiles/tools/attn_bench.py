@@ -4,6 +4,8 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import sdxl_amd
 from sdxl_amd import lib
+if '--lib' in sys.argv:      # knock-out builds (tools/build_diag_attn.sh)
+    lib.LIB_PATH = Path(sys.argv[sys.argv.index('--lib') + 1]).resolve()
 L = lib.load(); dev = torch.device('cuda:0')
 ptr = lambda t: C.c_void_p(t.data_ptr())
 r = lambda *s: torch.randn(*s, device=dev).to(torch.bfloat16)

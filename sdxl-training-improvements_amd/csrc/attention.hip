@@ -124,7 +124,24 @@ __device__ __forceinline__ float sum_over_g(float x) {
 // (The first version read each V^T fragment right before its two MFMAs: ~100 cycles of exposed LDS latency eight times
 // per tile; PMC: 45 % of the wave cycles issue-stalled, profiles/r02d.)
 // ------------------------------------------------------------------------------------------------
+#if defined(ATTN_DIAG) && (ATTN_DIAG & 256)
+__device__ unsigned long long g_attn_wg[4096 * 3];
+extern "C" int sdxl_debug_attn_wg(unsigned long long* out) {
+  if (hipDeviceSynchronize() != hipSuccess) return 2;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_wg), sizeof(unsigned long long) * 4096 * 3) == hipSuccess ? 0 : 2;
+}
+#endif
+#if defined(ATTN_DIAG) && (ATTN_DIAG & 128)
+__device__ unsigned long long g_attn_stamps[4 * 4 * 6];
+extern "C" int sdxl_debug_attn_stamps(unsigned long long* out) {
+  if (hipDeviceSynchronize() != hipSuccess) return 2;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_stamps), sizeof(unsigned long long) * 96) == hipSuccess ? 0 : 2;
+}
+#endif
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
+#if defined(ATTN_DIAG) && (ATTN_DIAG & 256)
+  const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
   __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE_ELEMS];  // K0 V0 K1 V1
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l16 = lane & 15, g = lane >> 4;
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
@@ -149,6 +166,17 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
     for (int j = 0; j < 2; ++j) ot[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float mrow[2] = {-1e30f, -1e30f}, lrow[2] = {0.f, 0.f};
   const float c = SCALE * LOG2E;
+#ifdef ATTN_DIAG   // diagnostics only (never defined in the product build; profiles/tools/build_diag_attn.sh): knock out one component of
+  constexpr int dbg = ATTN_DIAG;   // the tile loop -- 1: no exp, 2: no S MFMAs, 4: no PV MFMAs, 8: no max / rescale logic, 32: no K fragment
+#else                              // reads, 64: no V^T fragment reads (tile-dependent stand-ins: nothing becomes loop-invariant);
+  constexpr int dbg = 0;           // 128: s_memtime per phase (attn_stamps.py); 256: start / end / placement per workgroup (attn_wg_trace.py)
+#endif
+#if defined(ATTN_DIAG) && (ATTN_DIAG & 128)
+  unsigned long long acc_ph[6] = {0, 0, 0, 0, 0, 0}, ts_prev = 0;
+#define ATTN_STAMP(ph) { unsigned long long ts_ = __builtin_amdgcn_s_memtime(); acc_ph[ph] += ts_ - ts_prev; ts_prev = ts_; }
+#else
+#define ATTN_STAMP(ph)
+#endif
 
   const int ntiles = (p.Nk + 63) / 64;
   const TileSrc ksrc = tile_src(Kb, p.ldk, wave, lane), vsrc = tile_src(Vb, p.ldv, wave, lane);
@@ -160,8 +188,11 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
   // one key tile; MASK: the tile holds keys beyond Nk (only the last tile of a ragged sequence)
   auto tile = [&](int t, auto MASKC) {
     constexpr bool MASK = decltype(MASKC)::value;
+    ATTN_STAMP(5)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my DMA pieces of tile t have landed ...
+    ATTN_STAMP(0)
     __syncthreads();                                     // ... everyone's have; everyone is done with the other buffer
+    ATTN_STAMP(1)
     if (t + 1 < ntiles) {
       tile_dma(ksrc, t + 1, p.Nk, sm + ((buf ^ 1) * 2) * TILE_ELEMS, wave);
       tile_dma(vsrc, t + 1, p.Nk, sm + ((buf ^ 1) * 2 + 1) * TILE_ELEMS, wave);
@@ -172,6 +203,11 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
     bf16x8 kf[4][2];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
+      if (dbg & 32) {
+        kf[kb][0] = qf[0][0]; kf[kb][1] = qf[1][1];
+        asm volatile("v_add_u32 %0, %0, %1" : "+v"(*(unsigned*)&kf[kb][0]) : "s"(t));
+        continue;
+      }
       kf[kb][0] = ld_frag(Kt, kb * 16 + l16, g * 8);
       kf[kb][1] = ld_frag(Kt, kb * 16 + l16, 32 + g * 8);
     }
@@ -181,8 +217,11 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
         f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb][0], qf[qb][0], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb][1], qf[qb][1], a, 0, 0, 0);
+        if (dbg & 2) { a[0] = (float)kf[kb][0][0]; a[1] = (float)qf[qb][1][1]; a[2] = a[0] + 1.f; a[3] = a[1] - 1.f; }
+        else {
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb][0], qf[qb][0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb][1], qf[qb][1], a, 0, 0, 0);
+        }
         st[kb][qb] = a;
       }
     // V^T fragments for the second product: requested now, consumed after the softmax arithmetic
@@ -190,8 +229,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) vfr[db][t2] = tr_frag(Vt, t2, db * 16, l16, g);
+      for (int t2 = 0; t2 < 2; ++t2) {
+        if (dbg & 64) { vfr[db][t2] = qf[t2][db & 1]; asm volatile("v_add_u32 %0, %0, %1" : "+v"(*(unsigned*)&vfr[db][t2]) : "s"(t)); }
+        else vfr[db][t2] = tr_frag(Vt, t2, db * 16, l16, g);
+      }
     __builtin_amdgcn_sched_barrier(0);
+    ATTN_STAMP(2)
     if (MASK) {
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
@@ -209,8 +252,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kb][qb][r]);
-      mx = max_over_g(mx);
+        for (int r = 0; r < 4; ++r) { if (!(dbg & 8)) mx = fmaxf(mx, st[kb][qb][r]); }
+      if (!(dbg & 8)) mx = max_over_g(mx);
       // lazy rescaling: the running reference mrow only moves when some query's tile maximum exceeds it by more than
       // 2^8 in the exponent (p <= 256 until then: exact in fp32 sums, same relative precision in bf16); after the first
       // tiles that is rare, and the accumulator rescale (alpha, 16 two-wide multiplies) is skipped wave-uniformly
@@ -232,7 +275,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {      // two-wide fp32 arithmetic on the register pairs of the MFMA results
           const f32x2 arg = (f32x2){st[kb][qb][2 * hh], st[kb][qb][2 * hh + 1]} * c + nmc;
-          const f32x2 e = (f32x2){__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+          const f32x2 e = (dbg & 1) ? arg : (f32x2){__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
           st[kb][qb][2 * hh] = e[0]; st[kb][qb][2 * hh + 1] = e[1];
           ls2 += e;
         }
@@ -242,6 +285,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
       pf[1][qb] = pack8(st[2][qb], st[3][qb]);
     }
     __builtin_amdgcn_sched_barrier(0);
+    ATTN_STAMP(3)
     // O^T[d][q] += V^T . P^T
 #pragma unroll
     for (int db = 0; db < 4; ++db)
@@ -249,12 +293,22 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
       for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
-          ot[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[db][t2], pf[t2][qb], ot[db][qb], 0, 0, 0);
+          if (dbg & 4) ot[db][qb][0] += (float)vfr[db][t2][0] + (float)pf[t2][qb][1];
+          else ot[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[db][t2], pf[t2][qb], ot[db][qb], 0, 0, 0);
     buf ^= 1;
   };
   const int nfull = p.Nk / 64;
+#if defined(ATTN_DIAG) && (ATTN_DIAG & 128)
+  ts_prev = __builtin_amdgcn_s_memtime();
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();     // constant 100 MHz
+#endif
   for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
   if (nfull < ntiles) tile(nfull, std::true_type{});
+#if defined(ATTN_DIAG) && (ATTN_DIAG & 128)
+  acc_ph[4] = __builtin_amdgcn_s_memrealtime() - rt0;
+  if (lane == 0 && blockIdx.x < 4 && blockIdx.y == 5)
+    for (int i = 0; i < 6; ++i) g_attn_stamps[(blockIdx.x * 4 + wave) * 6 + i] = acc_ph[i];
+#endif
   // finalize
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
@@ -273,6 +327,17 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
       if (g == 0 && p.LSE) p.LSE[(long)bh * p.Nq + q] = mrow[qb] * SCALE + logf(l);
     }
   }
+#if defined(ATTN_DIAG) && (ATTN_DIAG & 256)
+  if (threadIdx.x == 0) {
+    const int id = blockIdx.y * gridDim.x + blockIdx.x;
+    if (id < 4096) {
+      unsigned hwid, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g_attn_wg[id * 3] = wg_t0; g_attn_wg[id * 3 + 1] = __builtin_amdgcn_s_memrealtime(); g_attn_wg[id * 3 + 2] = ((unsigned long long)xcc << 32) | hwid;
+    }
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
