@@ -208,66 +208,47 @@ __global__ void gn_bwd_reduce_kernel(const bf16* __restrict__ x, const bf16* __r
   }
 }
 
-// fixed-order sum over chunks: block = 64 channels x 16 chunk slices -> sums[b][c][2]
-__global__ __launch_bounds__(1024) void gn_bwd_chunksum_kernel(const float* __restrict__ part, int chunks, int C,
-                                                               float* __restrict__ sums) {
-  __shared__ float ps[16][64][2];
-  const int b = blockIdx.y, B = gridDim.y;
-  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+// One block per (group, sample): fixed-order sum of the group's channels over the chunk partials, then -- all of a group's
+// channels being here -- dgamma / dbeta, the two group sums and the per-(b, c) coefficients of dx = c1*dn + c3*x + c2.
+// (Was two launches: a chunk sum over 64-channel blocks and a per-sample finalize; 46 of each per step.)
+__global__ __launch_bounds__(1024) void gn_bwd_group_kernel(const float* __restrict__ part, int chunks, const bf16* __restrict__ gamma,
+                                                            const float* __restrict__ stats, float* __restrict__ coef,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int HW, int C, int G) {
+  __shared__ float ps[1024][2];
+  __shared__ float wa[128], wb[128];
+  const int g = blockIdx.x, b = blockIdx.y, B = gridDim.y;
+  const int cpg = C / G;                        // <= 128 (launcher check)
+  const int nsl = 1024 / cpg;                   // chunk slices per channel
+  const int cl = threadIdx.x % cpg, sl = threadIdx.x / cpg;
+  const int c = g * cpg + cl;
   float a = 0.f, q = 0.f;
-  if (c < C)
-    for (int k = sl; k < chunks; k += 16) {
+  if (sl < nsl)
+    for (int k = sl; k < chunks; k += nsl) {
       const float* pp = part + (((long)k * B + b) * C + c) * 2;
       a += pp[0];
       q += pp[1];
     }
-  ps[sl][cl][0] = a;
-  ps[sl][cl][1] = q;
+  if (sl < nsl) { ps[sl * cpg + cl][0] = a; ps[sl * cpg + cl][1] = q; }
   __syncthreads();
-  if (sl == 0 && c < C) {
-    float ta = 0.f, tq = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { ta += ps[k][cl][0]; tq += ps[k][cl][1]; }
-    sums[((long)b * C + c) * 2] = ta;
-    sums[((long)b * C + c) * 2 + 1] = tq;
-  }
-}
-
-// per sample: dgamma/dbeta, group sums, per-(b,c) coefficients: dx = c1*dn + c3*x + c2
-__global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, const bf16* __restrict__ gamma,
-                                       const float* __restrict__ stats, float* __restrict__ coef,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int HW, int C, int G) {
-  extern __shared__ float sh[];  // [2][C] gamma-weighted sums, then [2][G] group sums
-  float* wa = sh;
-  float* wb = sh + C;
-  float* gs = sh + 2 * C;
-  const int b = blockIdx.x;
-  const int cpg = C / G;
-  const float n = (float)HW * (float)cpg;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float A = part[((long)b * C + c) * 2], Bs = part[((long)b * C + c) * 2 + 1];   // chunk-summed
+  float A = 0.f, Bs = 0.f, ga = 0.f;
+  if (sl == 0) {
+    for (int k = 0; k < nsl; ++k) { A += ps[k * cpg + cl][0]; Bs += ps[k * cpg + cl][1]; }
     atomicAdd(&dbeta[c], A);     // parameter gradients: fp32 sum over the batch (order-insensitive to ~1e-7)
     atomicAdd(&dgamma[c], Bs);
-    float ga = (float)gamma[c];
-    wa[c] = ga * A;
-    wb[c] = ga * Bs;
+    ga = (float)gamma[c];
+    wa[cl] = ga * A;
+    wb[cl] = ga * Bs;
   }
   __syncthreads();
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
-    float a = 0.f, q = 0.f;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += wa[c]; q += wb[c]; }
-    gs[g * 2] = a / n;
-    gs[g * 2 + 1] = q / n;
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    int g = c / cpg;
-    float mean = stats[((long)b * G + g) * 2], rstd = stats[((long)b * G + g) * 2 + 1];
-    float S1 = gs[g * 2], S2 = gs[g * 2 + 1];
-    float c1 = rstd * (float)gamma[c];
-    float c3 = -rstd * rstd * S2;
-    float c2 = -rstd * S1 - mean * c3;
+  if (sl == 0) {
+    float S1 = 0.f, S2 = 0.f;
+    for (int k = 0; k < cpg; ++k) { S1 += wa[k]; S2 += wb[k]; }
+    const float n = (float)HW * (float)cpg;
+    S1 /= n; S2 /= n;
+    const float mean = stats[((long)b * G + g) * 2], rstd = stats[((long)b * G + g) * 2 + 1];
+    const float c1 = rstd * ga;
+    const float c3 = -rstd * rstd * S2;
+    const float c2 = -rstd * S1 - mean * c3;
     coef[((long)b * C + c) * 3] = c1;
     coef[((long)b * C + c) * 3 + 1] = c2;
     coef[((long)b * C + c) * 3 + 2] = c3;
@@ -322,11 +303,10 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const
                          bf16* dx, const bf16* addend, float* dgamma, float* dbeta, float* ws, int B, int HW, int C,
                          int G, int silu, hipStream_t st) {
   const int accumulate = addend != nullptr;
-  ARG_CHECK(C % 8 == 0 && C % G == 0 && G <= 64, "groupnorm bwd: C=%d G=%d unsupported", C, G);
+  ARG_CHECK(C % 8 == 0 && C % G == 0 && G <= 64 && C / G <= 128, "groupnorm bwd: C=%d G=%d unsupported", C, G);
   GnGeom g = gn_geom(HW, C);
   float* part = ws;                                      // [chunks][B][C][2]
   float* coef = ws + (size_t)GN_MAX_CHUNKS * B * C * 2;  // [B][C][3]
-  float* sums = coef + (size_t)B * C * 3;                // [B][C][2]
   size_t sh = sizeof(float) * 2 * g.rpi * C;
   if (silu)
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<true>, dim3(g.chunks, B), dim3(g.threads), sh, st, x, dy, gamma, beta,
@@ -334,9 +314,7 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const
   else
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<false>, dim3(g.chunks, B), dim3(g.threads), sh, st, x, dy, gamma, beta,
                        stats, part, HW, C, G, g.vpr, g.rpi, g.rows_per_chunk);
-  hipLaunchKernelGGL(gn_bwd_chunksum_kernel, dim3(cdiv(C, 64), B), dim3(1024), 0, st, part, g.chunks, C, sums);
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), sizeof(float) * (2 * C + 2 * G), st, sums, g.chunks,
-                     gamma, stats, coef, dgamma, dbeta, HW, C, G);
+  hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(G, B), dim3(1024), 0, st, part, g.chunks, gamma, stats, coef, dgamma, dbeta, HW, C, G);
 #define GN_BWD_APPLY(S, A)                                                                                          \
   hipLaunchKernelGGL((gn_bwd_apply_kernel<S, A>), dim3(g.chunks, B), dim3(g.threads), 0, st, x, dy, gamma, beta, stats, \
                      coef, dx, addend, HW, C, G, g.vpr, g.rpi, g.rows_per_chunk)
