@@ -105,6 +105,7 @@ class NativeSDXLTrainer:
         self.sharded = bool(getattr(self.config.training, "shard_optimizer", True)) and isinstance(self.optimizer, AdamWBF16)
         Sync = D.ShardedGradSync if self.sharded else D.GradSync
         self.sync = Sync(self.net.param_elems, self._cast, torch.bfloat16, getattr(self.net, "device", "cpu"))
+        self._emit = False                   # this backward's weight-gradient GEMMs write the bf16 exchange arena themselves
         self._micro = 0                      # micro-step index inside the accumulation cycle
         self._zeroed = False                 # gradients already zeroed for the cycle in progress
         self._anchor = torch.zeros((), requires_grad=True)
@@ -117,7 +118,7 @@ class NativeSDXLTrainer:
     def _cast(self, off, n, dst):
         # the exchange micro-step's weight-gradient GEMMs wrote bf16 into the comm arena themselves (set_grad_emit): what is
         # left to cast per bucket are the biases / norm parameters (fp32 atomic accumulators)
-        if getattr(self, "_emit", False):
+        if self._emit:
             self.net.cast_small(off, n, dst)
             return
         lib.check(self.net.L.sdxl_grads_to_bf16(self.net.h, off, n, C.c_void_p(dst.data_ptr()), 1.0,
