@@ -725,11 +725,21 @@ int launch_attn_fwd(const AttnP& p, hipStream_t st) {
   return 0;
 }
 
-int launch_attn_bwd(const AttnP& p, hipStream_t st) {
+static int check_attn_bwd(const AttnP& p) {
   if (int e = check_attn(p)) return e;
   ARG_CHECK(p.O && p.dO && p.dQ && p.dK && p.dV && p.LSE && p.Delta, "attention bwd: missing buffers");
   ARG_CHECK(!p.accumulate, "attention bwd: accumulate not implemented");
+  return 0;
+}
+// dQ (+ Delta, which the dK / dV kernel reads: launch this one first, on a stream the other is ordered behind)
+int launch_attn_bwd_dq(const AttnP& p, hipStream_t st) {
+  if (int e = check_attn_bwd(p)) return e;
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(cdiv(p.Nq, 128), p.B * p.H), dim3(256), 0, st, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int launch_attn_bwd_dkv(const AttnP& p, hipStream_t st) {
+  if (int e = check_attn_bwd(p)) return e;
   AttnP q = p;
   if (q.qsplit < 1 || !q.part) q.qsplit = 1;
   // two key blocks per wave when the 128-key workgroups still fill the chip twice over
@@ -743,4 +753,8 @@ int launch_attn_bwd(const AttnP& p, hipStream_t st) {
   }
   HIP_CHECK_RET(hipGetLastError());
   return 0;
+}
+int launch_attn_bwd(const AttnP& p, hipStream_t st) {
+  if (int e = launch_attn_bwd_dq(p, st)) return e;
+  return launch_attn_bwd_dkv(p, st);
 }

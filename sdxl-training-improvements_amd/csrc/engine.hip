@@ -441,7 +441,12 @@ struct AttnOp : Op {
     if (bad) { sdxl_set_error("attention: operand gradient has another writer"); return 3; }
     AttnP a;
     fill(p, a, true);
-    return launch_attn_bwd(a, st);
+    if (self) return launch_attn_bwd(a, st);
+    // cross attention: dK | dV (this block's slice of the grouped projection's gradient) is read by nothing before that
+    // projection's weight gradient, a leaf on the side stream -- so the dK / dV kernel (+ its partial reduce) goes there too,
+    // behind the dQ kernel that produces Delta, and leaves the caller's stream (1.8 ms per step)
+    CHK(launch_attn_bwd_dq(a, st));
+    return on_side(p, st, [=](hipStream_t s2) -> int { return launch_attn_bwd_dkv(a, s2); });
   }
 };
 

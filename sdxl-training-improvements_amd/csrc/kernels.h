@@ -112,7 +112,9 @@ struct AttnP {
 size_t attn_part_floats(int B, int H, int Nk, int qsplit);
 int attn_pick_qsplit(int B, int H, int Nq, int Nk);
 int launch_attn_fwd(const AttnP& p, hipStream_t st);
-int launch_attn_bwd(const AttnP& p, hipStream_t st);
+int launch_attn_bwd(const AttnP& p, hipStream_t st);       // = dq, then dkv
+int launch_attn_bwd_dq(const AttnP& p, hipStream_t st);
+int launch_attn_bwd_dkv(const AttnP& p, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
 // normalisation (norm.hip)
