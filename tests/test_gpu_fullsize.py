@@ -212,6 +212,46 @@ def test_configs1_shape_step_properties(full):
     assert rel_g <= 5e-3
 
 
+def test_headline_shape_grad_emit_equals_cast(full):
+    """configs[1] shape (B=4, 1024^2 -- the shape at which three 1280x1280 wgrads go out per grouped launch and the K | V wgrad
+    runs over padded rows): the bf16 exchange arena written by the wgrad epilogues (sdxl_set_grad_emit; TN epilogue, split-K
+    reduce, grouped launches) + the small-range casts has the bits of a cast of the fp32 gradient arena."""
+    import ctypes as C
+    from sdxl_amd import lib
+    net = full
+    x = _inputs(4, 128, 128, seed=303)
+    ts = torch.tensor([450, 613, 700, 820])
+    sig = R.karras_sigmas()[ts]
+    n = net.param_elems
+
+    def step(arena):
+        net.zero_grads()
+        net.forward_loss("ddpm", x["lat"], x["noise"], sig, ts.float(), x["ehs"], x["pooled"], x["tid"])
+        if arena is None:
+            net.backward(0.25, True)
+        else:
+            net.set_grad_emit(arena, 1.0)
+            net.backward(0.25, True, on_segment=lambda k, off, cnt: net.cast_small(off, cnt, arena[off:off + cnt]), segment_stream=True)
+            net.set_grad_emit(None)
+
+    step(None)
+    ref = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    lib.check(net.L.sdxl_grads_to_bf16(net.h, 0, n, C.c_void_p(ref.data_ptr()), 1.0, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    got = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    step(got)
+    torch.cuda.synchronize()
+    differ = 0
+    worst = 0.0
+    scale = float(ref.float().abs().max())
+    for i in range(0, n, 1 << 28):                     # in slices: the fp32 differences of 2.6 G elements need not all be resident
+        d = (got[i:i + (1 << 28)].float() - ref[i:i + (1 << 28)].float()).abs()
+        differ += int((d > 0).sum())
+        worst = max(worst, float(d.max()))
+    print(f"[parity] full-size grad emit: {differ} of {n} elements differ, max |d| / max |ref| = {worst / scale:.2e}")
+    assert worst <= 2e-2 * scale
+    assert differ <= 3_000_000        # biases / norm parameters (2.1 M elements of fp32 atomic sums) only
+
+
 def test_ddpm_batch_decomposes(full):
     """configs[1] (ddpm v-pred + MinSNR, B=4, 1024^2): per-sample weights (D3) -- the batch loss is the mean of the
     per-sample losses and the gradient the 1/B-weighted sum, which ties the B=4 step to the B=1 oracle comparison."""
