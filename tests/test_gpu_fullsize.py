@@ -315,3 +315,37 @@ def test_flow_matching_batch_decomposes(full, shape):
     assert math.isfinite(lb) and 0 < lb < 1000
     assert abs(lb - mean) <= 1e-3 * abs(lb)
     assert abs(nb - ns) <= 5e-3 * nb and rel_g <= 1e-2
+
+
+def test_configs4_mixed_buckets_accumulate_across_plans(full):
+    """configs[4] (flow matching, buckets 1024x1024 and 1344x768 alternating micro-step by micro-step, gradient accumulation): two
+    plans share the weights, the gradient arena and the workspace; a cycle over both buckets accumulates exactly the sum of the
+    two buckets' own gradients, in either order."""
+    net = full
+    shapes = [(4, 128, 128), (4, 96, 168)]
+    xs = [_inputs(*s, seed=410 + i) for i, s in enumerate(shapes)]
+    ts = [torch.tensor([0.15, 0.4, 0.65, 0.9]), torch.tensor([0.1, 0.35, 0.6, 0.85])]
+    probes = ["down_blocks.2.attentions.1.transformer_blocks.3.attn1.to_out.0.weight", "up_blocks.1.resnets.0.conv1.weight",
+              "mid_block.attentions.0.transformer_blocks.7.attn2.to_k.weight"]
+
+    def micro(i, scale, first):
+        x, t = xs[i], ts[i]
+        net.forward_loss("flow_matching", x["lat"], x["noise"], t, t, x["ehs"], x["pooled"], x["tid"])
+        net.backward(scale, first)
+        return net.read_loss()[0]
+
+    singles = []
+    for i in range(2):
+        net.zero_grads()
+        micro(i, 0.5, True)
+        singles.append({k: net.export(k, grad=True).clone() for k in probes})
+    for order in ((0, 1), (1, 0)):
+        net.zero_grads()
+        losses = [micro(i, 0.5, j == 0) for j, i in enumerate(order)]
+        assert all(math.isfinite(l) and 0 < l < 1000 for l in losses)
+        for k in probes:
+            acc = net.export(k, grad=True)
+            ref = singles[0][k] + singles[1][k]
+            rel = float((acc - ref).norm() / ref.norm())
+            print(f"[parity] mixed buckets order {order} {k}: rel {rel:.3e}")
+            assert rel <= 1e-5, (order, k, rel)
