@@ -61,7 +61,7 @@ struct GemmP {
   float cb_scale;
   float* bias_grad;  // TN only, optional: bias_grad[m] += sum_k A(k, m)  (column sums of dY, computed on the matrix pipe
                      // by the n-tile-0 / tap-0 workgroups with an all-ones B fragment; fp32 atomics, 128 per workgroup)
-  int xcd_px;      // set by the launcher: XCD grid width over n-tiles (0 = identity order; SDXL_GEMM_XCD=0 disables)
+  int xcd_px;      // set by the launcher: XCD grid width over n-tiles (0 = identity order)
   // grouped launch (TN, taps == 1, splitk == 1): `group` > 1 problems of one shape in one grid (blockIdx.z = problem i, which
   // uses gA[i], gB[i], gC[i], gbias_grad[i] in place of A, B, C, bias_grad).  Small weight gradients (1280 x 1280: 80 tiles)
   // fill the chip three at a time instead of each being cut into split-K slabs and reduced.
