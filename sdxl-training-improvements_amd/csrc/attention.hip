@@ -417,8 +417,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb][0], qf[qb][0], a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb][1], qf[qb][1], a, 0, 0, 0);
         st[kb][qb] = a;
-        f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
-        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kb][0], df[qb][0], d, 0, 0, 0);
+        f32x4 d = (f32x4){-delta[qb], -delta[qb], -delta[qb], -delta[qb]};    // dP - Delta for free: the accumulator starts at -Delta
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kb][0], df[qb][0], d, 0, 0, 0);      // (a lane's four scores share its query column)
         d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kb][1], df[qb][1], d, 0, 0, 0);
         dp[kb][qb] = d;
       }
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       // two-wide fp32 arithmetic (v_pk_fma / v_pk_add / v_pk_mul) on the register pairs of the MFMA results
-      const f32x2 nl2 = (f32x2){-lse2[qb], -lse2[qb]}, ndl = (f32x2){-delta[qb], -delta[qb]};
+      const f32x2 nl2 = (f32x2){-lse2[qb], -lse2[qb]};
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
             if (t * 64 + kb * 16 + g * 4 + 2 * hh >= p.Nk) pr[0] = 0.f;
             if (t * 64 + kb * 16 + g * 4 + 2 * hh + 1 >= p.Nk) pr[1] = 0.f;
           }
-          const f32x2 ds = pr * ((f32x2){dp[kb][qb][2 * hh], dp[kb][qb][2 * hh + 1]} + ndl);   // (softmax scale: once, on dQ, at the end)
+          const f32x2 ds = pr * (f32x2){dp[kb][qb][2 * hh], dp[kb][qb][2 * hh + 1]};   // (dp holds dP - Delta; softmax scale: once, on dQ, at the end)
           st[kb][qb][2 * hh] = ds[0]; st[kb][qb][2 * hh + 1] = ds[1];
         }
       dsf[0][qb] = pack8(st[0][qb], st[1][qb]);
@@ -558,6 +558,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
       da[qb][0] = ld_frag(Dt, qb * 16 + l16, g * 8); da[qb][1] = ld_frag(Dt, qb * 16 + l16, 32 + g * 8);
     }
     f32x4 s[KB][4], dp[KB][4];
+    f32x4 ndl4[4];                       // -Delta of the lane's four query rows per query block (the tile's statistics are in LDS)
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      const f32x4 dl = *(const f32x4*)&sstat[buf][1][qb * 16 + g * 4];
+      ndl4[qb] = (f32x4){-dl[0], -dl[1], -dl[2], -dl[3]};
+    }
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb)
 #pragma unroll
@@ -566,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[qb][0], kf[kb][0], a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[qb][1], kf[kb][1], a, 0, 0, 0);
         s[kb][qb] = a;
-        f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 d = ndl4[qb];                                                 // dP - Delta for free: the accumulator starts at -Delta
         d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[qb][0], vf[kb][0], d, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[qb][1], vf[kb][1], d, 0, 0, 0);
         dp[kb][qb] = d;
@@ -581,13 +587,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     // P = exp2(c S - log2e LSE), dS = P (dP - Delta): two-wide fp32 operations (v_pk_fma / v_pk_add / v_pk_mul) on the
     // register pairs the MFMA results arrive in.  Keys beyond Nk need no masking here: their K / V fragments are zero and
     // their P / dS ROWS only feed their own dK / dV rows, which are never stored.
-    f32x2 l2s[4][2], dls[4][2];
+    f32x2 l2s[4][2];
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) {
       const f32x4 l2 = *(const f32x4*)&sstat[buf][0][qb * 16 + g * 4];      // natural-log LSE
-      const f32x4 dl = *(const f32x4*)&sstat[buf][1][qb * 16 + g * 4];
       l2s[qb][0] = (f32x2){l2[0], l2[1]} * LOG2E; l2s[qb][1] = (f32x2){l2[2], l2[3]} * LOG2E;
-      dls[qb][0] = (f32x2){-dl[0], -dl[1]}; dls[qb][1] = (f32x2){-dl[2], -dl[3]};     // negated: dP - Delta as a two-wide add
     }
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
@@ -604,7 +608,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
             if (t * 64 + qb * 16 + g * 4 + 2 * hh + 1 >= p.Nq) e[1] = 0.f;
           }
           const f32x2 dpv = (f32x2){dp[kb][qb][2 * hh], dp[kb][qb][2 * hh + 1]};
-          const f32x2 dsv = e * (dpv + dls[qb][hh]);          // (the softmax scale is applied once, to dK, at the end)
+          const f32x2 dsv = e * dpv;                          // (dpv = dP - Delta; the softmax scale is applied once, to dK, at the end)
           pr[qb][2 * hh] = e[0]; pr[qb][2 * hh + 1] = e[1];
           s[kb][qb][2 * hh] = dsv[0]; s[kb][qb][2 * hh + 1] = dsv[1];
         }
