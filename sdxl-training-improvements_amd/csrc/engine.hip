@@ -221,7 +221,7 @@ struct LinearOp : Op {
           return launch_gemm(g, s2);
         }));
       } else
-      if (wgroup > 1 && p.eng->use_side && p.eng->side && !gemm_profiling()) CHK(p.eng->defer_wgrad(p, st, g, wgroup));
+      if (wgroup > 1) CHK(p.eng->defer_wgrad(p, st, g, wgroup));     // (also in the serialized measurement modes: the launch structure that ships)
       else CHK(on_side(p, st, [&](hipStream_t s2) -> int { return launch_gemm(g, s2); }));
     }
     if (x->need_grad) {
