@@ -138,6 +138,14 @@ extern "C" int sdxl_debug_attn_stamps(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_stamps), sizeof(unsigned long long) * 96) == hipSuccess ? 0 : 2;
 }
 #endif
+// x * c rounded back to bf16, element by element (operand prescale: the scores then come out of the matrix pipe in the log2
+// domain, exp2's argument needs no multiply)
+__device__ __forceinline__ bf16x8 scale8(bf16x8 v, float c) {
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)v[e] * c);
+  return o;
+}
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
 #if defined(ATTN_DIAG) && (ATTN_DIAG & 256)
   const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
@@ -164,8 +172,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) ot[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float mrow[2] = {-1e30f, -1e30f}, lrow[2] = {0.f, 0.f};
+  // running reference mrow, in the scaled log2 domain (s * c): a tile's score accumulators start from -mrow, so exp2's
+  // argument is the MFMA result itself; 0 until the first tile sets it
+  float mrow[2] = {0.f, 0.f}, lrow[2] = {0.f, 0.f};
   const float c = SCALE * LOG2E;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) { qf[qb][0] = scale8(qf[qb][0], c); qf[qb][1] = scale8(qf[qb][1], c); }   // Q^T * (scale * log2 e), once
 #ifdef ATTN_DIAG   // diagnostics only (never defined in the product build; profiles/tools/build_diag_attn.sh): knock out one component of
   constexpr int dbg = ATTN_DIAG;   // the tile loop -- 1: no exp, 2: no S MFMAs, 4: no PV MFMAs, 8: no max / rescale logic, 32: no K fragment
 #else                              // reads, 64: no V^T fragment reads (tile-dependent stand-ins: nothing becomes loop-invariant);
@@ -216,7 +228,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
-        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 a = (f32x4){-mrow[qb], -mrow[qb], -mrow[qb], -mrow[qb]};
         if (dbg & 2) { a[0] = (float)kf[kb][0][0]; a[1] = (float)qf[qb][1][1]; a[2] = a[0] + 1.f; a[3] = a[1] - 1.f; }
         else {
           a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb][0], qf[qb][0], a, 0, 0, 0);
@@ -254,27 +266,28 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { if (!(dbg & 8)) mx = fmaxf(mx, st[kb][qb][r]); }
       if (!(dbg & 8)) mx = max_over_g(mx);
-      // lazy rescaling: the running reference mrow only moves when some query's tile maximum exceeds it by more than
-      // 2^8 in the exponent (p <= 256 until then: exact in fp32 sums, same relative precision in bf16); after the first
-      // tiles that is rare, and the accumulator rescale (alpha, 16 two-wide multiplies) is skipped wave-uniformly
-      if (__builtin_amdgcn_ballot_w64((mx - mrow[qb]) * c > 8.f) != 0) {
-        const float mnew2 = fmaxf(mrow[qb], mx);
-        const float alpha2 = __builtin_amdgcn_exp2f((mrow[qb] - mnew2) * c);
-        mrow[qb] = mnew2;
+      // st holds s * c - mrow.  Lazy rescaling: the reference only moves when some query's tile maximum exceeds it by more
+      // than 2^8 (p <= 256 until then: exact in fp32 sums, same relative precision in bf16) -- and in the first tile, which
+      // sets it to that tile's maximum; afterwards that is rare, and the rescale (alpha on the accumulators, the shift of
+      // this tile's scores) is skipped wave-uniformly
+      if (t == 0 || __builtin_amdgcn_ballot_w64(mx > 8.f) != 0) {
+        const float shift = t == 0 ? mx : fmaxf(mx, 0.f);
+        const float alpha2 = t == 0 ? 1.f : __builtin_amdgcn_exp2f(-shift);
+        mrow[qb] += shift;
         lrow[qb] *= alpha2;
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
           ot[db][qb][0] *= alpha2; ot[db][qb][1] *= alpha2; ot[db][qb][2] *= alpha2; ot[db][qb][3] *= alpha2;
         }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) { st[kb][qb][0] -= shift; st[kb][qb][1] -= shift; st[kb][qb][2] -= shift; st[kb][qb][3] -= shift; }
       }
-      const float mnew = mrow[qb];
-      const f32x2 nmc = (f32x2){-mnew * c, -mnew * c};
       f32x2 ls2 = (f32x2){0.f, 0.f};
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {      // two-wide fp32 arithmetic on the register pairs of the MFMA results
-          const f32x2 arg = (f32x2){st[kb][qb][2 * hh], st[kb][qb][2 * hh + 1]} * c + nmc;
+          const f32x2 arg = (f32x2){st[kb][qb][2 * hh], st[kb][qb][2 * hh + 1]};
           const f32x2 e = (dbg & 1) ? arg : (f32x2){__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
           st[kb][qb][2 * hh] = e[0]; st[kb][qb][2 * hh + 1] = e[1];
           ls2 += e;
@@ -324,7 +337,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
         o[2] = (bf16)(ot[db][qb][2] * inv); o[3] = (bf16)(ot[db][qb][3] * inv);
         *(bf16x4*)(orow + db * 16 + g * 4) = o;
       }
-      if (g == 0 && p.LSE) p.LSE[(long)bh * p.Nq + q] = mrow[qb] * SCALE + logf(l);
+      if (g == 0 && p.LSE) p.LSE[(long)bh * p.Nq + q] = mrow[qb] * (1.f / LOG2E) + logf(l);      // natural log: mrow is in log2 units
     }
   }
 #if defined(ATTN_DIAG) && (ATTN_DIAG & 256)
@@ -382,6 +395,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) dq[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float c = SCALE * LOG2E;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) { qf[qb][0] = scale8(qf[qb][0], c); qf[qb][1] = scale8(qf[qb][1], c); }   // as the forward: scores in the log2 domain
 
   const int ntiles = (p.Nk + 63) / 64;
   const TileSrc ksrc = tile_src(Kb, p.ldk, wave, lane), vsrc = tile_src(Vb, p.ldv, wave, lane);
@@ -413,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
-        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 a = (f32x4){-lse2[qb], -lse2[qb], -lse2[qb], -lse2[qb]};      // exp2's argument s * c - LSE * log2 e straight from the matrix pipe
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb][0], qf[qb][0], a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb][1], qf[qb][1], a, 0, 0, 0);
         st[kb][qb] = a;
@@ -432,12 +447,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       // two-wide fp32 arithmetic (v_pk_fma / v_pk_add / v_pk_mul) on the register pairs of the MFMA results
-      const f32x2 nl2 = (f32x2){-lse2[qb], -lse2[qb]};
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-          const f32x2 arg = (f32x2){st[kb][qb][2 * hh], st[kb][qb][2 * hh + 1]} * c + nl2;
+          const f32x2 arg = (f32x2){st[kb][qb][2 * hh], st[kb][qb][2 * hh + 1]};
           f32x2 pr = (f32x2){__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
           if (MASK) {
             if (t * 64 + kb * 16 + g * 4 + 2 * hh >= p.Nk) pr[0] = 0.f;
@@ -505,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     kok[kb] = key < p.Nk;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      kf[kb][ks] = kok[kb] ? *(const bf16x8*)(Kb + (long)key * p.ldk + ks * 32 + g * 8) : z8();
+      kf[kb][ks] = kok[kb] ? scale8(*(const bf16x8*)(Kb + (long)key * p.ldk + ks * 32 + g * 8), SCALE * LOG2E) : z8();   // K * (scale * log2 e): scores in the log2 domain
       vf[kb][ks] = kok[kb] ? *(const bf16x8*)(Vb + (long)key * p.ldv + ks * 32 + g * 8) : z8();
     }
   }
@@ -514,7 +528,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
   for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
     for (int i = 0; i < 4; ++i) { dk[kb][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[kb][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-  const float c = SCALE * LOG2E;
 
   const int ntiles_all = (p.Nq + 63) / 64;
   const int per = (ntiles_all + p.qsplit - 1) / p.qsplit;
@@ -558,17 +571,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
       da[qb][0] = ld_frag(Dt, qb * 16 + l16, g * 8); da[qb][1] = ld_frag(Dt, qb * 16 + l16, 32 + g * 8);
     }
     f32x4 s[KB][4], dp[KB][4];
-    f32x4 ndl4[4];                       // -Delta of the lane's four query rows per query block (the tile's statistics are in LDS)
+    f32x4 ndl4[4], nl4[4];               // -Delta, -LSE * log2 e of the lane's four query rows per query block (the tile's statistics are in LDS)
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) {
       const f32x4 dl = *(const f32x4*)&sstat[buf][1][qb * 16 + g * 4];
+      const f32x4 l2 = *(const f32x4*)&sstat[buf][0][qb * 16 + g * 4];      // natural-log LSE
       ndl4[qb] = (f32x4){-dl[0], -dl[1], -dl[2], -dl[3]};
+      nl4[qb] = l2 * (-LOG2E);
     }
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb)
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
-        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 a = nl4[qb];                                                  // exp2's argument s * c - LSE * log2 e straight from the matrix pipe
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[qb][0], kf[kb][0], a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[qb][1], kf[kb][1], a, 0, 0, 0);
         s[kb][qb] = a;
@@ -587,12 +602,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     // P = exp2(c S - log2e LSE), dS = P (dP - Delta): two-wide fp32 operations (v_pk_fma / v_pk_add / v_pk_mul) on the
     // register pairs the MFMA results arrive in.  Keys beyond Nk need no masking here: their K / V fragments are zero and
     // their P / dS ROWS only feed their own dK / dV rows, which are never stored.
-    f32x2 l2s[4][2];
-#pragma unroll
-    for (int qb = 0; qb < 4; ++qb) {
-      const f32x4 l2 = *(const f32x4*)&sstat[buf][0][qb * 16 + g * 4];      // natural-log LSE
-      l2s[qb][0] = (f32x2){l2[0], l2[1]} * LOG2E; l2s[qb][1] = (f32x2){l2[2], l2[3]} * LOG2E;
-    }
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       f32x4 pr[4];
@@ -601,8 +610,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           const f32x2 sv = (f32x2){s[kb][qb][2 * hh], s[kb][qb][2 * hh + 1]};
-          const f32x2 arg = sv * c - l2s[qb][hh];
-          f32x2 e = (f32x2){__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+          f32x2 e = (f32x2){__builtin_amdgcn_exp2f(sv[0]), __builtin_amdgcn_exp2f(sv[1])};
           if (MASK) {
             if (t * 64 + qb * 16 + g * 4 + 2 * hh >= p.Nq) e[0] = 0.f;
             if (t * 64 + qb * 16 + g * 4 + 2 * hh + 1 >= p.Nq) e[1] = 0.f;
