@@ -583,7 +583,11 @@ int sdxl_op_gemm(int form, const void* A, const void* B, void* C, int M, int N, 
   g.M = M; g.N = N; g.K = K;
   if (form == GEMM_NT) { g.lda = K; g.ldb = K; }
   else if (form == GEMM_NN) { g.lda = K; g.ldb = N; }
-  else {
+  if (form != GEMM_TN && splitk > 1) {
+    g.splitk = splitk;
+    CHK(test_slab(gemm_slab_floats(M, N, 1, splitk), &g.slab));
+  }
+  if (form == GEMM_TN) {
     g.lda = M; g.ldb = N; g.out_f32 = 1; g.splitk = splitk;
     if (splitk > 1) CHK(test_slab(gemm_slab_floats(M, N, 1, splitk), &g.slab));
   }
@@ -625,6 +629,10 @@ int sdxl_op_conv3x3_fwd(const void* x, const void* w, const void* bias, void* y,
   g.taps = 9; g.Hm = Ho; g.Wm = Wo; g.Hs = H; g.Ws = W; g.sm = stride; g.sd = 1;
   g.b_tap_stride = Cin;
   g.bias = (const bf16*)bias;
+  if (stride == 1 && Cin % 64 == 0) {     // as the plan does: small images split the (tap, channel) reduction
+    g.splitk = gemm_pick_splitk_small(g.M, Cout, 9 * Cin);
+    if (g.splitk > 1) CHK(test_slab(gemm_slab_floats(g.M, Cout, 1, g.splitk), &g.slab));
+  }
   return launch_gemm(g, (hipStream_t)st);
 }
 int sdxl_op_conv3x3_dgrad(const void* dy, const void* w, void* dx, int B, int H, int W, int Cin, int Cout, int stride,
@@ -638,6 +646,10 @@ int sdxl_op_conv3x3_dgrad(const void* dy, const void* w, void* dx, int B, int H,
   g.lda = Cout; g.ldb = 9L * Cin; g.ldc = Cin;
   g.taps = 9; g.Hm = H; g.Wm = W; g.Hs = Ho; g.Ws = Wo; g.sm = 1; g.sd = stride;
   g.flip = 1; g.b_tap_stride = Cin;
+  if (stride == 1 && Cout % 64 == 0) {
+    g.splitk = gemm_pick_splitk_small(g.M, Cin, 9 * Cout);
+    if (g.splitk > 1) CHK(test_slab(gemm_slab_floats(g.M, Cin, 1, g.splitk), &g.slab));
+  }
   return launch_gemm(g, (hipStream_t)st);
 }
 int sdxl_op_conv3x3_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, int stride,

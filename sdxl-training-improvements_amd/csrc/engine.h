@@ -79,6 +79,7 @@ struct Plan {
                                                                                           // addresses for the captured graphs)
   size_t gn_ws_off = NONE, gn_ws_floats = 0;  // GroupNorm scratch shared by all (stream-ordered) norm ops
   size_t slab_off = NONE, slab_floats = 0;    // split-K partial slabs of the wgrad GEMMs (shared, stream-ordered)
+  size_t slab_main_off = NONE, slab_main_floats = 0;   // the same for split forward / dgrad launches (caller's stream)
   size_t apart_off = NONE, apart_floats = 0;  // query-split partials of the cross-attention dK/dV kernel (main stream)
 
   Act* new_act(long rows, int cols, bool need_grad = true, int pad_rows = 0);

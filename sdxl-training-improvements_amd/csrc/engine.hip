@@ -145,6 +145,10 @@ bool Plan::grad_alias(Act* x, Act* y) {
 // Ops
 // ================================================================================================
 static int pick_splitk(long out_rows, long out_cols, int taps, long red) { return gemm_pick_splitk((int)out_rows, (int)out_cols, taps, red); }
+static void want_slab_main(Plan& p, int M, int N, int splitk) {     // slabs of the caller's-stream launches (forward, dgrad)
+  size_t need = gemm_slab_floats(M, N, 1, splitk);
+  if (need > p.slab_main_floats) p.slab_main_floats = need;
+}
 static void want_slab(Plan& p, int M, int N, int taps, int splitk) {
   size_t need = gemm_slab_floats(M, N, taps, splitk);
   if (need > p.slab_floats) p.slab_floats = need;
@@ -157,6 +161,7 @@ struct LinearOp : Op {
   PRef w, b;
   int K, N;
   int resid_alias = 0, splitk = 1, wgroup = 1;
+  int fsplit = 1, dsplit = 1;   // split-K of the forward / dgrad launch (small-M problems, gemm_pick_splitk_small)
   size_t dy32_off = NONE;   // the output gradient arrives as fp32 sums (grouped time-embedding projection): cast first
   size_t dy_off = NONE;
   Plan::GradDst dx, dres;
@@ -176,6 +181,7 @@ struct LinearOp : Op {
     g.bias = b.off == NONE ? nullptr : p.eng->Wp(b);
     if (resid) { g.resid = p.P(resid); g.ldr = N; }
     if (gact) { g.geglu = 1; g.geglu_group = ggroup; g.aux = p.P(gact); g.ldaux = N / 2; }
+    if (fsplit > 1 && !hoist_fwd) { g.splitk = fsplit; g.slab = p.F(p.slab_main_off); }     // (the hoisted projection runs on the side stream)
     return launch_gemm(g, st);
   }
   void plan_bwd(Plan& p) override {
@@ -189,6 +195,8 @@ struct LinearOp : Op {
     splitk = pick_splitk(N, K, 1, x->rows);
     wgroup = gemm_pick_group(N, K, 1, x->rows, splitk);
     want_slab(p, N, K, 1, splitk);
+    if (!gact) { fsplit = gemm_pick_splitk_small((int)x->rows, N, K); want_slab_main(p, (int)x->rows, N, fsplit); }
+    if (!gu && x->need_grad) { dsplit = gemm_pick_splitk_small((int)x->rows, K, N); want_slab_main(p, (int)x->rows, K, dsplit); }
   }
   int bwd(Plan& p, hipStream_t st, bool first) override {
     const bf16* dy = p.GP(dy_off);
@@ -233,6 +241,7 @@ struct LinearOp : Op {
       g.lda = N; g.ldb = K; g.ldc = K;
       if (gu) { g.geglu = 2; g.geglu_group = ggroup; g.aux = p.P(gu); g.ldaux = 2L * K; g.ldc = 2L * K; }
       else if (dx.addend != NONE) { g.resid = p.GP(dx.addend); g.ldr = K; }
+      if (dsplit > 1) { g.splitk = dsplit; g.slab = p.F(p.slab_main_off); }
       CHK(launch_gemm(g, st));
     }
     return 0;
@@ -244,6 +253,7 @@ struct ConvOp : Op {
   PRef w, b;
   int Bn, H, W, Cin, Cout, stride, Ho, Wo;
   int resid_alias = 0, splitk = 1;
+  int fsplit = 1, dsplit = 1;   // split-K of the forward / dgrad launch (small images, gemm_pick_splitk_small)
   size_t rv32_off = NONE;  // rowvec gradient: this conv's column slice of the plan's fp32 [B][sum Cout] buffer
   long rv32_ld = 0;
   size_t dy_off = NONE;
@@ -267,6 +277,7 @@ struct ConvOp : Op {
     g.bias = p.eng->Wp(b);
     if (resid) { g.resid = p.P(resid); g.ldr = Cout; }
     if (rowvec) { g.rowvec = p.P(rowvec); g.ldv = rowvec->ld(); g.rows_per_batch = Ho * Wo; }
+    if (fsplit > 1) { g.splitk = fsplit; g.slab = p.F(p.slab_main_off); }
     return launch_gemm(g, st);
   }
   void plan_bwd(Plan& p) override {
@@ -283,6 +294,11 @@ struct ConvOp : Op {
     if (x->need_grad) dx = p.grad_dst(x);
     splitk = pick_splitk(Cout, Cin, 9, (long)Bn * Ho * Wo);
     want_slab(p, Cout, Cin, 9, splitk);
+    if (stride == 1 && Cin % 64 == 0) {
+      fsplit = gemm_pick_splitk_small(Bn * Ho * Wo, Cout, 9 * Cin);
+      want_slab_main(p, Bn * Ho * Wo, Cout, fsplit);
+      if (x->need_grad && Cout % 64 == 0) { dsplit = gemm_pick_splitk_small(Bn * H * W, Cin, 9 * Cout); want_slab_main(p, Bn * H * W, Cin, dsplit); }
+    }
   }
   int bwd(Plan& p, hipStream_t st, bool first) override {
     const bf16* dy = p.GP(dy_off);
@@ -320,6 +336,7 @@ struct ConvOp : Op {
       g.taps = 9; g.Hm = H; g.Wm = W; g.Hs = Ho; g.Ws = Wo; g.sm = 1; g.sd = stride;
       g.flip = 1; g.b_tap_stride = Cin;
       if (dx.addend != NONE) { g.resid = p.GP(dx.addend); g.ldr = Cin; }
+      if (dsplit > 1) { g.splitk = dsplit; g.slab = p.F(p.slab_main_off); }
       CHK(launch_gemm(g, st));
     }
     return 0;
@@ -874,6 +891,7 @@ void Engine::build(Plan* plan) {
     plan->grad_dst(plan->pred);
     for (int i = (int)plan->ops.size() - 1; i >= 0; --i) plan->ops[i]->plan_bwd(*plan);
     plan->slab_off = plan->alloc(sizeof(float) * (plan->slab_floats ? plan->slab_floats : 4));
+    plan->slab_main_off = plan->alloc(sizeof(float) * (plan->slab_main_floats ? plan->slab_main_floats : 4));
     plan->apart_off = plan->alloc(sizeof(float) * (plan->apart_floats ? plan->apart_floats : 4));
     plan->seg_first_op.assign(nseg, -1);
     plan->seg_last_op.assign(nseg, -2);

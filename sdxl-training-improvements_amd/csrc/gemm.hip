@@ -104,12 +104,22 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
     tap_fixed = blockIdx.z / p.splitk;
     split = blockIdx.z - tap_fixed * p.splitk;
   }
+  // NT / NN with split-K (linear FAST staging only, launcher-checked: small-M problems -- a 256-row batch is 16 tiles for 256 CUs
+  // and a 160-step reduction per tile): split `blockIdx.z` multiplies its K range, the fp32 partial tile goes to its slab,
+  // splitk_epilogue_kernel sums the slabs in a fixed order and applies the bf16 epilogue
+  constexpr bool NSPLIT = FORM != GEMM_TN && FAST && !KSP;      // (linear, or the same-size stride-1 3x3 gather: K range = taps x channels)
+  if (NSPLIT && p.splitk > 1) split = blockIdx.z;
   const int ktiles_per_tap = (p.K + BK - 1) / BK;
   int kt_begin = 0, kt_end;
   if (FORM == GEMM_TN) {
     int chunk = (ktiles_per_tap + p.splitk - 1) / p.splitk;
     kt_begin = split * chunk;
     kt_end = min(ktiles_per_tap, kt_begin + chunk);
+  } else if (NSPLIT && p.splitk > 1) {
+    const int total = ktiles_per_tap * p.taps;
+    int chunk = (total + p.splitk - 1) / p.splitk;
+    kt_begin = split * chunk;
+    kt_end = min(total, kt_begin + chunk);
   } else {
     kt_end = ktiles_per_tap * p.taps;
   }
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
         const int row = c * KC_ROWS + kc_rowl;
         const int m = m0 + row;
         ok = ok && m < p.M;
-        pa[j] = ok ? p.A + (long)m * p.lda + ((kc_pv ^ kc_swz<BK>(row)) << 3) : zsrc;
+        pa[j] = ok ? p.A + (long)m * p.lda + (long)kt_begin * BK + ((kc_pv ^ kc_swz<BK>(row)) << 3) : zsrc;
         sa[j] = ok ? BK : 0;
       }
     }
@@ -168,7 +178,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
         const int row = c * KC_ROWS + kc_rowl;
         const int n = n0 + row;
         ok = ok && n < p.N;
-        pb[j] = ok ? p.B + (long)n * p.ldb + ((kc_pv ^ kc_swz<BK>(row)) << 3) : zsrc;
+        pb[j] = ok ? p.B + (long)n * p.ldb + (long)kt_begin * BK + ((kc_pv ^ kc_swz<BK>(row)) << 3) : zsrc;
         sb[j] = ok ? BK : 0;
       } else {
         constexpr int V = BN / 8;
@@ -231,9 +241,14 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
         }
       }
     }
-    if (FORM != GEMM_TN) {
-      ua = -(long)(p.Wm + 1) * p.lda;                            // tap 0 = (-1, -1)
-      ub = (long)(p.flip ? p.taps - 1 : 0) * p.b_tap_stride;
+    if (FORM != GEMM_TN) {                                       // (tap, channel step) of this workgroup's first K-step
+      s_tap = kt_begin / ktiles_per_tap;
+      s_c = kt_begin - s_tap * ktiles_per_tap;
+      const int dy = s_tap / 3 - 1, dx = s_tap - (s_tap / 3) * 3 - 1;
+      const int wtap = p.flip ? p.taps - 1 - s_tap : s_tap;
+      ua = (long)(dy * p.Wm + dx) * p.lda + (long)s_c * BK;
+      if (FORM == GEMM_NT) ub = (long)wtap * p.b_tap_stride + (long)s_c * BK;
+      else ub = (long)wtap * p.b_tap_stride + (long)s_c * BK * p.ldb;
     }
   }
   // CF: move the uniform state to the next K-step (called once all pieces of a step have been issued)
@@ -598,6 +613,20 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
       *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) = o;
     }
   };
+  if (NSPLIT && p.splitk > 1) {      // fp32 partial tile -> this split's slab (same fragment layout as the TN epilogue)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wm * (MI * 16) + i * 16 + l16;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 16 + g * 4;
+        if (n >= p.N) continue;
+        *(f32x4*)(p.slab + ((long)split * p.M + m) * p.slab_ld + n) = acc[i][j];
+      }
+    }
+    return;
+  }
   if (FORM == GEMM_TN || !p.geglu) {
     if (FORM != GEMM_TN) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // 24 wait states: MFMA results -> inline-asm VALU reads below (XDL write -> VALU read needs up to 18)
 #pragma unroll
@@ -748,6 +777,42 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __re
   }
 }
 
+// split-K of the bf16-output forms: C[m][n] = bf16(sum_s slab[s][m][n] + bias[n] + rowvec[m / rpb][n] + resid[m][n]), fixed order
+__global__ void splitk_epilogue_kernel(const float* __restrict__ slab, bf16* __restrict__ C, int M, int N, long ldc, long slab_ld,
+                                       int splitk, const bf16* __restrict__ bias, const bf16* __restrict__ resid, long ldr,
+                                       const bf16* __restrict__ rowvec, long ldv, int rows_per_batch) {
+  const int vpr = N / 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)M * vpr; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / vpr;
+    const int n = (int)(i - m * vpr) * 8;
+    float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < splitk; ++s) {
+      const float* sp = slab + ((long)s * M + m) * slab_ld + n;
+      const f32x4 a = *(const f32x4*)sp, b = *(const f32x4*)(sp + 4);
+      x[0] += a[0]; x[1] += a[1]; x[2] += a[2]; x[3] += a[3]; x[4] += b[0]; x[5] += b[1]; x[6] += b[2]; x[7] += b[3];
+    }
+    if (bias) {
+      const bf16x8 v = *(const bf16x8*)(bias + n);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] += (float)v[e];
+    }
+    if (rowvec) {
+      const bf16x8 v = *(const bf16x8*)(rowvec + (m / rows_per_batch) * ldv + n);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] += (float)v[e];
+    }
+    if (resid) {
+      const bf16x8 v = *(const bf16x8*)(resid + m * ldr + n);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] += (float)v[e];
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16)x[e];
+    *(bf16x8*)(C + m * ldc + n) = o;
+  }
+}
+
 size_t gemm_slab_floats(int M, int N, int taps, int splitk) { return splitk > 1 ? (size_t)splitk * M * N * taps : 0; }
 
 void gemm_defaults(GemmP* p) {
@@ -768,7 +833,7 @@ static int launch_k(const GemmP& p, hipStream_t st) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), FORM == GEMM_TN ? (p.group > 1 ? p.group : p.taps * p.splitk) : 1);
+  dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), FORM == GEMM_TN ? (p.group > 1 ? p.group : p.taps * p.splitk) : p.splitk);
   hipLaunchKernelGGL((gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW, KSP>), grid, dim3(NW * 64), smem, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
@@ -821,6 +886,7 @@ static int launch_one(const GemmP& p, hipStream_t st) {
   //  -2 ms, step +2.4 ms, profiles/r02c)
   if (FORM == GEMM_NT && n160 && t160 <= 256 && (long)p.K * p.taps >= 2560) cfg = 23;
   if (g_force_cfg > 0) cfg = g_force_cfg;
+  if (FORM != GEMM_TN && p.splitk > 1) cfg = n160 ? 13 : 1;     // split-K of the bf16-output forms: the 4-wave FAST configurations
   if (p.geglu && !g80 && (cfg == 3 || cfg == 13 || cfg == 23)) cfg = 1;   // group-64 packing needs 128-column tiles
   if (g80 && cfg != 3 && cfg != 13 && cfg != 23) cfg = 13;                 // group-80 packing needs 160-column tiles
   if ((cfg == 3 || cfg == 13 || cfg == 23) && p.N % 160 != 0) cfg = 1;
@@ -915,6 +981,20 @@ int gemm_pick_splitk(int M, int N, int taps, long red) {
   if (s > 32) s = 32;
   return (int)s;
 }
+// split-K factor for the bf16-output forms (forward, dgrad) of SMALL problems: a 512^2 image at batch 1 has 256 rows at the
+// 1280-channel level -- 16 tiles of 128x160 for 256 CUs, each walking up to 160 K-steps at ~1 us: 58 us per dgrad launch,
+// 22 ms of a 59 ms step.  Enough splits to put ~one workgroup on every CU, at least 4 K-steps each; 1 when the tiles alone
+// fill half the chip (every problem of the B = 4, 1024^2 step).
+int gemm_pick_splitk_small(int M, int N, int K) {     // K = the whole reduction length (taps x channels for a convolution)
+  if (M < 64 || K % 64) return 1;
+  const long tiles = (long)cdiv(M, 128) * cdiv(N, N % 160 == 0 ? 160 : 128);
+  if (tiles >= 128) return 1;
+  long s = 256 / tiles;
+  const long maxs = K / 64 / 4;
+  if (s > maxs) s = maxs;
+  if (s > 32) s = 32;
+  return s < 2 ? 1 : (int)s;
+}
 // weight gradients whose tile count fills a third or a quarter of the chip are launched 3 or 4 at a time (GemmP::group)
 // instead of alone with split-K slabs + a reduce pass each: 1280 x 1280 x 4096 (192 per step at B=4 1024^2) took
 // 43 us + 6 us of reduce each, three of them in one grid take the time of one 3840 x 1280 x 4096 product (~90 us)
@@ -957,7 +1037,10 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
     ARG_CHECK(p.ldc % 4 == 0, "gemm TN: ldc=%ld must be a multiple of 4", p.ldc);
   } else {
     ARG_CHECK(p.K % 8 == 0, "gemm: K=%d must be a multiple of 8", p.K);
-    ARG_CHECK(!p.out_f32 && p.splitk == 1, "gemm NT/NN: bf16 output, no split-K");
+    ARG_CHECK(!p.out_f32, "gemm NT/NN: bf16 output");
+    // split-K of the bf16-output forms: plain linear problems whose K is a whole number of 64-element steps
+    const bool conv_fast = p.taps == 9 && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws;
+    if (p.splitk > 1 && (!(p.taps == 1 || conv_fast) || p.geglu || p.K % 64 != 0 || p.N % 8 != 0)) p.splitk = 1;
     ARG_CHECK(p.ldc % 8 == 0, "gemm: ldc=%ld must be a multiple of 8", p.ldc);
     if (p.accumulate) { p.resid = (const bf16*)p.C; p.ldr = p.ldc; }
     if (p.geglu) {
@@ -1001,14 +1084,14 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
     }
   }
   if (p.splitk > 1) {
-    ARG_CHECK(p.form == GEMM_TN, "gemm: split-K only for the TN (wgrad) form");
     ARG_CHECK(p.slab != nullptr, "gemm: split-K needs a slab scratch buffer");
-    p.slab_ld = (long)p.N * p.taps;
+    if (p.form != GEMM_TN && p.splitk > p.K / 64 * p.taps) p.splitk = p.K / 64 * p.taps;
+    p.slab_ld = p.form == GEMM_TN ? (long)p.N * p.taps : (long)p.N;
   }
   const bool conv = p.taps == 9;
   int rc;
   {   // 256 x 256 kernel (gemm256.hip)
-    if (g_mode256 && p.group <= 1 && !p.Cb && gemm256_applicable(p)) {
+    if (g_mode256 && p.group <= 1 && !p.Cb && !(p.form != GEMM_TN && p.splitk > 1) && gemm256_applicable(p)) {
       if (g_mode256 == 2 || gemm_use256(p.form, p.M, p.N, p.K, p.splitk)) {
         rc = launch_gemm256(p, st);
         if (rc == 0 && p.splitk > 1) {
@@ -1022,6 +1105,19 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
         return rc;
       }
     }
+  }
+  if (p.form != GEMM_TN && p.splitk > 1) {     // partial tiles to the slabs, then the fixed-order sum + bf16 epilogue
+    const bf16* resid = p.resid; const long ldr = p.ldr;
+    if (conv) rc = p.form == GEMM_NT ? launch_one<GEMM_NT, true>(p, st) : launch_one<GEMM_NN, true>(p, st);
+    else rc = p.form == GEMM_NT ? launch_one<GEMM_NT, false>(p, st) : launch_one<GEMM_NN, false>(p, st);
+    if (rc) return rc;
+    const long nv = (long)p.M * (p.N / 8);
+    int g = (int)((nv + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(g), dim3(256), 0, st, p.slab, (bf16*)p.C, p.M, p.N, p.ldc, p.slab_ld, p.splitk,
+                       p.bias, resid, ldr, p.rowvec, p.ldv, p.rows_per_batch > 0 ? p.rows_per_batch : 1);
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
   }
   switch (p.form) {
     case GEMM_NT: return conv ? launch_one<GEMM_NT, true>(p, st) : launch_one<GEMM_NT, false>(p, st);

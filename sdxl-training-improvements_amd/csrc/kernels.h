@@ -46,6 +46,8 @@ struct GemmP {
   int geglu_group;   // 64 (128-column tiles) or 80 (160-column tiles); 0 = 64
   bf16* aux;
   long ldaux;
+  // NT / NN (bf16 output), taps == 1, no GEGLU, K % 64 == 0: splitk > 1 -> fp32 partial tiles to slab[split], then
+  // splitk_epilogue_kernel sums them in a fixed order and applies bias / row vector / residual (small-M problems).
   // fp32 output (wgrad): C_f32 (+)= acc.  splitk > 1: each split writes its partial [M][N*taps] tile set to
   // slab[split] (plain stores) and a reduce kernel sums the slabs in a fixed order (deterministic, no atomics);
   // the conv form requires C to be the dense [M][taps*N] weight-gradient matrix (ldc == N*taps).
@@ -81,6 +83,7 @@ bool gemm256_applicable(const GemmP& p);
 void gemm_set_mode(int mode);   // bits 0-1: 0 never / 1 policy / 2 wherever applicable; bits 2..: force a 128-row configuration
 bool gemm_use256(int form, int M, int N, int K, int splitk);   // the policy of mode 1
 int gemm_pick_splitk(int M, int N, int taps, long red);        // split-K factor the wgrad launchers should request
+int gemm_pick_splitk_small(int M, int N, int K);               // split-K factor for NT / NN (bf16 output) launches of small problems
 int launch_gemm256(const GemmP& p, hipStream_t st);
 // per-launch HIP-event timing of every GEMM launch between begin and end (end synchronises the device)
 int gemm_profile_begin();

@@ -100,6 +100,26 @@ def test_gemm_nn_and_accumulate(L, M, N, K):
     report(f"gemm_nn+= {M}x{N}x{K}", out2, ref + base.float(), 6e-3)
 
 
+@pytest.mark.parametrize("M,N,K,splitk", [(256, 1280, 10240, 16), (256, 1280, 1280, 5), (77, 640, 2048, 4), (1000, 640, 2560, 3),
+                                          (256, 384, 320, 7), (128, 160, 64, 4)])
+def test_gemm_nt_nn_splitk_small_problems(L, M, N, K, splitk):
+    """split-K of the bf16-output forms (small-M problems: batch 1 / 512^2): fp32 partial tiles per split, fixed-order sum +
+    bias / residual / accumulate epilogue; a factor beyond K / 64 is clamped, ragged M and non-160 N go through."""
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    lib.check(L.sdxl_op_gemm(0, ptr(a), ptr(w), ptr(out), M, N, K, ptr(bias), ptr(res), 0, splitk, stream()))
+    report(f"gemm_nt splitk={splitk} {M}x{N}x{K}", out, a.float() @ w.float().t() + bias.float() + res.float(), 6e-3)
+    ref1 = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    lib.check(L.sdxl_op_gemm(0, ptr(a), ptr(w), ptr(ref1), M, N, K, ptr(bias), ptr(res), 0, 1, stream()))
+    assert float((out.float() - ref1.float()).abs().max()) <= 2 ** -7 * float(ref1.float().abs().max())     # vs the unsplit launch: one bf16 step
+    wn = rnd(K, N, seed=6, scale=K ** -0.5)
+    base = rnd(M, N, seed=7)
+    out2 = base.clone()
+    lib.check(L.sdxl_op_gemm(1, ptr(a), ptr(wn), ptr(out2), M, N, K, None, None, 1, splitk, stream()))
+    report(f"gemm_nn+= splitk={splitk} {M}x{N}x{K}", out2, a.float() @ wn.float() + base.float(), 6e-3)
+
+
 @pytest.mark.parametrize("M,N,K,splitk", [(128, 128, 64, 1), (320, 384, 1000, 1), (1280, 640, 4096, 4),
                                           (8, 320, 65536, 16), (640, 640, 308, 2)])
 def test_gemm_tn_wgrad(L, M, N, K, splitk):
@@ -230,7 +250,9 @@ def _conv_ref(x_nhwc, w_native, bias, stride):
                                                    (2, 8, 8, 192, 8, 1), (1, 32, 32, 960, 320, 1),
                                                    # the 1344x768 bucket's level widths (84, 42): the wgrad fast path's
                                                    # incremental (y, x) tracking wraps rows mid-K-step there
-                                                   (2, 24, 42, 128, 64, 1), (1, 48, 84, 64, 128, 1), (3, 10, 42, 64, 64, 1)])
+                                                   (2, 24, 42, 128, 64, 1), (1, 48, 84, 64, 128, 1), (3, 10, 42, 64, 64, 1),
+                                                   # batch 1, 512^2 at the 1280-channel level: 256 pixels -> split (tap, channel) reduction
+                                                   (1, 16, 16, 1280, 1280, 1), (1, 32, 32, 640, 1280, 1)])
 def test_conv3x3_fwd_dgrad_wgrad(L, B, H, W, Cin, Cout, stride):
     x = rnd(B, H, W, Cin, seed=10)
     w = rnd(Cout, 9, Cin, seed=11, scale=(9 * Cin) ** -0.5)
