@@ -149,7 +149,9 @@ int sdxl_clip_coef(const float* sumsq_dev, float max_norm, float* coef_dev, void
 
 /* ---- single-kernel entry points (parity tests call these; same kernels the plan launches) --------------------- */
 /* C[M,N] = A.B ; form 0: A[M,K],B[N,K] ; 1: A[M,K],B[K,N] ; 2: A[K,M],B[K,N] -> fp32 C (+= if accumulate).
- * form 2 (wgrad): `bias`, when given, is the fp32 bias-GRADIENT accumulator float[M]: += column sums of A. */
+ * form 2 (wgrad): `bias`, when given, is the fp32 bias-GRADIENT accumulator float[M]: += column sums of A.
+ * splitk > 1: deterministic split-K (fp32 partial slabs, fixed-order sum): the wgrad form always; forms 0 / 1 when K is a
+ * multiple of 64 (what the plan does for problems with fewer than 128 output tiles), otherwise ignored. */
 int sdxl_op_gemm(int form, const void* A, const void* B, void* C, int M, int N, int K, const void* bias,
                  const void* resid, int accumulate, int splitk, void* stream);
 /* n (<= 4) weight gradients of one shape in one launch, as the plan groups them: dw[i][Mo][No] (+)= dy[i]^T . x[i] with
