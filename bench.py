@@ -29,6 +29,7 @@ sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
 
 FLOP_PER_IMAGE_1024 = 20.28e12      # fwd+bwd, BASELINE.md section 2 (2*M*N*K of every matmul, bwd = 2x fwd)
+FLOP_PER_IMAGE_1344x768 = 19.93e12          # 1344x768 (latent 96x168)
 FLOP_PER_IMAGE_512 = 4.77e12
 PEAK_BF16_TFLOPS = 2516.6           # 256 CU x 2.4 GHz x 4096 FLOP/clk/CU (MI355X dense bf16 MFMA)
 
@@ -38,6 +39,8 @@ WORKLOADS = {
                               "batch 4/GPU, 1024^2 (latent 128x128)"),
     "flow_b4_1024": dict(method="flow_matching", B=4, H=128, W=128, flop_per_image=FLOP_PER_IMAGE_1024,
                          desc="method=flow_matching (logit-normal t), SDXL-base UNet fwd+bwd, batch 4/GPU, 1024^2"),
+    "flow_b4_1344x768": dict(method="flow_matching", B=4, H=96, W=168, flop_per_image=FLOP_PER_IMAGE_1344x768,
+                             desc="method=flow_matching, SDXL-base UNet fwd+bwd, batch 4/GPU, 1344x768 bucket (latent 96x168)"),
     "ddpm_b1_512": dict(method="ddpm", B=1, H=64, W=64, flop_per_image=FLOP_PER_IMAGE_512,
                         desc="method=ddpm, SDXL-base UNet fwd+bwd, batch 1, 512^2 (latent 64x64)"),
 }
