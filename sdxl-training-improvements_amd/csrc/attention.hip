@@ -754,8 +754,9 @@ int launch_attn_bwd_dkv(const AttnP& p, hipStream_t st) {
   if (int e = check_attn_bwd(p)) return e;
   AttnP q = p;
   if (q.qsplit < 1 || !q.part) q.qsplit = 1;
-  // two key blocks per wave when the 128-key workgroups still fill the chip twice over
-  if (q.qsplit == 1 && (long)cdiv(p.Nk, 128) * p.B * p.H >= 512)
+  // two key blocks per wave (232 VGPRs, 2 workgroups per CU) when the 128-key workgroups fill the chip four times over; at
+  // N = 1024 (640 of them: 1.25 rounds of 512 slots) the one-block variant (143 VGPRs, 3 per CU, 1 280 workgroups) is 4 % faster
+  if (q.qsplit == 1 && (long)cdiv(p.Nk, 128) * p.B * p.H >= 1024)
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, dim3(cdiv(p.Nk, 128), p.B * p.H, 1), dim3(256), 0, st, q);
   else
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, dim3(cdiv(p.Nk, 64), p.B * p.H, q.qsplit), dim3(256), 0, st, q);
