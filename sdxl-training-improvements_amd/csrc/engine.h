@@ -80,7 +80,8 @@ struct Plan {
   size_t gn_ws_off = NONE, gn_ws_floats = 0;  // GroupNorm scratch shared by all (stream-ordered) norm ops
   size_t slab_off = NONE, slab_floats = 0;    // split-K partial slabs of the wgrad GEMMs (shared, stream-ordered)
   size_t slab_main_off = NONE, slab_main_floats = 0;   // the same for split forward / dgrad launches (caller's stream)
-  size_t apart_off = NONE, apart_floats = 0;  // query-split partials of the cross-attention dK/dV kernel (main stream)
+  size_t apart_off = NONE, apart_floats = 0;  // query-split partials of the self-attention dK / dV kernel (caller's stream)
+  size_t apart_side_off = NONE, apart_side_floats = 0;   // ... of the cross-attention dK / dV kernel (side stream): never shared
 
   Act* new_act(long rows, int cols, bool need_grad = true, int pad_rows = 0);
   Act* view(Act* parent, int col0, int cols);   // columns [col0, col0 + cols) of parent

@@ -412,7 +412,9 @@ struct AttnOp : Op {
     delta_off = p.alloc(sizeof(float) * (size_t)Bn * heads * Nq);
     qsplit = attn_pick_qsplit(Bn, heads, Nq, Nk);
     size_t need = attn_part_floats(Bn, heads, Nk, qsplit);
-    if (need > p.apart_floats) p.apart_floats = need;
+    // self-attention's dK / dV kernel runs on the caller's stream, cross-attention's on the side stream (bwd): one scratch each
+    if (self) { if (need > p.apart_floats) p.apart_floats = need; }
+    else if (need > p.apart_side_floats) p.apart_side_floats = need;
   }
   void fill(Plan& p, AttnP& a, bool grads) {
     memset(&a, 0, sizeof(a));
@@ -430,7 +432,7 @@ struct AttnOp : Op {
       a.dO = p.GP(do_off); a.lddo = C;
       a.Delta = p.F(delta_off);
       a.qsplit = qsplit;
-      a.part = p.F(p.apart_off);
+      a.part = p.F(self ? p.apart_off : p.apart_side_off);
       if (self) {
         a.dQ = p.GP(dq.out); a.dK = a.dQ + C; a.dV = a.dQ + 2 * C;
         a.lddq = a.lddk = a.lddv = 3L * C;
@@ -893,6 +895,7 @@ void Engine::build(Plan* plan) {
     plan->slab_off = plan->alloc(sizeof(float) * (plan->slab_floats ? plan->slab_floats : 4));
     plan->slab_main_off = plan->alloc(sizeof(float) * (plan->slab_main_floats ? plan->slab_main_floats : 4));
     plan->apart_off = plan->alloc(sizeof(float) * (plan->apart_floats ? plan->apart_floats : 4));
+    plan->apart_side_off = plan->alloc(sizeof(float) * (plan->apart_side_floats ? plan->apart_side_floats : 4));
     plan->seg_first_op.assign(nseg, -1);
     plan->seg_last_op.assign(nseg, -2);
     for (int i = 0; i < (int)plan->ops.size(); ++i) {

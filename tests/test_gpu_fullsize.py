@@ -314,10 +314,9 @@ def test_flow_matching_batch_decomposes(full, shape):
     print(f"[parity] flow matching {B}x{H}x{W}: batch loss {lb:.6f} mean of per-sample {mean:.6f}; |grad| {nb:.4e} vs {ns:.4e}; probe rel {rel_g:.3e}")
     assert math.isfinite(lb) and 0 < lb < 1000
     assert abs(lb - mean) <= 1e-3 * abs(lb)
-    # the per-sample steps are small problems and take the split-K forward / dgrad launches (another fp32 summation order): two
-    # bf16 evaluations of the 70-block network then agree to bf16 noise -- the level of either against the fp32 oracle
-    # (rel-L2 ~1e-2 per tensor, test_headline_shape_b1...), a few times that on the most sensitive tensors (this probe)
-    assert abs(nb - ns) <= 5e-3 * nb and rel_g <= 5e-2
+    # (the per-sample steps are small problems and take the split-K forward / dgrad launches: another fp32 summation order, the
+    #  same bits to bf16 noise)
+    assert abs(nb - ns) <= 5e-3 * nb and rel_g <= 1e-2
 
 
 def test_configs4_mixed_buckets_accumulate_across_plans(full):
@@ -352,3 +351,23 @@ def test_configs4_mixed_buckets_accumulate_across_plans(full):
             rel = float((acc - ref).norm() / ref.norm())
             print(f"[parity] mixed buckets order {order} {k}: rel {rel:.3e}")
             assert rel <= 1e-5, (order, k, rel)
+
+
+def test_small_batch_accumulation_is_run_to_run_reproducible(full):
+    """Batch-1 micro-steps (where self-attention's dK / dV also goes through query-split partials, on the caller's stream, while
+    cross-attention's runs on the side stream) accumulated over different samples give the same gradient norm every time: the
+    two kernels' partial scratch buffers are separate (they once were not: a race only changing inputs made visible)."""
+    net = full
+    B, H, W = 3, 96, 168
+    x = _inputs(B, H, W, seed=77)
+    t = torch.tensor([0.2, 0.5, 0.8])
+    norms = []
+    for _ in range(4):
+        net.zero_grads()
+        for i in range(B):
+            s = slice(i, i + 1)
+            net.forward_loss("flow_matching", x["lat"][s], x["noise"][s], t[s], t[s], x["ehs"][s], x["pooled"][s], x["tid"][s])
+            net.backward(1.0 / B, i == 0)
+        norms.append(net.grad_norm())
+    print(f"[parity] small-batch accumulation |grad| over 4 repeats: {norms}")
+    assert max(norms) - min(norms) <= 1e-5 * max(norms), norms
