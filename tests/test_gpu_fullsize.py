@@ -371,3 +371,30 @@ def test_small_batch_accumulation_is_run_to_run_reproducible(full):
         norms.append(net.grad_norm())
     print(f"[parity] small-batch accumulation |grad| over 4 repeats: {norms}")
     assert max(norms) - min(norms) <= 1e-5 * max(norms), norms
+
+
+@pytest.mark.parametrize("B", [4, 2, 1])
+def test_step_results_do_not_depend_on_the_previous_step(full, B):
+    """A step's loss and gradients are functions of its inputs only: A, then B, then A again gives A's numbers again (to the
+    fp32-atomic noise of the small parameters) -- what a missing stream dependency or a shared scratch buffer would break, and
+    what repeating the SAME step cannot show (stale data of an identical step is the right data)."""
+    net = full
+    xa, xb = _inputs(B, 128, 128, seed=901), _inputs(B, 128, 128, seed=902)
+    ts = torch.tensor([100, 400, 650, 900][:B])
+    sig = R.karras_sigmas()[ts]
+    probes = ["mid_block.attentions.0.transformer_blocks.3.attn1.to_v.weight", "down_blocks.2.attentions.0.transformer_blocks.2.attn2.to_k.weight",
+              "up_blocks.1.resnets.1.conv1.weight", "up_blocks.0.attentions.1.transformer_blocks.8.ff.net.2.weight"]
+
+    def step(x):
+        net.zero_grads()
+        net.forward_loss("ddpm", x["lat"], x["noise"], sig, ts.float(), x["ehs"], x["pooled"], x["tid"])
+        net.backward(1.0, True)
+        return net.read_loss()[0], net.grad_norm(), {k: net.export(k, grad=True).clone() for k in probes}
+
+    l1, n1, g1 = step(xa)
+    step(xb)
+    l2, n2, g2 = step(xa)
+    print(f"[parity] B={B}: loss {l1!r} / {l2!r}, |grad| {n1!r} / {n2!r}")
+    assert abs(l1 - l2) <= 1e-6 * abs(l1) and abs(n1 - n2) <= 1e-6 * n1
+    for k in probes:
+        assert torch.equal(g1[k], g2[k]), k
