@@ -32,6 +32,19 @@ FLOP_PER_IMAGE_1024 = 20.28e12      # fwd+bwd, BASELINE.md section 2 (2*M*N*K of
 FLOP_PER_IMAGE_1344x768 = 19.93e12          # 1344x768 (latent 96x168)
 FLOP_PER_IMAGE_512 = 4.77e12
 PEAK_BF16_TFLOPS = 2516.6           # 256 CU x 2.4 GHz x 4096 FLOP/clk/CU (MI355X dense bf16 MFMA)
+PMC_SUMMARY = "r03_pmc_step_summary.json"     # committed PMC passes (profiles/tools/measure_step.sh), stamped with the commit they were taken at
+
+
+def kernels_changed_since(commit):
+    """True if the kernel sources differ between `commit` and the working tree (then the committed PMC traffic figure is stale);
+    None when git is not available (the GPU box's snapshot has no .git: the stamp is reported, the comparison is the reader's)."""
+    try:
+        import subprocess
+        r = subprocess.run(["git", "-C", str(ROOT), "diff", "--quiet", commit, "--", "sdxl-training-improvements_amd/csrc"],
+                           capture_output=True, timeout=20)
+        return None if r.returncode not in (0, 1) else r.returncode == 1
+    except Exception:
+        return None
 
 WORKLOADS = {
     "ddpm_b4_1024": dict(method="ddpm", B=4, H=128, W=128, flop_per_image=FLOP_PER_IMAGE_1024,
@@ -43,6 +56,13 @@ WORKLOADS = {
                              desc="method=flow_matching, SDXL-base UNet fwd+bwd, batch 4/GPU, 1344x768 bucket (latent 96x168)"),
     "ddpm_b1_512": dict(method="ddpm", B=1, H=64, W=64, flop_per_image=FLOP_PER_IMAGE_512,
                         desc="method=ddpm, SDXL-base UNet fwd+bwd, batch 1, 512^2 (latent 64x64)"),
+    # configs[4]: the two bucket shapes alternate 1:1 per micro-step (two plans sharing arenas and workspace), gradient
+    # accumulation 4 -- gradients are zeroed at the start of a cycle and exchanged (N > 1) on every 4th micro-step only.
+    # One "step" of the bench = one micro-step (4 images per GPU).
+    "flow_mixed_accum4": dict(method="flow_matching", B=4, H=128, W=128, accum=4, buckets=[(128, 128), (96, 168)],
+                              flop_per_image=0.5 * (FLOP_PER_IMAGE_1024 + FLOP_PER_IMAGE_1344x768),
+                              desc="method=flow_matching, mixed aspect-ratio buckets 1024^2 / 1344x768 alternating per micro-step, "
+                                   "grad-accum 4 (exchange on every 4th micro-step), batch 4/GPU; one step = one micro-step"),
 }
 
 
@@ -51,9 +71,11 @@ def karras_table(n=1000, smin=0.002, smax=20000.0, rho=7.0):
     return (smax ** (1 / rho) + ramp * (smin ** (1 / rho) - smax ** (1 / rho))) ** rho
 
 
-def make_batch(wl, rank, device, cross=2048, pooled=1280):
+def make_batch(wl, rank, device, cross=2048, pooled=1280, hw=None):
     g = torch.Generator().manual_seed(1234 + rank)
     B, H, W = wl["B"], wl["H"], wl["W"]
+    if hw is not None:
+        H, W = hw
     r = lambda *s: torch.randn(*s, generator=g)
     b = dict(lat=r(B, 4, H, W), noise=r(B, 4, H, W), ehs=r(B, 77, cross), pooled=r(B, pooled),
              tid=torch.tensor([[8.0 * W, 8.0 * H, 0, 0, 8.0 * W, 8.0 * H]] * B))
@@ -131,6 +153,22 @@ def cpu_baseline(threads_list=None, timed_steps: int = 3):
                       f"threads) scaled to 1024^2-equivalent images by the FLOP ratio 4.77/20.28; weight init {t_init:.1f} s untimed"}
 
 
+def rccl_info(max_lines: int = 6):
+    """what RCCL said about the algorithm / protocol / channels it picked (NCCL_DEBUG=INFO lines of this rank's log file), or None"""
+    path = os.environ.get("SDXL_RCCL_LOG")
+    if not path or not os.path.exists(path):
+        return None
+    import re
+    out = []
+    with open(path, errors="replace") as f:
+        for line in f:
+            if re.search(r"(?i)\b(algo|proto|ring|tree|channel|xgmi|p2p)", line):
+                out.append(line.strip()[-200:])
+                if len(out) >= max_lines:
+                    break
+    return out or None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,8 +178,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="skip the (untimed) fused-optimizer measurement")
     ap.add_argument("--cpu-threads", type=int, nargs="*", default=None, help="thread counts of the CPU baseline (default: one socket's cores, 8)")
-    ap.add_argument("--exchange", default="zero1", choices=["zero1", "allreduce"],
-                    help="N > 1: reduce-scatter of the gradient buckets (ZeRO-1, default) or all-reduce")
+    ap.add_argument("--exchange", default="allreduce", choices=["zero1", "allreduce"],
+                    help="N > 1: all-reduce of the bf16 gradient buckets overlapped with the backward (default: what north_star "
+                         "names), or zero1 = reduce-scatter of the buckets + the all-gather of the (updated) parameters, BOTH inside "
+                         "the timed step (the same bytes on the wire as the all-reduce; the sharded update itself is reported apart)")
     ap.add_argument("--no-emit", action="store_true", help="N > 1 A/B: cast the fp32 gradient arena per bucket instead of bf16 wgrad epilogues")
     ap.add_argument("--profile-steps", type=int, default=1, help="extra steps with per-launch GEMM event timing")
     ap.add_argument("--gemm-mode", type=int, default=None, help="A/B runs: sdxl_set_gemm_mode (0 = 128-row kernel only)")
@@ -162,6 +202,10 @@ def main():
     backend = os.environ.get("SDXL_BENCH_BACKEND", "nccl")
     if os.environ.get("SDXL_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
+    if world > 1 and backend == "nccl" and rank == 0 and "NCCL_DEBUG" not in os.environ:
+        # rank 0 logs RCCL's topology / algorithm choices to a file; the lines end up in config.exchange.rccl
+        os.environ["SDXL_RCCL_LOG"] = f"/tmp/sdxl_rccl_{os.getpid()}.log"
+        os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,TUNING", NCCL_DEBUG_FILE=os.environ["SDXL_RCCL_LOG"])
     D.init_process_group(backend if world > 1 else None)
     wl = WORKLOADS[args.workload]
     dev = torch.device("cuda", local_rank)
@@ -176,8 +220,11 @@ def main():
         lib.check(lib.load().sdxl_set_gemm_mode(args.gemm_mode))
     net = NU.NativeUNet(NU.make_config(), device=local_rank)
     synth.load_synthetic(net, seed=0)                      # same weights on every rank
-    net.plan(wl["B"], wl["H"], wl["W"], 77)
-    b = make_batch(wl, rank, dev)
+    buckets = wl.get("buckets", [(wl["H"], wl["W"])])
+    accum = int(wl.get("accum", 1))
+    for (h_, w_) in buckets:
+        net.plan(wl["B"], h_, w_, 77)
+    batches = [make_batch(wl, rank, dev, hw=hw) for hw in buckets]
     L = net.L
 
     emit = world > 1 and not args.no_emit and hasattr(L, "sdxl_set_grad_emit")
@@ -193,37 +240,62 @@ def main():
     # keeps slice r of every bucket, bf16, pre-scaled by 1/N) over RCCL under the rest of the backward.  The sharded optimizer
     # update + parameter all-gather that follow belong to the optimizer phase, which the metric excludes at every N (measured
     # separately below).
-    Sync = D.ShardedGradSync if args.exchange == "zero1" else D.GradSync
-    sync = Sync(net.param_elems, cast, torch.bfloat16, dev)
-    scale = 1.0 / world
-    if emit:
-        net.set_grad_emit(sync.comm, 1.0)
+    sync = D.make_grad_sync(net.param_elems, cast, torch.bfloat16, dev, sharded=args.exchange == "zero1",
+                            segment_sizes=[n for _o, n in net.segment_ranges()])
+    sharded_exchange = isinstance(sync, D.ShardedGradSync)
+    scale = 1.0 / world / accum
+    micro = [0]
 
     def step():
-        net.zero_grads()
+        """one micro-step: (cycle start: zero grads) + loss prep + UNet forward + loss + UNet backward (+ at N > 1, on the cycle's
+        last micro-step, the COMPLETE gradient exchange: all-reduce, or reduce-scatter + parameter all-gather)"""
+        i = micro[0]
+        micro[0] += 1
+        b = batches[i % len(batches)]
+        first, last = i % accum == 0, i % accum == accum - 1
+        if first:
+            net.zero_grads()
         net.forward_loss(wl["method"], b["lat"], b["noise"], b["sigma_or_t"], b["timestep"], b["ehs"], b["pooled"], b["tid"])
-        net.backward(scale, True, on_segment=sync.on_segment if world > 1 else None, segment_stream=True)
-        sync.finish()
+        exch = world > 1 and last
+        if exch and emit:
+            net.set_grad_emit(sync.comm, 1.0)
+        net.backward(scale, first, on_segment=sync.on_segment if exch else None, segment_stream=True)
+        if exch:
+            if emit:
+                net.set_grad_emit(None)
+            sync.finish()
+            if sharded_exchange:          # the other half of the all-reduce's bytes: all-gather of this rank's parameter slices
+                sync.gather_params(net.weights)
 
     for _ in range(args.warmup):
         step()
+    micro[0] = 0
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    # per-step HIP events on the stream the step is launched on (SURVEY 8(d): report the median), inside the wall-clock bracket
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         step()
+        evs[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+    step_stats = {"median_ms": round(per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2]), 3),
+                  "min_ms": round(per_step[0], 3), "max_ms": round(per_step[-1], 3), "n": len(per_step),
+                  "how": "HIP events on the launch stream around every step of the timed region"}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
     loss = net.read_loss()[0]
+    net_param_elems = int(net.param_elems)       # bf16 gradient bytes sent (and, reduced, received) per rank and exchange = 2 x this
     images = world * wl["B"] * args.steps
     value = images / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
@@ -237,18 +309,24 @@ def main():
         fl, ms, n = C.c_double(), C.c_double(), C.c_int()
         lib.check(L.sdxl_profile_gemm_end(C.byref(fl), C.byref(ms), C.byref(n)))
         achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-        traffic = None       # fabric-side bytes of the GEMM family per step (one launch set), from the committed PMC passes of this
-        try:                 # workload: FETCH_SIZE x 2 (the gfx950 correction of the microarchitecture guide) + WRITE_SIZE, both in KiB
-            with open(ROOT / "profiles" / "r02_pmc_step_summary.json") as f:
+        traffic, traffic_commit = None, None   # fabric-side bytes of the GEMM family per step (one launch set), from the committed PMC passes
+        try:                 # of this workload: FETCH_SIZE x 2 (the gfx950 correction of the microarchitecture guide) + WRITE_SIZE, both in KiB
+            with open(ROOT / "profiles" / PMC_SUMMARY) as f:
                 pm = json.load(f)
             if pm.get("workload") == args.workload:
                 traffic = round(pm["gemm"]["hbm_bytes_per_step"])
+                traffic_commit = pm.get("commit")
         except Exception:
             pass
+        stale = kernels_changed_since(traffic_commit) if traffic_commit else None
+        if stale:
+            traffic = None
         roof = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "traffic_note": "bytes per step over all launches of the family (fabric side, MALL hits included); algorithmic "
-                                "operand + result bytes ~94e9",
+                "traffic_note": ("the committed PMC summary was taken at commit %s and the kernel sources changed since: re-run "
+                                 "profiles/tools/measure_step.sh" % traffic_commit) if stale else
+                                ("bytes per step over all launches of the family (fabric side, MALL hits included), PMC passes at commit %s; "
+                                 "algorithmic operand + result bytes ~94e9" % traffic_commit),
                 "kernel": "gemm_kernel<NT|NN|TN, conv|linear> (128-row tiles) + gemm256_kernel (256x256 tiles): bf16 MFMA 16x16x32",
                 "launches_per_step": n.value // args.profile_steps,
                 "gemm_ms_per_step": round(ms.value / args.profile_steps, 2),
@@ -260,7 +338,7 @@ def main():
     if not args.no_optimizer:
         from sdxl_amd.optimizer import AdamWBF16
         opt = AdamWBF16(net, lr=4e-7, weight_decay=0.01)
-        sharded = world > 1 and args.exchange == "zero1"
+        sharded = world > 1 and sharded_exchange
 
         def update():
             if sharded:           # ZeRO-1: this rank's slices of every bucket, then the parameters are all-gathered
@@ -305,9 +383,15 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": wl["desc"], "global_batch": wl["B"] * world, "parallelism": f"dp{world}",
-                          "exchange": None if world == 1 else ("reduce-scatter of bf16 gradient buckets overlapped with backward (ZeRO-1)"
-                                                               if args.exchange == "zero1" else "all-reduce of bf16 gradient buckets overlapped with backward"),
+                          "exchange": None if world == 1 else {
+                              "what": ("reduce-scatter of the bf16 gradient buckets overlapped with the backward + all-gather of the parameter slices, "
+                                       "both inside the timed step (ZeRO-1 wire pattern; the sharded update is in `optimizer`)") if sharded_exchange
+                                      else "all-reduce of the bf16 gradient buckets overlapped with the backward, complete inside the timed step",
+                              "every_n_micro_steps": accum,
+                              "exchange_bytes_timed": 2 * net_param_elems,     # bf16 gradient arena per rank and exchange (in: RS / AR; out: AG / AR)
+                              "backend": backend, "rccl": rccl_info()},
                           "weights": "synthetic (counter-hash init of the 2,567,463,684-parameter SDXL-base UNet)"},
+               "step_time": step_stats,
                "step_tflops_per_gpu": round(step_tflops, 1),
                "step_mfma_frac": round(step_tflops / PEAK_BF16_TFLOPS, 4),
                "loss": loss, "roofline": roof, "optimizer": opt_extra}

@@ -230,6 +230,17 @@ int sdxl_profile_gemm_begin(void);
  * + 4 * c forces configuration c (1, 2, 3 or 13) of the 128-row kernel. */
 int sdxl_set_gemm_mode(int mode);
 int sdxl_profile_gemm_end(double* flops, double* ms, int* launches);
+/* Persistent stream-K GEMM (csrc/gemm_sk.hip; 256 x 256 tiles, one workgroup per CU, the K-steps of ALL problems of a launch
+ * cut evenly over the CUs).  sdxl_set_sk_mode: mode 0 = never, 1 = the plan's policy (default), 2 = wherever a problem is
+ * applicable (M, N multiples of 256, K of 64); workers > 0 forces the worker count (microbenchmarks), 0 = policy.
+ * sdxl_sk_error: *out != 0 iff an owner workgroup ever gave up waiting for a partial tile on that stream (results invalid).
+ * sdxl_op_gemm_sk: n (<= 4) problems in ONE launch, arguments per problem as sdxl_op_gemm (form 2: bias[i] = fp32 bias
+ * gradient accumulator or NULL, C fp32); this is how the plan launches a layer's dgrad and wgrad together. */
+int sdxl_set_sk_mode(int mode, int workers);
+int sdxl_sk_error(void* stream, unsigned* out);
+int sdxl_op_gemm_sk(int n, const int* form, const void* const* A, const void* const* B, void* const* C, const int* M,
+                    const int* N, const int* K, const void* const* bias, const void* const* resid, const int* accumulate,
+                    void* stream);
 /* debug: checksum of every activation (grads != 0: of every activation gradient) of the current plan, in creation
  * order; synchronises the device.  n_out receives the number of activations. */
 int sdxl_debug_act_checksums(sdxl_handle* h, unsigned long long* out_host, int cap, int* n_out, int grads);

@@ -1,8 +1,10 @@
 # Everything profiles/ holds about the headline step at one commit, in one box (run through gpurun from the repo root):
-#   bash profiles/tools/measure_step.sh <tag>      -> gpurun_out/<tag>/{bench.json,kernel_stats.csv,kernel_stats_serialized.csv,
+#   bash profiles/tools/measure_step.sh <tag> <commit>   (commit = `git rev-parse --short HEAD` of the snapshot: stamped into
+#                                                          pmc_step_summary.json, bench.py refuses a stale one)  -> gpurun_out/<tag>/{bench.json,kernel_stats.csv,kernel_stats_serialized.csv,
 #                                                     timeline.txt,gemm_shapes.txt,pmc_step_summary.json}
 # PMC passes are separate rocprofv3 runs with --kernel-trace only (never combined with other trace domains).
-TAG=${1:-r02}
+TAG=${1:-r03}
+export SDXL_MEASURE_COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
@@ -24,14 +26,14 @@ for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" 
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc/$d -o p -- $B --steps 1 --warmup 1 2>&1 | tail -1 | cut -c1-100
 done
 cd $O/pmc && python - <<'PY'
-import csv, glob, collections, json
+import csv, glob, collections, json, os
 def fam(n):
-    if 'gemm_kernel' in n or 'gemm256_kernel' in n: return 'gemm'
+    if 'gemm_kernel' in n or 'gemm256_kernel' in n or 'gemm_sk_kernel' in n: return 'gemm'
     if 'attn_' in n: return 'attention'
     if 'splitk_reduce' in n: return 'splitk_reduce'
     if n.startswith('void at::') or 'at::native' in n or 'repack' in n or 'elementwise_kernel' in n or 'distribution' in n: return None
     return 'norm_elementwise_loss'
-out = {"workload": "ddpm_b4_1024", "note": "last step of `bench.py --steps 1 --warmup 1`; FETCH_SIZE / WRITE_SIZE are in KiB "
+out = {"workload": "ddpm_b4_1024", "commit": os.environ.get("SDXL_MEASURE_COMMIT", "unknown"), "note": "last step of `bench.py --steps 1 --warmup 1`; FETCH_SIZE / WRITE_SIZE are in KiB "
        "(hbm_bytes = FETCH_SIZE x 2 x 1024 [gfx950 correction] + WRITE_SIZE x 1024); kernels are serialised by the collection"}
 raw = {}
 for d in ['SQ_VALU_MFMA_BUSY_CYCLES', 'FETCH_SIZE', 'WRITE_SIZE']:

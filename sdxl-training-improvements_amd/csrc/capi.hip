@@ -535,6 +535,7 @@ int sdxl_small_grads_to_bf16(sdxl_handle* h, size_t off, size_t n, void* dst, fl
 int sdxl_set_grad_emit(sdxl_handle* h, void* bf16_arena, float scale) {
   H_CHECK(h);
   ARG_CHECK(((uintptr_t)bf16_arena & 15) == 0, "bf16 gradient arena must be 16-byte aligned");
+  if (h->e.emit_base != (bf16*)bf16_arena || h->e.emit_scale != scale) h->e.clear_graphs();   // captured wgrad launches hold the old target
   h->e.emit_base = (bf16*)bf16_arena;
   h->e.emit_scale = scale;
   return 0;
@@ -822,6 +823,36 @@ int sdxl_set_gemm_mode(int mode) {
   return 0;
 }
 int sdxl_profile_gemm_end(double* flops, double* ms, int* launches) { return gemm_profile_end(flops, ms, launches); }
+int sdxl_set_sk_mode(int mode, int workers) {
+  ARG_CHECK(mode >= 0 && mode <= 2 && workers >= 0 && workers <= 256, "stream-K mode %d / workers %d", mode, workers);
+  gemm_set_sk_mode(mode);
+  gemm_sk_set_workers(workers);
+  return 0;
+}
+int sdxl_sk_error(void* st, unsigned* out) {
+  ARG_CHECK(out, "null output");
+  return gemm_sk_error((hipStream_t)st, out);
+}
+int sdxl_op_gemm_sk(int n, const int* form, const void* const* A, const void* const* B, void* const* C, const int* M, const int* N,
+                    const int* K, const void* const* bias, const void* const* resid, const int* accumulate, void* st) {
+  ARG_CHECK(n >= 1 && n <= 4 && form && A && B && C && M && N && K, "gemm_sk: bad arguments");
+  GemmP g[4];
+  for (int i = 0; i < n; ++i) {
+    gemm_defaults(&g[i]);
+    g[i].form = form[i];
+    g[i].A = (const bf16*)A[i]; g[i].B = (const bf16*)B[i]; g[i].C = C[i];
+    g[i].M = M[i]; g[i].N = N[i]; g[i].K = K[i];
+    if (form[i] == GEMM_NT) { g[i].lda = K[i]; g[i].ldb = K[i]; }
+    else if (form[i] == GEMM_NN) { g[i].lda = K[i]; g[i].ldb = N[i]; }
+    else { g[i].lda = M[i]; g[i].ldb = N[i]; g[i].out_f32 = 1; }
+    g[i].ldc = N[i];
+    if (form[i] == GEMM_TN) g[i].bias_grad = bias ? (float*)bias[i] : nullptr;
+    else g[i].bias = bias ? (const bf16*)bias[i] : nullptr;
+    if (resid && resid[i]) { g[i].resid = (const bf16*)resid[i]; g[i].ldr = N[i]; }
+    g[i].accumulate = accumulate ? accumulate[i] : 0;
+  }
+  return launch_gemm_multi(g, n, (hipStream_t)st);
+}
 
 // debug: order-independent checksum (sum of raw 16-bit patterns) of every activation of the current plan, in
 // creation order.  Synchronises.  Used to localise run-to-run differences.

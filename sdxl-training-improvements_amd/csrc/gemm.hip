@@ -27,6 +27,7 @@
 
 static int g_mode256 = 1;     // 0: 128-row kernel only, 1: selection policy (gemm_use256), 2: 256 x 256 kernel wherever applicable
 static int g_force_cfg = 0;   // > 0: force that configuration of the 128-row kernel (microbenchmarks; sdxl_set_gemm_mode)
+static int g_sk_mode = 0;     // stream-K kernel (gemm_sk.hip): 0 never, 1 policy (gemm_use_sk), 2 wherever applicable
 
 static constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
 static constexpr int gemm_smem_bytes(int BN, int S, int BK, int NW = 4) {
@@ -1006,7 +1007,35 @@ int gemm_pick_group(int M, int N, int taps, long red, int splitk) {
   return g < 2 ? 1 : (g > GEMM_MAX_GROUP ? GEMM_MAX_GROUP : g);
 }
 void gemm_set_mode(int mode) { g_mode256 = mode & 3; g_force_cfg = mode >> 2; }
+void gemm_set_sk_mode(int mode) { g_sk_mode = mode; }
+int gemm_sk_mode() { return g_sk_mode; }
+// Policy of the stream-K kernel for a single problem (measured, profiles/r03*): where 256 x 256 tiles do not fill whole rounds
+// of 256 CUs -- few tiles with a long reduction (N = 1280 outputs at M = 4096: 80 tiles), or 2.5 rounds (the GEGLU projection).
+bool gemm_use_sk(const GemmP& p) {
+  if (!gemm_sk_applicable(p)) return false;
+  const long tiles = (long)(p.M / 256) * (p.N / 256), kt = p.K / 64;
+  if (tiles * kt < 1024) return false;                 // less than 4 K-steps per CU
+  return true;
+}
 static int launch_gemm_impl(const GemmP& pin, hipStream_t st);
+// several problems in ONE stream-K launch (a layer's dgrad + wgrad); every problem must satisfy gemm_sk_applicable
+int launch_gemm_multi(const GemmP* ps, int n, hipStream_t st) {
+  if (!g_prof.on) return launch_gemm_sk(ps, n, st);
+  while (g_prof.ev.size() < g_prof.used + 2) {
+    hipEvent_t e;
+    HIP_CHECK_RET(hipEventCreate(&e));
+    g_prof.ev.push_back(e);
+  }
+  HIP_CHECK_RET(hipEventRecord(g_prof.ev[g_prof.used], st));
+  int rc = launch_gemm_sk(ps, n, st);
+  HIP_CHECK_RET(hipEventRecord(g_prof.ev[g_prof.used + 1], st));
+  g_prof.used += 2;
+  double f = 0;
+  for (int i = 0; i < n; ++i) f += 2.0 * (double)ps[i].M * (double)ps[i].N * (double)ps[i].K;
+  g_prof.flops.push_back(f);
+  g_prof.recs.push_back({n > 1 ? 3 : ps[0].form, n, ps[0].M, ps[0].N, ps[0].K, 1});
+  return rc;
+}
 int launch_gemm(const GemmP& p, hipStream_t st) {
   if (!g_prof.on) return launch_gemm_impl(p, st);
   while (g_prof.ev.size() < g_prof.used + 2) {
@@ -1090,6 +1119,11 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
   }
   const bool conv = p.taps == 9;
   int rc;
+  if (g_sk_mode && !(p.form != GEMM_TN && p.splitk > 1) && (g_sk_mode == 2 ? gemm_sk_applicable(p) : gemm_use_sk(p))) {
+    GemmP q = p;
+    q.splitk = 1;
+    return launch_gemm_sk(&q, 1, st);      // persistent stream-K kernel (gemm_sk.hip)
+  }
   {   // 256 x 256 kernel (gemm256.hip)
     if (g_mode256 && p.group <= 1 && !p.Cb && !(p.form != GEMM_TN && p.splitk > 1) && gemm256_applicable(p)) {
       if (g_mode256 == 2 || gemm_use256(p.form, p.M, p.N, p.K, p.splitk)) {

@@ -85,6 +85,16 @@ bool gemm_use256(int form, int M, int N, int K, int splitk);   // the policy of 
 int gemm_pick_splitk(int M, int N, int taps, long red);        // split-K factor the wgrad launchers should request
 int gemm_pick_splitk_small(int M, int N, int K);               // split-K factor for NT / NN (bf16 output) launches of small problems
 int launch_gemm256(const GemmP& p, hipStream_t st);
+// persistent stream-K kernel (gemm_sk.hip): up to 4 problems (M, N multiples of 256, K of 64, no gather) in ONE launch, their
+// K-steps cut evenly over the CUs; partial tiles are handed to the tile's owner inside the launch (fixed order: reproducible)
+bool gemm_sk_applicable(const GemmP& p);
+int launch_gemm_sk(const GemmP* problems, int n, hipStream_t st);
+int launch_gemm_multi(const GemmP* problems, int n, hipStream_t st);   // = launch_gemm_sk + the per-launch profiling of launch_gemm
+void gemm_set_sk_mode(int mode);                      // 0 never / 1 policy (gemm_use_sk) / 2 wherever applicable
+int gemm_sk_mode();
+bool gemm_use_sk(const GemmP& p);
+void gemm_sk_set_workers(int n);                      // > 0: force the worker count (microbenchmarks), 0: policy
+int gemm_sk_error(hipStream_t st, unsigned* out);     // != 0: an owner gave up waiting for a partial tile (results invalid)
 // per-launch HIP-event timing of every GEMM launch between begin and end (end synchronises the device)
 int gemm_profile_begin();
 bool gemm_profiling();   // true between begin and end: the engine then runs everything on one stream (clean durations)

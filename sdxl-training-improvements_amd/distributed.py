@@ -136,7 +136,7 @@ class ShardedGradSync(GradSync):
             return
         if k == 0:
             self.begin()
-        if count % (8 * self.world):
+        if count % (8 * self.world):     # (make_grad_sync checks the segment sizes up front and falls back to GradSync)
             raise ValueError(f"bucket of {count} elements does not split into {self.world} slices of whole 16-byte vectors")
         n = count // self.world
         buf = self.comm[offset:offset + count]
@@ -161,13 +161,35 @@ class ShardedGradSync(GradSync):
 
     def gather_params(self, weights: torch.Tensor) -> None:
         """all-gather the updated slices back into every rank's full weight arena, bucket by bucket."""
+        self.gather_arena(weights)
+
+    def gather_arena(self, arena: torch.Tensor) -> None:
+        """all-gather this rank's slices of any arena-layout tensor (parameters after the sharded update; the optimizer's
+        exp_avg / exp_avg_sq / shift before a checkpoint, so that optimizer.pt holds every rank's state, not rank 0's stale copy)
+        into every rank's full copy, bucket by bucket (same buckets / slices as the exchange).  Collective: every rank calls it."""
         if self.world < 2:
             return
         works = []
         for (off, cnt), (poff, n, _g) in zip(self.buckets, self.pieces):
-            mine = weights[poff:poff + n].clone()       # (in-place all-gather is an RCCL feature, not a gloo one)
-            w = _via_host(dist.all_gather_into_tensor, weights[off:off + cnt], mine, group=self.group, async_op=True)
+            mine = arena[poff:poff + n].clone()         # (in-place all-gather is an RCCL feature, not a gloo one)
+            w = _via_host(dist.all_gather_into_tensor, arena[off:off + cnt], mine, group=self.group, async_op=True)
             if w is not None:
                 works.append(w)
         for w in works:
             w.wait()
+
+
+def make_grad_sync(total_elems: int, cast, comm_dtype=torch.bfloat16, device="cuda", sharded: bool = True,
+                   segment_sizes: Optional[List[int]] = None, group=None) -> GradSync:
+    """ShardedGradSync (ZeRO-1) where every backward segment splits into `world` slices of whole 16-byte vectors, else the
+    all-reduce GradSync.  Segments are multiples of 64 elements (the arena's alignment), so reduce-scatter works for world sizes
+    that divide 8 (2, 4, 8); any other world size (3, 5, 6, 7, 16 = 2 nodes x 8, ...) falls back to all-reduce + the full update
+    with a warning instead of failing at the first exchange."""
+    world = get_world_size()
+    if sharded and world > 1 and segment_sizes is not None and any(int(c) % (8 * world) for c in segment_sizes):
+        import warnings
+        warnings.warn(f"ZeRO-1 gradient exchange needs segment sizes divisible by 8 * world = {8 * world}; "
+                      f"falling back to all-reduce + unsharded optimizer update (world size {world})")
+        sharded = False
+    cls = ShardedGradSync if sharded else GradSync
+    return cls(total_elems, cast, comm_dtype, device, group)

@@ -60,5 +60,15 @@ class NativeMI355XTrainer(NativeSDXLTrainer):
         self.sync_to_model()
         if self.parent_trainer is not None and callable(getattr(self.parent_trainer, "save_checkpoint", None)) \
                 and not isinstance(epoch_or_path, (str, bytes)) and not hasattr(epoch_or_path, "__fspath__"):
-            return self.parent_trainer.save_checkpoint(epoch_or_path, is_final)      # ddpm_trainer.py:236-253
+            out = self.parent_trainer.save_checkpoint(epoch_or_path, is_final)       # ddpm_trainer.py:236-253
+            # the parent wrote ITS optimizer's state (the reference's torch AdamWBF16, which never stepped); the state that
+            # trained the weights is the fused optimizer's: replace optimizer.pt in the directory the parent used
+            # (sdxl_trainer.py:171-178: outputs/final_checkpoint or outputs/checkpoint-XXXX)
+            from pathlib import Path
+            save_dir = Path("outputs") / ("final_checkpoint" if is_final else f"checkpoint-{int(epoch_or_path):04d}")
+            if isinstance(out, (str, Path)):
+                save_dir = Path(out)
+            save_dir.mkdir(parents=True, exist_ok=True)
+            self.save_optimizer_state(save_dir)
+            return out
         return super().save_checkpoint(epoch_or_path, is_final)

@@ -102,14 +102,17 @@ class NativeSDXLTrainer:
             reference_ema=bool(getattr(self.config.optimizer, "reference_ema", True)))
         self._clip_coef = None
         # data parallel: ZeRO-1 (reduce-scatter, sharded fused AdamW, all-gather) with the fused optimizer, else all-reduce
-        self.sharded = bool(getattr(self.config.training, "shard_optimizer", True)) and isinstance(self.optimizer, AdamWBF16)
-        Sync = D.ShardedGradSync if self.sharded else D.GradSync
-        self.sync = Sync(self.net.param_elems, self._cast, torch.bfloat16, getattr(self.net, "device", "cpu"))
+        want_sharded = bool(getattr(self.config.training, "shard_optimizer", True)) and isinstance(self.optimizer, AdamWBF16)
+        seg_sizes = [n for _off, n in self.net.segment_ranges()] if hasattr(self.net, "segment_ranges") else None
+        self.sync = D.make_grad_sync(self.net.param_elems, self._cast, torch.bfloat16, getattr(self.net, "device", "cpu"),
+                                     sharded=want_sharded, segment_sizes=seg_sizes)
+        self.sharded = isinstance(self.sync, D.ShardedGradSync)      # (falls back to all-reduce where the segments do not split)
         self._emit = False                   # this backward's weight-gradient GEMMs write the bf16 exchange arena themselves
         self._micro = 0                      # micro-step index inside the accumulation cycle
         self._zeroed = False                 # gradients already zeroed for the cycle in progress
         self._anchor = torch.zeros((), requires_grad=True)
         self._exchange = True
+        self._final_known = False            # this backward is known to be the cycle's last micro-step (emit mode is safe)
         hook = getattr(self.optimizer, "register_step_post_hook", None)
         if callable(hook):                   # an optimizer step ends the accumulation cycle, whoever calls it
             hook(lambda *_a, **_k: self._end_cycle())
@@ -196,7 +199,12 @@ class NativeSDXLTrainer:
         self.sync.enabled = exchange
         # per-segment joins (side stream -> caller's stream) only on the micro-step that exchanges gradients
         if exchange:    # bucket casts + collectives ride the engine's side stream, behind the segment's weight gradients
-            self._emit = hasattr(self.net, "set_grad_emit") and self.sync.comm is not None
+            # emit mode (wgrad GEMMs write bf16 straight into the exchange arena, the fp32 arena is NOT written) is only correct
+            # on the LAST micro-step of a cycle: a later micro-step would add to an fp32 arena that never received this one.
+            # `_execute_training_step` knows that; a caller-owned `compute_loss(...)["loss"].backward()` loop with accumulation does
+            # not say which backward is the last, so every one of its micro-steps takes the fp32-accumulate + cast path.
+            final = self._final_known or self.gradient_accumulation_steps == 1
+            self._emit = final and hasattr(self.net, "set_grad_emit") and self.sync.comm is not None
             if self._emit:
                 self.net.set_grad_emit(self.sync.comm, 1.0)
             try:
@@ -216,9 +224,13 @@ class NativeSDXLTrainer:
             self.net.zero_grads()                                      # start of the cycle (D10 repair)
             self._zeroed = True
         self._exchange = (not accumulate) or is_last_accumulation_step
+        self._final_known = self._exchange
         out = self.compute_loss(batch, **kw)
         loss = out["loss"] / N if accumulate else out["loss"]
-        loss.backward()
+        try:
+            loss.backward()
+        finally:
+            self._final_known = False
         if self._exchange:
             self._end_cycle()
             self.sync.finish()
@@ -329,6 +341,9 @@ class NativeSDXLTrainer:
         directory instead of an epoch: accepted too); the model through `model.save_pretrained(dir, safe_serialization=True)`
         when the caller's model has it (weights synced back first), else the UNet as diffusers-keyed safetensors;
         `optimizer.pt` = optimizer.state_dict(); `config.json` = the training config."""
+        # ZeRO-1: each rank has updated exp_avg / exp_avg_sq / shift on its own slices only -- gather them (collective, every
+        # rank calls save_checkpoint) so that optimizer.pt holds the complete state, whichever rank writes it
+        self._gather_optimizer_state()
         if not D.is_main_process():
             return None
         if isinstance(epoch_or_path, (str, Path)):
@@ -353,9 +368,25 @@ class NativeSDXLTrainer:
             json.dump(self.config.to_dict(), f, indent=2)
         return save_dir
 
+    def _gather_optimizer_state(self) -> None:
+        if self.sharded and self.sync.world > 1 and isinstance(self.optimizer, AdamWBF16) and self.sync.buckets:
+            for arena in (self.optimizer.exp_avg, self.optimizer.exp_avg_sq, self.optimizer.shift):
+                self.sync.gather_arena(arena)
+
+    def save_optimizer_state(self, save_dir) -> None:
+        """optimizer.pt of the NATIVE fused optimizer (complete state under ZeRO-1: collective, every rank calls it)."""
+        self._gather_optimizer_state()
+        if not D.is_main_process() or self.optimizer is None or not callable(getattr(self.optimizer, "state_dict", None)):
+            return
+        osd = self.optimizer.state_dict()
+        if isinstance(osd.get("state"), dict):
+            osd["state"] = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in osd["state"].items()}
+        torch.save(osd, str(Path(save_dir) / "optimizer.pt"))
+
     def load_optimizer_state(self, checkpoint_dir) -> None:
-        """resume: optimizer.pt written by save_checkpoint (the UNet weights come back through the model object)."""
-        sd = torch.load(str(Path(checkpoint_dir) / "optimizer.pt"), map_location="cpu", weights_only=False)
+        """resume: optimizer.pt written by save_checkpoint (the UNet weights come back through the model object).  The state
+        holds tensors, numbers and dicts only, so the safe loader is enough."""
+        sd = torch.load(str(Path(checkpoint_dir) / "optimizer.pt"), map_location="cpu", weights_only=True)
         self.optimizer.load_state_dict(sd)
 
 

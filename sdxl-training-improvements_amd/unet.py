@@ -190,6 +190,10 @@ class NativeUNet:
         lib.check(self.L.sdxl_segment_range(self.h, k, C.byref(off), C.byref(n)))
         return off.value, n.value
 
+    def segment_ranges(self):
+        """[(offset, count)] of every backward segment, in exchange order."""
+        return [self.segment_range(k) for k in range(self.num_segments)]
+
     # ------------------------------------------------------------------ the step
     def zero_grads(self) -> None:
         lib.check(self.L.sdxl_zero_grads(self.h, _stream()))

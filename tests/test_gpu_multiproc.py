@@ -26,6 +26,25 @@ def test_two_ranks_one_device_gloo():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
     assert out["scaling"] == "weak" and out["value"] > 0 and out["steps"] == 1
     assert 0 < out["loss"] < 1000
+    ex = out["config"]["exchange"]                                  # the timed region holds a COMPLETE exchange (default: all-reduce)
+    assert "all-reduce" in ex["what"] and ex["exchange_bytes_timed"] == 2 * 2567486784 and ex["every_n_micro_steps"] == 1
+    st = out["step_time"]
+    assert st["n"] == 1 and 0 < st["min_ms"] <= st["median_ms"] <= st["max_ms"]
+
+
+def test_two_ranks_mixed_buckets_accum4_zero1_gloo():
+    """configs[4] as a bench workload: the two bucket plans alternate per micro-step, gradients are exchanged on every 4th
+    micro-step only; with --exchange zero1 the timed region holds reduce-scatter AND the parameter all-gather."""
+    env = dict(os.environ, SDXL_BENCH_BACKEND="gloo", SDXL_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29545", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "0", "--no-optimizer",
+           "--profile-steps", "0", "--workload", "flow_mixed_accum4", "--exchange", "zero1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    ex = out["config"]["exchange"]
+    assert ex["every_n_micro_steps"] == 4 and "all-gather" in ex["what"] and "reduce-scatter" in ex["what"]
+    assert out["step_time"]["n"] == 4 and out["value"] > 0 and 0 < out["loss"] < 1000
 
 
 def test_zero1_update_bit_equal_to_unsharded():
