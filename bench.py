@@ -185,6 +185,7 @@ def main():
     ap.add_argument("--no-emit", action="store_true", help="N > 1 A/B: cast the fp32 gradient arena per bucket instead of bf16 wgrad epilogues")
     ap.add_argument("--profile-steps", type=int, default=1, help="extra steps with per-launch GEMM event timing")
     ap.add_argument("--gemm-mode", type=int, default=None, help="A/B runs: sdxl_set_gemm_mode (0 = 128-row kernel only)")
+    ap.add_argument("--knob", action="append", default=[], help="A/B runs: id=value for sdxl_set_knob (repeatable)")
     ap.add_argument("--lib", default=None, help="A/B runs: another build of libsdxlstep.so (e.g. last round's) on the same box")
     args = ap.parse_args()
 
@@ -218,6 +219,9 @@ def main():
         lib.SIGNATURES = {k: v for k, v in lib.SIGNATURES.items() if hasattr(probe, k)}
     if args.gemm_mode is not None:
         lib.check(lib.load().sdxl_set_gemm_mode(args.gemm_mode))
+    for kv in args.knob:
+        kid, kval = kv.split("=")
+        lib.check(lib.load().sdxl_set_knob(int(kid), int(kval)))
     net = NU.NativeUNet(NU.make_config(), device=local_rank)
     synth.load_synthetic(net, seed=0)                      # same weights on every rank
     buckets = wl.get("buckets", [(wl["H"], wl["W"])])

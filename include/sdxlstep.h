@@ -236,6 +236,8 @@ int sdxl_profile_gemm_end(double* flops, double* ms, int* launches);
  * sdxl_sk_error: *out != 0 iff an owner workgroup ever gave up waiting for a partial tile on that stream (results invalid).
  * sdxl_op_gemm_sk: n (<= 4) problems in ONE launch, arguments per problem as sdxl_op_gemm (form 2: bias[i] = fp32 bias
  * gradient accumulator or NULL, C fp32); this is how the plan launches a layer's dgrad and wgrad together. */
+/* experiment knobs of the plan (A/B runs; defaults are the shipped policy): see csrc/kernels.h */
+int sdxl_set_knob(int id, int value);
 int sdxl_set_sk_mode(int mode, int workers);
 int sdxl_sk_error(void* stream, unsigned* out);
 int sdxl_op_gemm_sk(int n, const int* form, const void* const* A, const void* const* B, void* const* C, const int* M,

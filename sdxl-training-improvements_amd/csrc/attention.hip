@@ -198,8 +198,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
   for (int qb = 0; qb < 2; ++qb) { landed(qf[qb][0]); landed(qf[qb][1]); }
   int buf = 0;
   // one key tile; MASK: the tile holds keys beyond Nk (only the last tile of a ragged sequence)
-  auto tile = [&](int t, auto MASKC) {
+  // FIXED (t > 0 of the first pass): the reference stays where the first tile put it -- no per-tile maximum, no rescale test.
+  // bf16 / fp32 carry 8 exponent bits, so P up to 2^100 loses nothing; what can go wrong is overflow (a later score more than
+  // ~100 log2 units above the first tile's maximum), which shows in the row sums after the loop and sends the whole workgroup
+  // through a second pass with the tracking form (rare; attention knock-outs: the maximum / rescale logic was 13 % of the tile).
+  auto tile = [&](int t, auto MASKC, auto FIXEDC) {
     constexpr bool MASK = decltype(MASKC)::value;
+    constexpr bool FIXED = decltype(FIXEDC)::value;
     ATTN_STAMP(5)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my DMA pieces of tile t have landed ...
     ATTN_STAMP(0)
@@ -260,6 +265,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
     bf16x8 pf[2][2];  // [step t2][qb]
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
+      if (!FIXED) {
       float mx = -1e30f;
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
@@ -281,6 +287,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
         }
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) { st[kb][qb][0] -= shift; st[kb][qb][1] -= shift; st[kb][qb][2] -= shift; st[kb][qb][3] -= shift; }
+      }
       }
       f32x2 ls2 = (f32x2){0.f, 0.f};
 #pragma unroll
@@ -315,8 +322,30 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
   ts_prev = __builtin_amdgcn_s_memtime();
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();     // constant 100 MHz
 #endif
-  for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
-  if (nfull < ntiles) tile(nfull, std::true_type{});
+  // first pass: tile 0 sets the reference (tracking form), the others keep it
+  if (nfull > 0) tile(0, std::false_type{}, std::false_type{});
+  for (int t = 1; t < nfull; ++t) tile(t, std::false_type{}, std::true_type{});
+  if (nfull < ntiles) {
+    if (nfull == 0) tile(0, std::true_type{}, std::false_type{});
+    else tile(nfull, std::true_type{}, std::true_type{});
+  }
+  {
+    // overflow check (NaN-safe): every per-lane partial row sum must be a moderate finite number
+    const bool bad = !(lrow[0] < 1e30f) || !(lrow[1] < 1e30f);
+    if (__syncthreads_or(bad ? 1 : 0)) {       // second pass, tracking form everywhere (all waves: the tiles are shared)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ot[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      mrow[0] = mrow[1] = 0.f;
+      lrow[0] = lrow[1] = 0.f;
+      buf = 0;
+      tile_dma(ksrc, 0, p.Nk, sm, wave);
+      tile_dma(vsrc, 0, p.Nk, sm + TILE_ELEMS, wave);
+      for (int t = 0; t < nfull; ++t) tile(t, std::false_type{}, std::false_type{});
+      if (nfull < ntiles) tile(nfull, std::true_type{}, std::false_type{});
+    }
+  }
 #if defined(ATTN_DIAG) && (ATTN_DIAG & 128)
   acc_ph[4] = __builtin_amdgcn_s_memrealtime() - rt0;
   if (lane == 0 && blockIdx.x < 4 && blockIdx.y == 5)
@@ -359,6 +388,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
 // has 16 of the row's 64 d; two cross-lane steps finish the sum) and stored for the dK/dV kernel that follows.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
+  set_wave_prio(p.prio);
   __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE_ELEMS];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l16 = lane & 15, g = lane >> 4;
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
@@ -501,6 +531,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 // feeds two key blocks, halving the LDS traffic per MFMA), 1 for the split-query cross-attention form.
 template <int KB>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
+  set_wave_prio(p.prio);
   // ONE LDS object (a second one makes hipcc drain the LDS-DMA before every ds_read): Q0 dO0 Q1 dO1 | stats
   __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE_ELEMS + 512];
   float (*sstat)[2][64] = (float (*)[2][64])(sm + 4 * TILE_ELEMS);                                   // [buf][lse2|delta][q]

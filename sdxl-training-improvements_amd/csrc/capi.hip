@@ -823,6 +823,11 @@ int sdxl_set_gemm_mode(int mode) {
   return 0;
 }
 int sdxl_profile_gemm_end(double* flops, double* ms, int* launches) { return gemm_profile_end(flops, ms, launches); }
+int sdxl_set_knob(int id, int value) {
+  ARG_CHECK(id >= 0 && id < SDXL_NKNOBS, "knob %d out of range", id);
+  g_knobs[id] = value;
+  return 0;
+}
 int sdxl_set_sk_mode(int mode, int workers) {
   ARG_CHECK(mode >= 0 && mode <= 2 && workers >= 0 && workers <= 256, "stream-K mode %d / workers %d", mode, workers);
   gemm_set_sk_mode(mode);

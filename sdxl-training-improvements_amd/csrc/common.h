@@ -76,6 +76,12 @@ __device__ __forceinline__ void lds_dma16_buffer(i32x4 srd_uniform, unsigned vof
                : "=&s"(keep) : "v"(voffset), "s"(srd_uniform), "s"(soffset_uniform), "s"(lds_dst_uniform) : "memory");
 }
 
+// whole-kernel wave priority (the immediate must be a literal; `prio` is a kernel argument: wave-uniform)
+__device__ __forceinline__ void set_wave_prio(int prio) {
+  if (prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (prio == 3) __builtin_amdgcn_s_setprio(3);
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

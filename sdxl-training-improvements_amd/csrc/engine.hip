@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+int g_knobs[SDXL_NKNOBS] = {0};
 static thread_local char g_err[1024] = "";
 void sdxl_set_error(const char* fmt, ...) {
   va_list ap;
@@ -242,6 +243,7 @@ struct LinearOp : Op {
       if (gu) { g.geglu = 2; g.geglu_group = ggroup; g.aux = p.P(gu); g.ldaux = 2L * K; g.ldc = 2L * K; }
       else if (dx.addend != NONE) { g.resid = p.GP(dx.addend); g.ldr = K; }
       if (dsplit > 1) { g.splitk = dsplit; g.slab = p.F(p.slab_main_off); }
+      g.prio = g_knobs[0];
       CHK(launch_gemm(g, st));
     }
     return 0;
@@ -337,6 +339,7 @@ struct ConvOp : Op {
       g.flip = 1; g.b_tap_stride = Cin;
       if (dx.addend != NONE) { g.resid = p.GP(dx.addend); g.ldr = Cin; }
       if (dsplit > 1) { g.splitk = dsplit; g.slab = p.F(p.slab_main_off); }
+      g.prio = g_knobs[0];
       CHK(launch_gemm(g, st));
     }
     return 0;
@@ -460,6 +463,7 @@ struct AttnOp : Op {
     if (bad) { sdxl_set_error("attention: operand gradient has another writer"); return 3; }
     AttnP a;
     fill(p, a, true);
+    a.prio = g_knobs[1];
     if (self) return launch_attn_bwd(a, st);
     // cross attention: dK | dV (this block's slice of the grouped projection's gradient) is read by nothing before that
     // projection's weight gradient, a leaf on the side stream -- so the dK / dV kernel (+ its partial reduce) goes there too,

@@ -58,6 +58,7 @@ static constexpr int gemm_occupancy(int BN, int S, int BK, int NW) {
 template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW, bool KSP = false>
 __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_kernel(const GemmP pin) {
   GemmP p = pin;
+  set_wave_prio(pin.prio);
   if (FORM == GEMM_TN && pin.group > 1) {          // grouped launch: this workgroup's problem
     const int gi = blockIdx.z;
     p.A = pin.gA[gi]; p.B = pin.gB[gi]; p.C = pin.gC[gi]; p.bias_grad = pin.gbias_grad[gi]; p.Cb = pin.gCb[gi];

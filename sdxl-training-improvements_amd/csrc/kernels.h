@@ -4,6 +4,11 @@
 #pragma once
 #include "common.h"
 
+// experiment knobs (sdxl_set_knob; defaults = the shipped policy): 0 wave priority of the main-stream dgrad GEMMs in the backward,
+// 1 of the attention backward kernels, 2 of the LayerNorm / GroupNorm backward kernels
+#define SDXL_NKNOBS 16
+extern int g_knobs[SDXL_NKNOBS];
+
 // ------------------------------------------------------------------------------------------------
 // bf16 MFMA GEMM family (gemm.hip).  C[M,N] = sum_k A(m,k) * B(k,n), fp32 accumulate.
 //   NT: A [M][K] K-contiguous (optionally rows gathered from an image = implicit-GEMM conv),
@@ -64,6 +69,8 @@ struct GemmP {
   float* bias_grad;  // TN only, optional: bias_grad[m] += sum_k A(k, m)  (column sums of dY, computed on the matrix pipe
                      // by the n-tile-0 / tap-0 workgroups with an all-ones B fragment; fp32 atomics, 128 per workgroup)
   int xcd_px;      // set by the launcher: XCD grid width over n-tiles (0 = identity order)
+  int prio;        // wave priority (s_setprio 0..3) of the whole kernel: the backward's critical-path launches (dgrad chain, caller's
+                   // stream) outrank the co-resident weight-gradient workgroups of the side stream on every SIMD they share
   // grouped launch (TN, taps == 1, splitk == 1): `group` > 1 problems of one shape in one grid (blockIdx.z = problem i, which
   // uses gA[i], gB[i], gC[i], gbias_grad[i] in place of A, B, C, bias_grad).  Small weight gradients (1280 x 1280: 80 tiles)
   // fill the chip three at a time instead of each being cut into split-K slabs and reduced.
@@ -121,6 +128,7 @@ struct AttnP {
   // kernel fills the chip; each split writes fp32 partials to `part` and a reduce kernel sums them (fixed order)
   int qsplit;
   float* part;         // qsplit * B*H * kvtiles*64 * 64 * 2 floats
+  int prio;            // wave priority of the backward kernels (see GemmP::prio)
 };
 size_t attn_part_floats(int B, int H, int Nk, int qsplit);
 int attn_pick_qsplit(int B, int H, int Nq, int Nk);

@@ -99,6 +99,7 @@ SIGNATURES = {
     "sdxl_set_gemm_mode": [_i],
     "sdxl_profile_gemm_end": [_P(C.c_double), _P(C.c_double), _P(_i)],
     "sdxl_debug_act_checksums": [_vp, _P(C.c_ulonglong), _i, _P(_i), _i],
+    "sdxl_set_knob": [_i, _i],
     "sdxl_set_sk_mode": [_i, _i],
     "sdxl_sk_error": [_vp, _P(C.c_uint)],
     "sdxl_op_gemm_sk": [_i, _P(_i), _P(_vp), _P(_vp), _P(_vp), _P(_i), _P(_i), _P(_i), _P(_vp), _P(_vp), _P(_i), _vp],

@@ -344,6 +344,32 @@ def test_attention_rescale_branch(L):
     report("attn fwd spike", o, ref, 8e-3)
 
 
+@pytest.mark.parametrize("F,Nk", [(150.0, 256), (150.0, 250), (150.0, 4096), (60.0, 4096)])
+def test_attention_fixed_reference_overflow_fallback(L, F, Nk):
+    """The forward keeps the first key tile's maximum as the softmax reference for the whole row and checks the row sums for
+    overflow afterwards.  One query gets a score 1.44 * F log2 units above everything else in a LATE key tile: F = 150 (216
+    units: exp2 overflows) must send its workgroup through the tracking second pass, F = 60 (86 units, P ~ 2^86) must come out
+    right without it.  The spike lives on one coordinate that every other query has zeroed, so no other row sees it (a large
+    score on many rows would only measure the bf16 rounding of the prescaled operand).  Output and LSE of every row against fp32
+    softmax; LSE tolerance 4e-3 of max|LSE|: the dominant score itself carries one bf16 rounding of q * scale * log2 e."""
+    B, heads, Nq, Cc = 1, 2, 256, 128
+    q, k, v = rnd(B, Nq, Cc, seed=33), rnd(B, Nk, Cc, seed=34), rnd(B, Nk, Cc, seed=35)
+    for (h, qi, ki) in ((0, 5, Nk - 3), (1, 200, Nk - 70)):      # (head, query, key): workgroup 0 / last tile, workgroup 1 / earlier tile
+        c0 = 64 * h
+        q[0, :, c0] = 0.0
+        q[0, qi, c0] = 8.0
+        k[0, ki, c0:c0 + 64] = 0.0
+        k[0, ki, c0] = F
+    o = torch.empty(B, Nq, Cc, dtype=torch.bfloat16, device=dev())
+    lse = torch.empty(B * heads, Nq, dtype=torch.float32, device=dev())
+    lib.check(L.sdxl_op_attention_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), B, heads, Nq, Nk, Cc, Cc, Cc, Cc, stream()))
+    ref, lse_ref = _attn_ref(q.float(), k.float(), v.float(), heads)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    report(f"attn fwd overflow F={F} Nk={Nk}", o, ref, 8e-3)
+    report("attn lse overflow", lse.view(B, heads, Nq), lse_ref, 4e-3)
+    assert float((o[0, 5, :64].float() - v[0, Nk - 3, :64].float()).abs().max()) <= 2e-2 * float(v[0, Nk - 3, :64].float().abs().max()) + 1e-3
+
+
 @pytest.mark.parametrize("B,HW,Cc,silu", [(2, 64, 64, 1), (2, 256, 320, 1), (1, 1024, 960, 1), (2, 144, 1280, 0),
                                           (2, 64, 192, 1), (1, 64, 2560, 1)])
 def test_groupnorm_fwd_bwd(L, B, HW, Cc, silu):
