@@ -197,7 +197,12 @@ struct LinearOp : Op {
     wgroup = gemm_pick_group(N, K, 1, x->rows, splitk);
     want_slab(p, N, K, 1, splitk);
     if (!gact) { fsplit = gemm_pick_splitk_small((int)x->rows, N, K); want_slab_main(p, (int)x->rows, N, fsplit); }
-    if (!gu && x->need_grad) { dsplit = gemm_pick_splitk_small((int)x->rows, K, N); want_slab_main(p, (int)x->rows, K, dsplit); }
+    if (!gu && x->need_grad) {
+      dsplit = gemm_pick_splitk_small((int)x->rows, K, N);
+      // knob 3 (experiment): split the reduction of the long-K dgrads (N >= knob 4) s ways although their tiles fill half the chip
+      if (g_knobs[3] > 1 && N >= (g_knobs[4] > 0 ? g_knobs[4] : 8192) && N % (64 * g_knobs[3]) == 0 && dsplit == 1) dsplit = g_knobs[3];
+      want_slab_main(p, (int)x->rows, K, dsplit);
+    }
   }
   int bwd(Plan& p, hipStream_t st, bool first) override {
     const bf16* dy = p.GP(dy_off);
@@ -693,8 +698,10 @@ struct Builder {
     Act* l3 = layernorm(b + ".norm3", x2, C);
     // feed-forward: GEGLU lives in the epilogues of the two projections (forward: value * gelu(gate) next to u;
     // backward: the second projection's dgrad writes dU directly), no separate activation pass
-    // packing group 80 (160-column tiles: fewer operand bytes per flop, fuller rounds) where 4C divides, else 64
-    const int group = (4 * C) % 80 == 0 ? 80 : 64;
+    // packing group 64: the forward projection then runs on the 256 x 256 kernel, whose register epilogue has value and gate of
+    // a channel in one lane (131 vs 156 us at level 2: the 128-row kernel stages the fp32 tile through LDS, two barriers per 64
+    // rows); the backward's dgrad epilogue takes any group.  (knob 5 = 80: round 2's packing for 160-column tiles, A/B runs)
+    const int group = (g_knobs[5] == 80 && (4 * C) % 80 == 0) ? 80 : 64;
     LinearOp *ff1 = nullptr, *ff2 = nullptr;
     Act* u = linear(b + ".ff.net.0.proj", l3, C, 8 * C, true, nullptr, false, 2, &ff1, group);
     Act* g = pl ? pl->new_act(x->rows, 4 * C) : nullptr;

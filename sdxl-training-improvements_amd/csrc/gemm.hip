@@ -733,12 +733,13 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
           *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + na) = oa;
           *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + nt) = ot;
           *(bf16x8*)(p.aux + (long)m * p.ldaux + (n0 >> 1) + col) = og;
-        } else {                        // dgrad of the second projection: dG tile -> dU (value and gate halves)
-          const int n = n0 + col;
-          if (n >= p.N) continue;
-          const long cu = (long)(n / G) * (2 * G) + (n % G);
+        } else {                        // dgrad of the second projection: dG tile -> dU (value and gate halves); any packing group
+          const int n = n0 + col;       // (rows are read and written in whole 16-byte vectors along the row: coalesced, which the
+          if (n >= p.N) continue;       //  register epilogue's 64-byte pieces per row are not -- measured 81 vs 75 us at level 2)
+          const int Gp = p.geglu_group;
+          const long cu = (long)(n / Gp) * (2 * Gp) + (n % Gp);
           bf16x8 ua = *(const bf16x8*)(p.aux + (long)m * p.ldaux + cu);
-          bf16x8 ut = *(const bf16x8*)(p.aux + (long)m * p.ldaux + cu + G);
+          bf16x8 ut = *(const bf16x8*)(p.aux + (long)m * p.ldaux + cu + Gp);
           bf16x8 oa, ot;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
             ot[e] = (bf16)(dv * (float)ua[e] * fmaf(tv, pdf, cdf));
           }
           *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + cu) = oa;
-          *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + cu + G) = ot;
+          *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + cu + Gp) = ot;
         }
       }
     }
@@ -865,8 +866,8 @@ static int launch_one(const GemmP& p, hipStream_t st) {
   // 128x128 (1.25 rounds, 62 % of the slots used) but exactly 512 tiles of 128x160.
   const long zmul = FORM == GEMM_TN ? p.taps * p.splitk : 1;
   const long blocks = (long)cdiv(p.M, BM) * cdiv(p.N, 128) * zmul;
-  const bool g80 = p.geglu && p.geglu_group == 80;        // packed for 160-column tiles: must run in a BN = 160 configuration
-  const bool n160 = p.N % 160 == 0 && (!p.geglu || g80);
+  const bool g80 = p.geglu == 1 && p.geglu_group == 80;   // forward GEGLU packed for 160-column tiles: must run in a BN = 160 configuration
+  const bool n160 = p.N % 160 == 0 && (p.geglu != 1 || g80);
   const long t160 = n160 ? (long)cdiv(p.M, BM) * (p.N / 160) * zmul : 0;
   auto fill = [](long t) { const long cap = 512; return (double)t / (double)(((t + cap - 1) / cap) * cap); };
   // the transpose-read forms (dgrad) spend twice the LDS-read issue slots per K-step: the BK = 32 variant with 3-4
@@ -889,11 +890,11 @@ static int launch_one(const GemmP& p, hipStream_t st) {
   if (FORM == GEMM_NT && n160 && t160 <= 256 && (long)p.K * p.taps >= 2560) cfg = 23;
   if (g_force_cfg > 0) cfg = g_force_cfg;
   if (FORM != GEMM_TN && p.splitk > 1) cfg = n160 ? 13 : 1;     // split-K of the bf16-output forms: the 4-wave FAST configurations
-  if (p.geglu && !g80 && (cfg == 3 || cfg == 13 || cfg == 23)) cfg = 1;   // group-64 packing needs 128-column tiles
+  if (p.geglu == 1 && !g80 && (cfg == 3 || cfg == 13 || cfg == 23)) cfg = 1;   // forward, group-64 packing: 128-column tiles
   if (g80 && cfg != 3 && cfg != 13 && cfg != 23) cfg = 13;                 // group-80 packing needs 160-column tiles
   if ((cfg == 3 || cfg == 13 || cfg == 23) && p.N % 160 != 0) cfg = 1;
   if (cfg == 23 && FORM == GEMM_TN) cfg = 13;
-  if (p.geglu && cfg == 2) cfg = 1;                           // the BK = 32 configuration has no room for the GEGLU staging tile
+  if (p.geglu == 1 && cfg == 2) cfg = 1;                      // the BK = 32 configuration has no room for the GEGLU staging tile
   switch (cfg) {
     case 2: return launch_cfg<FORM, CONV, 128, 2, 32, 4>(p, st);
     case 3: return launch_cfg<FORM, CONV, 160, 4, 64, 8>(p, st);
@@ -1075,7 +1076,7 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
     if (p.accumulate) { p.resid = (const bf16*)p.C; p.ldr = p.ldc; }
     if (p.geglu) {
       if (p.geglu_group == 0) p.geglu_group = 64;
-      ARG_CHECK(p.geglu_group == 64 || p.geglu_group == 80, "gemm: geglu group %d (64 or 80)", p.geglu_group);
+      ARG_CHECK(p.geglu == 2 ? p.geglu_group % 8 == 0 : (p.geglu_group == 64 || p.geglu_group == 80), "gemm: geglu group %d (forward: 64 or 80)", p.geglu_group);
       const int G = p.geglu_group;
       ARG_CHECK((p.geglu == 1 && p.form == GEMM_NT && p.N % (2 * G) == 0) || (p.geglu == 2 && p.form == GEMM_NN && p.N % G == 0),
                 "gemm: geglu mode %d does not fit form %d / N=%d / group %d", p.geglu, p.form, p.N, G);
@@ -1127,7 +1128,11 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
   }
   {   // 256 x 256 kernel (gemm256.hip)
     if (g_mode256 && p.group <= 1 && !p.Cb && !(p.form != GEMM_TN && p.splitk > 1) && gemm256_applicable(p)) {
-      if (g_mode256 == 2 || gemm_use256(p.form, p.M, p.N, p.K, p.splitk)) {
+      // the forward GEGLU projection packed in groups of 64: the 256 x 256 kernel's register epilogue (value and gate of a channel
+      // in one lane) against the 128-row kernel's LDS-staged one -- 131 vs 156 us at 4096 x 10240 x 1280 although its 640 tiles
+      // fill only 2.5 rounds (profiles/r03_notes)
+      const bool geglu256 = p.geglu == 1 && p.geglu_group == 64 && (long)(p.M / 256) * (p.N / 256) >= 256;
+      if (g_mode256 == 2 || gemm_use256(p.form, p.M, p.N, p.K, p.splitk) || geglu256) {
         rc = launch_gemm256(p, st);
         if (rc == 0 && p.splitk > 1) {
           const long nv = (long)p.M * (p.N / 4);
