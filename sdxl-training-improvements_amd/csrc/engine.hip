@@ -84,6 +84,8 @@ template <class F>
 static int on_side(Plan& p, hipStream_t main, F&& fn) {
   Engine& e = *p.eng;
   if (!e.use_side || !e.side || gemm_profiling()) return fn(main);
+  // (Timing experiment, r03: WITHOUT the fork event -- wrong results, the side stream free to run ahead -- the step takes 124.8 ms
+  //  instead of 116.8: the event is also what pairs each weight-gradient GEMM with the dgrad of its own layer on the CUs.)
   hipEvent_t ev = e.next_event();
   if (!ev) { sdxl_set_error("hipEventCreate failed"); return 2; }
   HIP_CHECK_RET(hipEventRecord(ev, main));
@@ -249,6 +251,7 @@ struct LinearOp : Op {
       else if (dx.addend != NONE) { g.resid = p.GP(dx.addend); g.ldr = K; }
       if (dsplit > 1) { g.splitk = dsplit; g.slab = p.F(p.slab_main_off); }
       g.prio = g_knobs[0];
+      if (g_knobs[6] > 0 && !gu && (g_knobs[8] <= 0 || N >= g_knobs[8])) g.cfg = g_knobs[6];     // experiment: configuration of the linear dgrads
       CHK(launch_gemm(g, st));
     }
     return 0;
@@ -345,6 +348,7 @@ struct ConvOp : Op {
       if (dx.addend != NONE) { g.resid = p.GP(dx.addend); g.ldr = Cin; }
       if (dsplit > 1) { g.splitk = dsplit; g.slab = p.F(p.slab_main_off); }
       g.prio = g_knobs[0];
+      if (g_knobs[7] > 0) g.cfg = g_knobs[7];     // experiment: configuration of the conv dgrads
       CHK(launch_gemm(g, st));
     }
     return 0;

@@ -888,6 +888,7 @@ static int launch_one(const GemmP& p, hipStream_t st) {
   // (forward only: in the backward a 145 KiB workgroup evicts the other stream from its CU -- dgrads on it: GEMM family
   //  -2 ms, step +2.4 ms, profiles/r02c)
   if (FORM == GEMM_NT && n160 && t160 <= 256 && (long)p.K * p.taps >= 2560) cfg = 23;
+  if (p.cfg > 0) cfg = p.cfg;
   if (g_force_cfg > 0) cfg = g_force_cfg;
   if (FORM != GEMM_TN && p.splitk > 1) cfg = n160 ? 13 : 1;     // split-K of the bf16-output forms: the 4-wave FAST configurations
   if (p.geglu == 1 && !g80 && (cfg == 3 || cfg == 13 || cfg == 23)) cfg = 1;   // forward, group-64 packing: 128-column tiles

@@ -69,6 +69,7 @@ struct GemmP {
   float* bias_grad;  // TN only, optional: bias_grad[m] += sum_k A(k, m)  (column sums of dY, computed on the matrix pipe
                      // by the n-tile-0 / tap-0 workgroups with an all-ones B fragment; fp32 atomics, 128 per workgroup)
   int xcd_px;      // set by the launcher: XCD grid width over n-tiles (0 = identity order)
+  int cfg;         // > 0: this launch's configuration of the 128-row kernel (1, 2, 3, 13, 23), overriding the selection policy
   int prio;        // wave priority (s_setprio 0..3) of the whole kernel: the backward's critical-path launches (dgrad chain, caller's
                    // stream) outrank the co-resident weight-gradient workgroups of the side stream on every SIMD they share
   // grouped launch (TN, taps == 1, splitk == 1): `group` > 1 problems of one shape in one grid (blockIdx.z = problem i, which
