@@ -133,6 +133,68 @@ def test_gemm_tn_wgrad(L, M, N, K, splitk):
         report("gemm_tn overwrite", out, ref, 2e-5 * math.sqrt(K) + 1e-5)
 
 
+def _sk_launch(L, probs, workers):
+    """probs: [(form, a, b, out, bias, resid, accumulate)] -> one stream-K launch (sdxl_op_gemm_sk)"""
+    n = len(probs)
+    I, V = C.c_int * n, C.c_void_p * n
+    p = lambda t: t.data_ptr() if t is not None else None
+    shape = lambda f, a, b: (a.shape[0], b.shape[0], a.shape[1]) if f == 0 else ((a.shape[0], b.shape[1], a.shape[1]) if f == 1 else (a.shape[1], b.shape[1], a.shape[0]))
+    dims = [shape(q[0], q[1], q[2]) for q in probs]
+    lib.check(L.sdxl_set_sk_mode(0, workers))
+    try:
+        lib.check(L.sdxl_op_gemm_sk(n, I(*[q[0] for q in probs]), V(*[p(q[1]) for q in probs]), V(*[p(q[2]) for q in probs]),
+                                    V(*[p(q[3]) for q in probs]), I(*[d[0] for d in dims]), I(*[d[1] for d in dims]), I(*[d[2] for d in dims]),
+                                    V(*[p(q[4]) for q in probs]), V(*[p(q[5]) for q in probs]), I(*[int(q[6]) for q in probs]), stream()))
+    finally:
+        lib.check(L.sdxl_set_sk_mode(0, 0))
+    torch.cuda.synchronize()
+    e = C.c_uint(0)
+    lib.check(L.sdxl_sk_error(stream(), C.byref(e)))
+    assert e.value == 0, f"stream-K hand-off gave up waiting (error word {e.value})"
+
+
+@pytest.mark.parametrize("workers", [1, 7, 37, 100, 255, 256, 0])
+def test_gemm_stream_k_forms_and_partitions(L, workers):
+    """Persistent stream-K kernel (gemm_sk.hip): every form, with partitions that cut tiles into two, three and many pieces
+    (worker counts that do not divide the iteration count), bias / residual / accumulate epilogues, bias gradient of the TN form."""
+    M, N, K = 512, 768, 640
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
+    _sk_launch(L, [(0, a, w, out, bias, res, 0)], workers)
+    report(f"sk nt w={workers}", out, a.float() @ w.float().t() + bias.float() + res.float(), 6e-3)
+    wn = rnd(K, N, seed=6, scale=K ** -0.5)
+    out2 = res.clone()
+    _sk_launch(L, [(1, a, wn, out2, None, None, 1)], workers)
+    report(f"sk nn+= w={workers}", out2, a.float() @ wn.float() + res.float(), 6e-3)
+    Kr = 2048
+    dy, x = rnd(Kr, 512, seed=8), rnd(Kr, 256, seed=9)
+    dw = torch.zeros(512, 256, dtype=torch.float32, device=dev())
+    db = torch.zeros(512, dtype=torch.float32, device=dev())
+    _sk_launch(L, [(2, dy, x, dw, db, None, 0)], workers)
+    report(f"sk tn w={workers}", dw, dy.float().t() @ x.float(), 2e-5 * math.sqrt(Kr) + 1e-5)
+    report("sk tn bias grad", db, dy.float().sum(0), 1e-4)
+
+
+def test_gemm_stream_k_fused_dgrad_wgrad_is_reproducible(L):
+    """A layer's dgrad (NN) and wgrad (TN) in ONE launch, as the work list is meant to be used; the partition is a function of the
+    shapes only, the partials are added in worker order: repeated launches give identical bits."""
+    M, Cin, Cout = 1024, 1280, 2560
+    dy, w, x = rnd(M, Cout, seed=11), rnd(Cout, Cin, seed=12, scale=Cout ** -0.5), rnd(M, Cin, seed=13)
+    dx = torch.zeros(M, Cin, dtype=torch.bfloat16, device=dev())
+    dw = torch.zeros(Cout, Cin, dtype=torch.float32, device=dev())
+    db = torch.zeros(Cout, dtype=torch.float32, device=dev())
+    probs = [(1, dy, w, dx, None, None, 0), (2, dy, x, dw, db, None, 0)]
+    _sk_launch(L, probs, 256)
+    report("sk fused dgrad", dx, dy.float() @ w.float(), 6e-3)
+    report("sk fused wgrad", dw, dy.float().t() @ x.float(), 2e-5 * math.sqrt(M) + 1e-5)
+    first = (dx.clone(), dw.clone())
+    for _ in range(10):
+        dx.fill_(3.0); dw.fill_(3.0)
+        _sk_launch(L, probs, 256)
+        assert torch.equal(dx, first[0]) and torch.equal(dw, first[1])
+
+
 @pytest.fixture
 def g256(L):
     """force the 256 x 256 / 8-phase kernel (gemm256.hip) wherever it is applicable, restore the default policy after"""
