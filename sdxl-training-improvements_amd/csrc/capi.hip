@@ -713,6 +713,11 @@ int sdxl_op_layernorm_bwd(const void* x, const void* dy, const void* gamma, cons
     return launch_layernorm_bwd((const bf16*)x, (const bf16*)dy, (const bf16*)gamma, stats, (bf16*)dx,
                                 accumulate ? (const bf16*)dx : nullptr, nullptr, nullptr, M, C, (hipStream_t)st);
   ARG_CHECK(dbeta, "layernorm bwd: dgamma and dbeta go together");
+  if (g_knobs[10] != 2) {     // the plan's default: lean dx kernel + parameter gradients as a pass of their own
+    CHK(launch_layernorm_bwd((const bf16*)x, (const bf16*)dy, (const bf16*)gamma, stats, (bf16*)dx,
+                             accumulate ? (const bf16*)dx : nullptr, nullptr, nullptr, M, C, (hipStream_t)st));
+    return launch_layernorm_param_grads((const bf16*)x, (const bf16*)dy, stats, dgamma, dbeta, M, C, (hipStream_t)st);
+  }
   LnRedBatch b;
   b.n = 1;
   float* part;

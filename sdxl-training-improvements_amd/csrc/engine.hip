@@ -402,6 +402,16 @@ struct LayerNormOp : Op {
   int bwd(Plan& p, hipStream_t st, bool) override {
     // dx and the per-block dgamma | dbeta partial sums in one pass (norm.hip); the partials of all LayerNorms of the segment
     // are folded into the gradients by one launch at its end (Engine::flush_ln_params)
+    // Default: the lean dx kernel (120 VGPRs, no LDS: two blocks per CU beside a wgrad workgroup) on the caller's stream, dgamma /
+    // dbeta as a leaf pass of their own on the side stream (re-reads x, dy: 21 MB, from L2 / MALL) -- step -0.7 ms against the fused
+    // form (dx + per-block parameter partial sums in one pass: 180 VGPRs + 40 KiB LDS, one block per CU when co-running;
+    // knob 10 = 2 selects it, A/B runs).  Round 2 measured the two forms equal; since then the main stream became the critical one.
+    if (g_knobs[10] != 2) {
+      CHK(launch_layernorm_bwd(p.P(x), p.GP(dy_off), p.eng->Wp(gm), p.F(stats_off), p.GP(dx.out), p.GP(dx.addend), nullptr, nullptr, (int)x->rows, C, st));
+      const bf16* xp = p.P(x); const bf16* dyp = p.GP(dy_off); const float* sp = p.F(stats_off);
+      float* dg = p.eng->Gp(gm); float* db = p.eng->Gp(bt); const int Mr = (int)x->rows, Cc = C;
+      return on_side(p, st, [=](hipStream_t s2) -> int { return launch_layernorm_param_grads(xp, dyp, sp, dg, db, Mr, Cc, s2); });
+    }
     LnRedEntry r;
     r.part = p.F(part_off); r.dgamma = p.eng->Gp(gm); r.dbeta = p.eng->Gp(bt); r.C = C;
     CHK(launch_layernorm_bwd(p.P(x), p.GP(dy_off), p.eng->Wp(gm), p.F(stats_off), p.GP(dx.out), p.GP(dx.addend),

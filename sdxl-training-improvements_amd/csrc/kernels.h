@@ -160,6 +160,7 @@ int launch_layernorm_fwd(const bf16* x, bf16* y, const bf16* gamma, const bf16* 
 size_t layernorm_bwd_part_floats(int M, int C);
 int launch_layernorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const float* stats, bf16* dx,
                          const bf16* addend, float* part, int* nblk_out, int M, int C, hipStream_t st);
+int launch_layernorm_param_grads(const bf16* x, const bf16* dy, const float* stats, float* dgamma, float* dbeta, int M, int C, hipStream_t st);
 #define LN_RED_MAX 64
 struct LnRedEntry { const float* part; float* dgamma; float* dbeta; int nblk, C; };
 struct LnRedBatch { LnRedEntry e[LN_RED_MAX]; int n; };   // passed by value as the kernel argument (2 KiB)

@@ -500,6 +500,59 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16* __restrict__
   }
 }
 
+// The critical path's lean form of the dx pass (no parameter sums, no LDS): the packed row stays in registers (8 NV VGPRs for x
+// and dy), everything else is transient and the per-vector steps are fenced so that hipcc does not hoist all of their operand
+// loads -- ~90 VGPRs instead of 166, so that two or three blocks fit on a CU beside a weight-gradient workgroup of the side
+// stream (224 VGPRs, 73 KiB LDS) where the fused form (180 VGPRs + 40 KiB) fits once.
+template <int NV, int LPR, bool ACC>
+__global__ __launch_bounds__(256) void ln_bwd_lean_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                   const bf16* __restrict__ gamma, const float* __restrict__ stats,
+                                   bf16* dx, const bf16* addend, int M) {
+  constexpr int C = NV * LPR * 8;
+  const int sub = threadIdx.x & (LPR - 1);
+  const int row = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+  const bool ok = row < M;                      // (rows beyond M: zeros; the wave stays converged for the shuffles)
+  const long ro = ok ? (long)row * C : 0;
+  const float mean = ok ? stats[(long)row * 2] : 0.f, rstd = ok ? stats[(long)row * 2 + 1] : 0.f;
+  bf16x8 v[NV], d[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = *(const bf16x8*)(x + ro + (i * LPR + sub) * 8);
+    d[i] = *(const bf16x8*)(dy + ro + (i * LPR + sub) * 8);
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const bf16x8 gv = *(const bf16x8*)(gamma + (i * LPR + sub) * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float h = ((float)v[i][e] - mean) * rstd;
+      const float t = ok ? (float)d[i][e] * (float)gv[e] : 0.f;
+      s1 += t;
+      s2 += t * h;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  s1 = group_sum<LPR>(s1) * (1.f / C);
+  s2 = group_sum<LPR>(s2) * (1.f / C);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const bf16x8 gv = *(const bf16x8*)(gamma + (i * LPR + sub) * 8);
+    bf16x8 o;
+    if (ACC) o = *(const bf16x8*)(addend + ro + (i * LPR + sub) * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float h = ((float)v[i][e] - mean) * rstd;
+      const float t = (float)d[i][e] * (float)gv[e];
+      float g = rstd * (t - s1 - h * s2);
+      if (ACC) g += (float)o[e];
+      o[e] = (bf16)g;
+    }
+    if (ok) *(bf16x8*)(dx + ro + (i * LPR + sub) * 8) = o;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // dgamma / dbeta += the block partials of up to LN_RED_MAX LayerNorm backward launches.  grid (column chunk of 256 over
 // [dgamma | dbeta], row chunk, entry): a thread sums its chunk of partials of one column and adds the result with one atomic.
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const LnRedBatch b) {
@@ -602,7 +655,10 @@ int launch_layernorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const
   dim3 blk(256), grid(nblk);
 #define LN_LAUNCH(NV, LPR)                                                                                               \
   {                                                                                                                      \
-    if (params) {                                                                                                        \
+    if (!params && g_knobs[11] != 1) {                                                                                  \
+      if (accumulate) hipLaunchKernelGGL((ln_bwd_lean_kernel<NV, LPR, true>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, M);  \
+      else hipLaunchKernelGGL((ln_bwd_lean_kernel<NV, LPR, false>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, M);            \
+    } else if (params) {                                                                                                        \
       if (accumulate) hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, LPR, true, true>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, part, M, iters); \
       else hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, LPR, false, true>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, part, M, iters);          \
     } else {                                                                                                             \
@@ -644,6 +700,15 @@ int launch_ln_param_reduce(const LnRedBatch& b, hipStream_t st) {
   return 0;
 }
 
+// dgamma[c] += sum_m dy[m][c] * xhat[m][c], dbeta[c] += sum_m dy[m][c] as a pass of its own (re-reads x, dy: a leaf, for the side stream)
+int launch_layernorm_param_grads(const bf16* x, const bf16* dy, const float* stats, float* dgamma, float* dbeta, int M, int C, hipStream_t st) {
+  ARG_CHECK(C % 8 == 0, "layernorm param grads: C=%d must be a multiple of 8", C);
+  dim3 g2; int rpc;
+  col_reduce_geom(M, C, &g2, &rpc);
+  hipLaunchKernelGGL(col_reduce_kernel, g2, dim3(256), 0, st, x, dy, (long)C, stats, dgamma, dbeta, M, C, rpc, 0L, 0L);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
 int launch_colsum_f32(const bf16* x, float* out, int M, int N, long ldx, hipStream_t st) {
   ARG_CHECK(N % 8 == 0 && ldx % 8 == 0, "colsum: N=%d ld=%ld must be multiples of 8", N, ldx);
   dim3 g2; int rpc;

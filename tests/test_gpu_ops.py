@@ -489,10 +489,20 @@ def test_layernorm_fwd_bwd(L, M, Cc):
     dx = torch.empty_like(x)
     dg = torch.zeros(Cc, dtype=torch.float32, device=dev())
     db = torch.zeros(Cc, dtype=torch.float32, device=dev())
-    lib.check(L.sdxl_op_layernorm_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(stats), ptr(dx), ptr(dg), ptr(db), M, Cc, 0, stream()))
-    report("layernorm dx", dx, xr.grad, 1e-2)
-    report("layernorm dgamma", dg, gr.grad, 2e-3)
-    report("layernorm dbeta", db, br.grad, 2e-3)
+    for form in (0, 2):      # 0: the plan's default (lean dx kernel + parameter-gradient pass), 2: dx and parameter partial sums in one pass
+        lib.check(L.sdxl_set_knob(10, form))
+        dx.zero_(); dg.zero_(); db.zero_()
+        try:
+            lib.check(L.sdxl_op_layernorm_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(stats), ptr(dx), ptr(dg), ptr(db), M, Cc, 0, stream()))
+        finally:
+            lib.check(L.sdxl_set_knob(10, 0))
+        report(f"layernorm dx (form {form})", dx, xr.grad, 1e-2)
+        report("layernorm dgamma", dg, gr.grad, 2e-3)
+        report("layernorm dbeta", db, br.grad, 2e-3)
+    base = rnd(M, Cc, seed=54)          # accumulate form: dx = addend + grad
+    dx2 = base.clone()
+    lib.check(L.sdxl_op_layernorm_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(stats), ptr(dx2), ptr(dg), ptr(db), M, Cc, 1, stream()))
+    report("layernorm dx += ", dx2, xr.grad + base.float(), 1e-2)
 
 
 def geglu_pack_rows(t, C4, G=64):
