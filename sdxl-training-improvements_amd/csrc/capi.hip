@@ -831,6 +831,7 @@ int sdxl_profile_gemm_end(double* flops, double* ms, int* launches) { return gem
 int sdxl_set_knob(int id, int value) {
   ARG_CHECK(id >= 0 && id < SDXL_NKNOBS, "knob %d out of range", id);
   g_knobs[id] = value;
+  if (id == 15) gemm256_set_tail(value == 0);     // knob 15 = 1: no half-height tail workgroups in the 256 x 256 kernel
   return 0;
 }
 int sdxl_set_sk_mode(int mode, int workers) {

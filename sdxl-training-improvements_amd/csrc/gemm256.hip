@@ -70,8 +70,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmP p) {
   const int wr = wave >> 2, wc = wave & 3;
   const int l16 = lane & 15, g = lane >> 4;
   int bx, by;
-  xcd_tile_map(p.xcd_px, bx, by);
-  const int n0 = bx * 256, m0 = by * 256;
+  // tail mode (1-D grid): workgroups [0, full) own whole tiles of the first tail_n0 tile columns, the others 128 x 256 HALF tiles of the
+  // remaining columns -- their waves 4-7 (the tile's rows 128..255) neither read fragments nor multiply, they only stage data and
+  // keep the barriers, so the active waves have their SIMD's matrix pipe to themselves and a K-step takes ~0.6 of a full tile's
+  bool half = false;
+  if (p.tail_n0 > 0) {
+    const int gy = p.M / 256, full = p.tail_n0 * gy;
+    const int id = blockIdx.x;
+    if (id < full) {
+      xcd_tile_map_id(p.xcd_px, id, p.tail_n0, gy, bx, by);
+      by *= 2;                                          // (by counts 128-row halves below)
+    } else {
+      half = true;
+      xcd_tile_map_id(0, id - full, p.N / 256 - p.tail_n0, 2 * gy, bx, by);
+      bx += p.tail_n0;
+    }
+  } else {
+    xcd_tile_map(p.xcd_px, bx, by);
+    by *= 2;
+  }
+  const int n0 = bx * 256, m0 = by * 128;
+  const bool idle = half && wr == 1;
   const bool gmap = p.geglu == 1;
   // first tile column of wave column wcx, quadrant half b (32 columns follow)
   auto cbase = [&](int wcx, int b) { return gmap ? 128 * (wcx >> 1) + 32 * (wcx & 1) + 64 * b : 64 * wcx + 32 * b; };
@@ -106,7 +125,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmP p) {
   auto piece = [&](auto REG, int h, int tile, int buf) {
     constexpr int R = decltype(REG)::v;
     constexpr int ab = R & 1;
-    const bool live = tile < T;
+    const bool live = tile < T && !(half && R < 2 && h == 1);      // (a half tile has no rows 128..255)
     if ((G256_DIAG & 2) && tile >= 2) return;
     const int k0 = (kt_begin + tile) * 64;
     const int q = wave + 8 * h;
@@ -165,8 +184,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmP p) {
   };
   // 32 products of one accumulator half (64 rows x 64 columns of the wave tile); the phase's LDS-DMA pieces are issued
   // between the MFMAs (one after every four), where their issue cost hides under the matrix pipe
-  auto mma = [&](auto AQ, int tile_next) {
+  auto mma = [&](auto AQ, int tile_next, auto IDLEC) {
     constexpr int a = decltype(AQ)::v;
+    constexpr bool IDLE = decltype(IDLEC)::v != 0;
     const int nbuf = tile_next & 1;
     if (!(G256_DIAG & 8)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -178,7 +198,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (G256_DIAG & 1) acc[4 * a + i][j][0] += (float)fa[i][ks][0] + (float)fb[j][ks][0];
-          else acc[4 * a + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[4 * a + i][j], 0, 0, 0);
+          else if (!IDLE) acc[4 * a + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[4 * a + i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         const int slot = ks * 4 + i;          // 8 slots of 4 MFMAs
         if (a == 0) {                         // phase A: A-a1 of the next K-tile
@@ -194,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmP p) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (BIAS && do_bias) {
+      if (BIAS && do_bias && !IDLE) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           accb[BIAS ? 4 * a + i : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i][ks], accb[BIAS ? 4 * a + i : 0], 0, 0, 0);
@@ -222,6 +242,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmP p) {
 #if G256_DIAG & 16
   const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && (wave & 3) == 0;
 #endif
+  if (!idle) {
   for (int t = 0; t < T; ++t) {
     const int cb = t & 1;
     int ph_ = 0;
@@ -235,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmP p) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     STAMP(2);
-    mma(IC<0>{}, t + 1);
+    mma(IC<0>{}, t + 1, IC<0>{});
     STAMP(3);
     post();
     STAMP(4);
@@ -248,14 +269,30 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmP p) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     STAMP(2);
-    mma(IC<1>{}, t + 2);
+    mma(IC<1>{}, t + 2, IC<0>{});
     STAMP(3);
     post();
     STAMP(4);
   }
+  } else {
+    // waves 4-7 of a half tile: the same DMA pieces, waits and barriers, no fragment reads, no products
+    for (int t = 0; t < T; ++t) {
+      wait_vmcnt<6>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      mma(IC<0>{}, t + 1, IC<1>{});
+      post();
+      wait_vmcnt<2>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      mma(IC<1>{}, t + 2, IC<1>{});
+      post();
+    }
+  }
   if (wr == 0) __builtin_amdgcn_s_barrier();   // both halves execute the same number of barriers
   wait_vmcnt<0>();                              // dummy tail pieces must not outlive the workgroup's LDS allocation
 
+  if (idle) return;
   // ---- epilogue, registers -> global.  Lane (l16, g) holds C[m = 16 i + l16][n = 16 j + 4 g .. + 3] of its wave tile ----
   const int mrow = m0 + 128 * wr + l16;   // + 16 i
   if (FORM == GEMM_TN) {
@@ -376,6 +413,7 @@ int launch256(const GemmP& p, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(p.N / 256, p.M / 256, FORM == GEMM_TN ? p.splitk : 1);
+  if (p.tail_n0 > 0) grid = dim3(p.tail_n0 * (p.M / 256) + 2 * (p.N / 256 - p.tail_n0) * (p.M / 256), 1, 1);
   hipLaunchKernelGGL((gemm256_kernel<FORM, BIAS>), grid, dim3(512), SMEM256, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
@@ -405,6 +443,8 @@ extern "C" int sdxl_debug_g256_stamps(unsigned long long* out) {   // diagnostic
 }
 #endif
 
+static bool g256_tail_enabled = true;
+void gemm256_set_tail(bool on) { g256_tail_enabled = on; }
 int launch_gemm256(const GemmP& pin, hipStream_t st) {
   ARG_CHECK(gemm256_applicable(pin), "gemm256: problem %dx%dx%d (form %d) does not fit the 256x256 kernel", pin.M, pin.N, pin.K, pin.form);
   GemmP p = pin;
@@ -417,6 +457,25 @@ int launch_gemm256(const GemmP& pin, hipStream_t st) {
       if (gx % px || gy % py) continue;
       const double cost = (double)p.N / px + (double)p.M / py;
       if (cost < best) { best = cost; p.xcd_px = px; }
+    }
+  }
+  // tail mode (NT): the tiles beyond the last full round of 256, when they are at most half a round and whole tile columns,
+  // go out as twice as many half-height workgroups in the same launch (see the kernel)
+  p.tail_n0 = 0;
+  if (p.form == GEMM_NT && g256_tail_enabled) {
+    const int gx = p.N / 256, gy = p.M / 256;
+    const long T = (long)gx * gy, r = T % 256;
+    if (T > 256 && r > 0 && r <= 128 && r % gy == 0) {
+      p.tail_n0 = gx - (int)(r / gy);
+      // XCD map of the full region: it must divide that region's grid
+      p.xcd_px = 0;
+      double best = 1e30;
+      for (int px = 1; px <= 8; px *= 2) {
+        const int py = 8 / px;
+        if (p.tail_n0 % px || gy % py) continue;
+        const double cost = 256.0 * p.tail_n0 / px + (double)p.M / py;
+        if (cost < best) { best = cost; p.xcd_px = px; }
+      }
     }
   }
   switch (p.form) {

@@ -96,6 +96,30 @@ __device__ __forceinline__ void wait_vmcnt() {
 // out as a px x py grid over the (n, m) tile grid (px chosen by the launcher to minimise the A-panel + B-panel footprint
 // per XCD) so that each private 4 MiB L2 sees a compact rectangle of output tiles; inside a rectangle tiles go n-fastest
 // in strips of 8 columns.  Identity when the grid does not divide.
+// the same map for a linear workgroup id over a gx x gy tile grid (regions of a 1-D launch)
+__device__ __forceinline__ void xcd_tile_map_id(int xcd_px, int id, int gx, int gy, int& bx, int& by) {
+  bx = id % gx;
+  by = id / gx;
+  if (xcd_px > 0 && gx % xcd_px == 0 && gy % (8 / xcd_px) == 0) {
+    const int px = xcd_px, py = 8 / px;
+    const int tn = gx / px, tm = gy / py;
+    const int xcd = id & 7, li = id >> 3;
+    const int sw = tn < 8 ? tn : 8;
+    const int full = (tn / sw) * sw * tm;
+    int ln, lm;
+    if (li < full) {
+      const int strip = li / (sw * tm), w = li - strip * (sw * tm);
+      lm = w / sw;
+      ln = strip * sw + (w - lm * sw);
+    } else {
+      const int rw = tn - (tn / sw) * sw, w = li - full;
+      lm = w / rw;
+      ln = (tn / sw) * sw + (w - lm * rw);
+    }
+    bx = (xcd % px) * tn + ln;
+    by = (xcd / px) * tm + lm;
+  }
+}
 __device__ __forceinline__ void xcd_tile_map(int xcd_px, int& bx, int& by) {
   bx = blockIdx.x;
   by = blockIdx.y;

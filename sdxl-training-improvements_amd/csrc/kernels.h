@@ -69,6 +69,8 @@ struct GemmP {
   float* bias_grad;  // TN only, optional: bias_grad[m] += sum_k A(k, m)  (column sums of dY, computed on the matrix pipe
                      // by the n-tile-0 / tap-0 workgroups with an all-ones B fragment; fp32 atomics, 128 per workgroup)
   int xcd_px;      // set by the launcher: XCD grid width over n-tiles (0 = identity order)
+  int tail_n0;     // 256 x 256 kernel, set by its launcher: > 0 = the tile columns from tail_n0 on are computed by HALF-HEIGHT workgroups
+                   // (128 x 256: waves 4-7 only stage data) so that a launch of 2.5 rounds of tiles takes ~2.6 rounds, not 3
   int cfg;         // > 0: this launch's configuration of the 128-row kernel (1, 2, 3, 13, 23), overriding the selection policy
   int prio;        // wave priority (s_setprio 0..3) of the whole kernel: the backward's critical-path launches (dgrad chain, caller's
                    // stream) outrank the co-resident weight-gradient workgroups of the side stream on every SIMD they share
@@ -93,6 +95,7 @@ bool gemm_use256(int form, int M, int N, int K, int splitk);   // the policy of 
 int gemm_pick_splitk(int M, int N, int taps, long red);        // split-K factor the wgrad launchers should request
 int gemm_pick_splitk_small(int M, int N, int K);               // split-K factor for NT / NN (bf16 output) launches of small problems
 int launch_gemm256(const GemmP& p, hipStream_t st);
+void gemm256_set_tail(bool on);     // half-height workgroups for the last partial round (default on; A/B runs)
 // persistent stream-K kernel (gemm_sk.hip): up to 4 problems (M, N multiples of 256, K of 64, no gather) in ONE launch, their
 // K-steps cut evenly over the CUs; partial tiles are handed to the tile's owner inside the launch (fixed order: reproducible)
 bool gemm_sk_applicable(const GemmP& p);
