@@ -165,6 +165,10 @@ int sdxl_op_conv3x3_dgrad(const void* dy, const void* w, void* dx, int B, int H,
                           int stride, void* stream);
 int sdxl_op_conv3x3_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout,
                           int stride, int splitk, void* stream);
+/* the same with the plan's options: dbias[Cout] += column sums of dy (may be NULL), accumulate 0 / 1, splitk <= 0 = the plan's choice.
+ * Same-size stride-1 convolutions with W % 64 == 0 and >= 16 384 pixels run on the three-taps-per-workgroup kernel (conv_wgrad3.hip). */
+int sdxl_op_conv3x3_wgrad2(const void* x, const void* dy, float* dw, float* dbias, int B, int H, int W, int Cin, int Cout,
+                           int stride, int splitk, int accumulate, void* stream);
 int sdxl_op_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int heads,
                           int Nq, int Nk, long ldq, long ldk, long ldv, long ldo, void* stream);
 int sdxl_op_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,

@@ -669,6 +669,25 @@ int sdxl_op_conv3x3_wgrad(const void* x, const void* dy, float* dw, int B, int H
   return launch_gemm(g, (hipStream_t)st);
 }
 
+int sdxl_op_conv3x3_wgrad2(const void* x, const void* dy, float* dw, float* dbias, int B, int H, int W, int Cin, int Cout, int stride,
+                           int splitk, int accumulate, void* st) {
+  int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  GemmP g;
+  gemm_defaults(&g);
+  g.form = GEMM_TN;
+  g.A = (const bf16*)dy; g.B = (const bf16*)x; g.C = dw;
+  g.M = Cout; g.N = Cin; g.K = B * Ho * Wo;
+  g.lda = Cout; g.ldb = Cin; g.ldc = 9L * Cin;
+  g.taps = 9; g.Hm = Ho; g.Wm = Wo; g.Hs = H; g.Ws = W; g.sm = stride; g.sd = 1;
+  g.c_tap_stride = Cin;
+  g.out_f32 = 1; g.accumulate = accumulate; g.bias_grad = dbias;
+  // splitk <= 0: the plan's choice (the three-taps-per-workgroup kernel has its own)
+  if (splitk <= 0) splitk = conv_wgrad3_policy(Cout, Cin, g.K, Wo, stride) ? conv_wgrad3_pick_splitk(Cout, Cin, g.K) : gemm_pick_splitk(Cout, Cin, 9, g.K);
+  g.splitk = splitk;
+  if (splitk > 1) CHK(test_slab(gemm_slab_floats(Cout, Cin, 9, splitk), &g.slab));
+  return launch_gemm(g, (hipStream_t)st);
+}
+
 int sdxl_op_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int heads, int Nq,
                           int Nk, long ldq, long ldk, long ldv, long ldo, void* st) {
   AttnP a;
@@ -831,6 +850,7 @@ int sdxl_profile_gemm_end(double* flops, double* ms, int* launches) { return gem
 int sdxl_set_knob(int id, int value) {
   ARG_CHECK(id >= 0 && id < SDXL_NKNOBS, "knob %d out of range", id);
   g_knobs[id] = value;
+  if (id == 12) conv_wgrad3_set_enabled(value == 0);    // knob 12 = 1: 3x3 weight gradients on the one-tap-per-workgroup kernel only
   if (id == 15) gemm256_set_tail(value == 0);     // knob 15 = 1: no half-height tail workgroups in the 256 x 256 kernel
   return 0;
 }

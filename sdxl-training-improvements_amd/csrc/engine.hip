@@ -303,6 +303,7 @@ struct ConvOp : Op {
     }
     if (x->need_grad) dx = p.grad_dst(x);
     splitk = pick_splitk(Cout, Cin, 9, (long)Bn * Ho * Wo);
+    if (conv_wgrad3_policy(Cout, Cin, (long)Bn * Ho * Wo, Wo, stride)) splitk = conv_wgrad3_pick_splitk(Cout, Cin, (long)Bn * Ho * Wo);
     want_slab(p, Cout, Cin, 9, splitk);
     if (stride == 1 && Cin % 64 == 0) {
       fsplit = gemm_pick_splitk_small(Bn * Ho * Wo, Cout, 9 * Cin);

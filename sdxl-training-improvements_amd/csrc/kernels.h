@@ -106,6 +106,12 @@ int gemm_sk_mode();
 bool gemm_use_sk(const GemmP& p);
 void gemm_sk_set_workers(int n);                      // > 0: force the worker count (microbenchmarks), 0: policy
 int gemm_sk_error(hipStream_t st, unsigned* out);     // != 0: an owner gave up waiting for a partial tile (results invalid)
+// 3x3 weight gradient, three taps per workgroup (conv_wgrad3.hip): same-size stride-1 convolutions whose image width is a multiple of 64
+bool conv_wgrad3_applicable(const GemmP& p);
+bool conv_wgrad3_policy(int M, int N, long red, int Wm, int stride);   // the plan's choice (long reductions: the 128^2 / 64^2 levels)
+int conv_wgrad3_pick_splitk(int M, int N, long red);
+int launch_conv_wgrad3(const GemmP& p, hipStream_t st);
+void conv_wgrad3_set_enabled(bool on);
 // per-launch HIP-event timing of every GEMM launch between begin and end (end synchronises the device)
 int gemm_profile_begin();
 bool gemm_profiling();   // true between begin and end: the engine then runs everything on one stream (clean durations)

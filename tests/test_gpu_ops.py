@@ -339,6 +339,50 @@ def test_conv3x3_fwd_dgrad_wgrad(L, B, H, W, Cin, Cout, stride):
         report(f"conv wgrad splitk={splitk}", dw, wr.grad, 1e-4 * math.sqrt(B * Ho * Wo) / 8 + 1e-5)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 128, 128, 320, 320), (4, 64, 64, 640, 320), (2, 128, 128, 192, 200), (1, 128, 128, 8, 320),
+                                            (5, 64, 64, 64, 64),
+                                            # W = 32 (the 1280-channel level at 1024^2): a K-step is two image rows, each with its own halo
+                                            (4, 32, 32, 1280, 1280), (5, 32, 32, 200, 72), (8, 16, 32, 64, 128)])
+@pytest.mark.parametrize("splitk", [0, 1, 5])
+def test_conv3x3_wgrad_three_taps_per_workgroup(L, B, H, W, Cin, Cout, splitk):
+    """conv_wgrad3.hip (same-size stride-1 3x3, W % 64 == 0, >= 16 384 pixels: the 128^2 / 64^2 levels): a workgroup computes the three
+    taps of one stencil row from ONE staged dY tile and an X tile with a one-pixel halo.  Against autograd through F.conv2d on every
+    tap (image borders, row ends at the K-step seams, batch seams, ragged channel tiles), bias gradient, overwrite and += , the
+    plan's split-K and forced ones; and against the one-tap-per-workgroup kernel."""
+    if W == 32:
+        lib.check(L.sdxl_set_knob(14, 2))          # the W = 32 form is not the plan's default (see conv_wgrad3_policy)
+    try:
+        _conv_wgrad3_case(L, B, H, W, Cin, Cout, splitk)
+    finally:
+        lib.check(L.sdxl_set_knob(14, 0))
+
+
+def _conv_wgrad3_case(L, B, H, W, Cin, Cout, splitk):
+    x, dy = rnd(B, H, W, Cin, seed=14), rnd(B, H, W, Cout, seed=15)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(False)
+    wr = torch.zeros(Cout, Cin, 3, 3, device=dev(), requires_grad=True)
+    y = torch.nn.functional.conv2d(xr, wr, padding=1)
+    y.backward(dy.float().permute(0, 3, 1, 2))
+    ref = wr.grad.permute(0, 2, 3, 1).reshape(Cout, 9, Cin)                # native layout [co][tap][ci]
+    tol = 1e-4 * math.sqrt(B * H * W) / 8 + 1e-5
+    dw = torch.full((Cout, 9, Cin), 5.0, dtype=torch.float32, device=dev())
+    db = torch.zeros(Cout, dtype=torch.float32, device=dev())
+    lib.check(L.sdxl_op_conv3x3_wgrad2(ptr(x), ptr(dy), ptr(dw), ptr(db), B, H, W, Cin, Cout, 1, splitk, 0, stream()))
+    report(f"conv wgrad3 {B}x{H}x{W} {Cin}->{Cout} splitk={splitk}", dw, ref, tol)
+    report("conv wgrad3 bias grad", db, dy.float().sum((0, 1, 2)), 1e-4)
+    lib.check(L.sdxl_op_conv3x3_wgrad2(ptr(x), ptr(dy), ptr(dw), None, B, H, W, Cin, Cout, 1, splitk, 1, stream()))
+    report("conv wgrad3 +=", dw, 2 * ref, tol)
+    lib.check(L.sdxl_set_knob(12, 1))                                         # the one-tap kernel on the same problem
+    try:
+        dw1 = torch.zeros(Cout, 9, Cin, dtype=torch.float32, device=dev())
+        lib.check(L.sdxl_op_conv3x3_wgrad2(ptr(x), ptr(dy), ptr(dw1), None, B, H, W, Cin, Cout, 1, 0, 0, stream()))
+    finally:
+        lib.check(L.sdxl_set_knob(12, 0))
+        if W == 32:
+            lib.check(L.sdxl_set_knob(14, 2))
+    report("conv wgrad3 vs one-tap kernel", dw * 0.5, dw1, tol)
+
+
 def _attn_ref(q, k, v, heads):
     B, Nq, Cc = q.shape
     d = Cc // heads
