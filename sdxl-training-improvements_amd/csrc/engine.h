@@ -7,6 +7,7 @@
 // Gradient buffers are assigned while walking the tape in reverse: the first writer of a tensor's gradient
 // overwrites, later writers accumulate, and a residual connection's gradient is an alias of its output's.
 #pragma once
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -138,6 +139,10 @@ struct Engine {
   std::vector<std::vector<GemmP>> wg_pending;   // weight gradients waiting for a grouped launch, one bucket per shape
   int defer_wgrad(Plan& p, hipStream_t main, const GemmP& g, int grp);
   int flush_wgrads(Plan& p, hipStream_t main);
+  // leaf launches for the side stream that may start any time after the point they were queued at (their inputs are write-once
+  // buffers produced by launches already enqueued on the caller's stream): they ride on the NEXT fork event instead of paying for
+  // one of their own (LayerNorm parameter gradients, cross-attention dK / dV: 280 events per step)
+  std::vector<std::function<int(hipStream_t)>> side_leaves;
   std::vector<LnRedEntry> ln_pending;     // LayerNorm backward launches whose dgamma | dbeta partials are not reduced yet
   int flush_ln_params(Plan& p, hipStream_t main);
   bool side_dirty = false;       // the side stream has work the caller's stream has not joined yet

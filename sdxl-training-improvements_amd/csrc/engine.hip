@@ -91,7 +91,20 @@ static int on_side(Plan& p, hipStream_t main, F&& fn) {
   HIP_CHECK_RET(hipEventRecord(ev, main));
   HIP_CHECK_RET(hipStreamWaitEvent(e.side, ev, 0));
   e.side_dirty = true;
+  if (!e.side_leaves.empty()) {              // queued leaves: everything they read was enqueued on `main` before this event
+    std::vector<std::function<int(hipStream_t)>> v;
+    v.swap(e.side_leaves);
+    for (auto& leaf : v) CHK(leaf(e.side));
+  }
   return fn(e.side);
+}
+// queue a leaf for the side stream (runs behind the next fork event; immediately, on `main`, in the single-stream modes)
+template <class F>
+static int side_leaf(Plan& p, hipStream_t main, F&& fn) {
+  Engine& e = *p.eng;
+  if (!e.use_side || !e.side || gemm_profiling() || g_knobs[8] == 1) return on_side(p, main, fn);     // (knob 8 = 1: own event each, A/B runs)
+  e.side_leaves.emplace_back(std::function<int(hipStream_t)>(fn));
+  return 0;
 }
 // weight gradients of one shape wait here until `grp` of them fill a launch (GemmP::group); flush_wgrads() at the end of a
 // backward segment launches the stragglers (their dY / X operands are write-once buffers of the plan, nothing reuses them)
@@ -121,6 +134,7 @@ int Engine::defer_wgrad(Plan& p, hipStream_t main, const GemmP& g, int grp) {
   return 0;
 }
 int Engine::flush_wgrads(Plan& p, hipStream_t main) {
+  if (!side_leaves.empty()) CHK(on_side(p, main, [](hipStream_t) -> int { return 0; }));     // the stragglers, behind one event
   for (auto& b : wg_pending) CHK(launch_wgrad_bucket(p, main, b));
   return 0;
 }
@@ -411,7 +425,7 @@ struct LayerNormOp : Op {
       CHK(launch_layernorm_bwd(p.P(x), p.GP(dy_off), p.eng->Wp(gm), p.F(stats_off), p.GP(dx.out), p.GP(dx.addend), nullptr, nullptr, (int)x->rows, C, st));
       const bf16* xp = p.P(x); const bf16* dyp = p.GP(dy_off); const float* sp = p.F(stats_off);
       float* dg = p.eng->Gp(gm); float* db = p.eng->Gp(bt); const int Mr = (int)x->rows, Cc = C;
-      return on_side(p, st, [=](hipStream_t s2) -> int { return launch_layernorm_param_grads(xp, dyp, sp, dg, db, Mr, Cc, s2); });
+      return side_leaf(p, st, [=](hipStream_t s2) -> int { return launch_layernorm_param_grads(xp, dyp, sp, dg, db, Mr, Cc, s2); });
     }
     LnRedEntry r;
     r.part = p.F(part_off); r.dgamma = p.eng->Gp(gm); r.dbeta = p.eng->Gp(bt); r.C = C;
@@ -489,7 +503,7 @@ struct AttnOp : Op {
     // projection's weight gradient, a leaf on the side stream -- so the dK / dV kernel (+ its partial reduce) goes there too,
     // behind the dQ kernel that produces Delta, and leaves the caller's stream (1.8 ms per step)
     CHK(launch_attn_bwd_dq(a, st));
-    return on_side(p, st, [=](hipStream_t s2) -> int { return launch_attn_bwd_dkv(a, s2); });
+    return side_leaf(p, st, [=](hipStream_t s2) -> int { return launch_attn_bwd_dkv(a, s2); });
   }
 };
 
