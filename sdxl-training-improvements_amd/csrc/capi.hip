@@ -589,6 +589,7 @@ int sdxl_op_gemm(int form, const void* A, const void* B, void* C, int M, int N, 
     CHK(test_slab(gemm_slab_floats(M, N, 1, splitk), &g.slab));
   }
   if (form == GEMM_TN) {
+    if (splitk <= 0) splitk = wgrad256_policy(M, N, K) ? wgrad256_pick_splitk(M, N, K) : gemm_pick_splitk(M, N, 1, K);     // the plan's choice
     g.lda = M; g.ldb = N; g.out_f32 = 1; g.splitk = splitk;
     if (splitk > 1) CHK(test_slab(gemm_slab_floats(M, N, 1, splitk), &g.slab));
   }
@@ -850,6 +851,7 @@ int sdxl_profile_gemm_end(double* flops, double* ms, int* launches) { return gem
 int sdxl_set_knob(int id, int value) {
   ARG_CHECK(id >= 0 && id < SDXL_NKNOBS, "knob %d out of range", id);
   g_knobs[id] = value;
+  if (id == 9) wgrad256_set_enabled(value == 0);         // knob 9 = 1: long-reduction linear weight gradients on the 128 x 160 kernel
   if (id == 12) conv_wgrad3_set_enabled(value == 0);    // knob 12 = 1: 3x3 weight gradients on the one-tap-per-workgroup kernel only
   if (id == 15) gemm256_set_tail(value == 0);     // knob 15 = 1: no half-height tail workgroups in the 256 x 256 kernel
   return 0;

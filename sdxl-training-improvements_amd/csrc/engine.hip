@@ -210,6 +210,7 @@ struct LinearOp : Op {
     if (gu) dx = p.grad_dst(gu);           // the activation itself gets no gradient buffer: dgrad emits dU
     else if (x->need_grad) dx = p.grad_dst(x);
     splitk = pick_splitk(N, K, 1, x->rows);
+    if (wgrad256_policy(N, K, x->rows)) splitk = wgrad256_pick_splitk(N, K, x->rows);
     wgroup = gemm_pick_group(N, K, 1, x->rows, splitk);
     want_slab(p, N, K, 1, splitk);
     if (!gact) { fsplit = gemm_pick_splitk_small((int)x->rows, N, K); want_slab_main(p, (int)x->rows, N, fsplit); }

@@ -1165,6 +1165,7 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
     case GEMM_NN: return conv ? launch_one<GEMM_NN, true>(p, st) : launch_one<GEMM_NN, false>(p, st);
     case GEMM_TN:
       if (conv && conv_wgrad3_applicable(p) && conv_wgrad3_policy(p.M, p.N, p.K, p.Wm, p.sm)) rc = launch_conv_wgrad3(p, st);
+      else if (!conv && wgrad256_applicable(p) && wgrad256_policy(p.M, p.N, p.K)) rc = launch_wgrad256(p, st);
       else
       rc = conv ? launch_one<GEMM_TN, true>(p, st) : launch_one<GEMM_TN, false>(p, st);
       if (rc == 0 && p.splitk > 1) {

@@ -112,6 +112,12 @@ bool conv_wgrad3_policy(int M, int N, long red, int Wm, int stride);   // the pl
 int conv_wgrad3_pick_splitk(int M, int N, long red);
 int launch_conv_wgrad3(const GemmP& p, hipStream_t st);
 void conv_wgrad3_set_enabled(bool on);
+// long-reduction linear weight gradient, 256 x 160 tiles, 8 waves (wgrad256.hip)
+bool wgrad256_applicable(const GemmP& p);
+bool wgrad256_policy(int M, int N, long red);
+int wgrad256_pick_splitk(int M, int N, long red);
+int launch_wgrad256(const GemmP& p, hipStream_t st);
+void wgrad256_set_enabled(bool on);
 // per-launch HIP-event timing of every GEMM launch between begin and end (end synchronises the device)
 int gemm_profile_begin();
 bool gemm_profiling();   // true between begin and end: the engine then runs everything on one stream (clean durations)

@@ -195,6 +195,31 @@ def test_gemm_stream_k_fused_dgrad_wgrad_is_reproducible(L):
         assert torch.equal(dx, first[0]) and torch.equal(dw, first[1])
 
 
+@pytest.mark.parametrize("M,N,K", [(5120, 640, 16384), (640, 2560, 16384), (1920, 640, 16384), (640, 640, 16384), (200, 72, 16384),
+                                   (256, 160, 32768)])
+@pytest.mark.parametrize("splitk", [0, 1, 3])
+def test_gemm_tn_long_reduction_wgrad256(L, M, N, K, splitk):
+    """wgrad256.hip (linear weight gradients over >= 16 384 rows: 256 x 160 tiles, two stacked dY tiles per staged X tile): fp32 result
+    against the fp32 product, bias gradient, += , the plan's split-K and forced ones, ragged tiles; and against the 128 x 160 kernel."""
+    a, b = rnd(K, M, seed=8), rnd(K, N, seed=9)
+    ref = a.float().t() @ b.float()
+    tol = 2e-5 * math.sqrt(K) + 1e-5
+    out = torch.full((M, N), 3.0, dtype=torch.float32, device=dev())
+    db = torch.zeros(M, dtype=torch.float32, device=dev())
+    lib.check(L.sdxl_op_gemm(2, ptr(a), ptr(b), ptr(out), M, N, K, ptr(db), None, 0, splitk, stream()))
+    report(f"wgrad256 {M}x{N}x{K} splitk={splitk}", out, ref, tol)
+    report("wgrad256 bias grad", db, a.float().sum(0), 1e-4)
+    lib.check(L.sdxl_op_gemm(2, ptr(a), ptr(b), ptr(out), M, N, K, None, None, 1, splitk, stream()))
+    report("wgrad256 +=", out, 2 * ref, tol)
+    lib.check(L.sdxl_set_knob(9, 1))
+    try:
+        o1 = torch.zeros(M, N, dtype=torch.float32, device=dev())
+        lib.check(L.sdxl_op_gemm(2, ptr(a), ptr(b), ptr(o1), M, N, K, None, None, 0, 0, stream()))
+    finally:
+        lib.check(L.sdxl_set_knob(9, 0))
+    report("wgrad256 vs 128x160 kernel", out * 0.5, o1, tol)
+
+
 @pytest.fixture
 def g256(L):
     """force the 256 x 256 / 8-phase kernel (gemm256.hip) wherever it is applicable, restore the default policy after"""
