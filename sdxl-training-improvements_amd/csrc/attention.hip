@@ -762,6 +762,7 @@ static int check_attn(const AttnP& p) {
 
 int launch_attn_fwd(const AttnP& p, hipStream_t st) {
   if (int e = check_attn(p)) return e;
+  if (FILE* f = launch_log()) { fprintf(f, "A,0,%d,%d,%d,%d\n", p.B, p.H, p.Nq, p.Nk); fflush(f); }
   dim3 grid(cdiv(p.Nq, 128), p.B * p.H);
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, st, p);
   HIP_CHECK_RET(hipGetLastError());
@@ -777,12 +778,14 @@ static int check_attn_bwd(const AttnP& p) {
 // dQ (+ Delta, which the dK / dV kernel reads: launch this one first, on a stream the other is ordered behind)
 int launch_attn_bwd_dq(const AttnP& p, hipStream_t st) {
   if (int e = check_attn_bwd(p)) return e;
+  if (FILE* f = launch_log()) { fprintf(f, "A,1,%d,%d,%d,%d\n", p.B, p.H, p.Nq, p.Nk); fflush(f); }
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(cdiv(p.Nq, 128), p.B * p.H), dim3(256), 0, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
 int launch_attn_bwd_dkv(const AttnP& p, hipStream_t st) {
   if (int e = check_attn_bwd(p)) return e;
+  if (FILE* f = launch_log()) { fprintf(f, "A,2,%d,%d,%d,%d\n", p.B, p.H, p.Nq, p.Nk); fflush(f); }
   AttnP q = p;
   if (q.qsplit < 1 || !q.part) q.qsplit = 1;
   // two key blocks per wave (232 VGPRs, 2 workgroups per CU) when the 128-key workgroups fill the chip four times over; at

@@ -990,7 +990,9 @@ int gemm_pick_splitk(int M, int N, int taps, long red) {
 // 22 ms of a 59 ms step.  Enough splits to put ~one workgroup on every CU, at least 4 K-steps each; 1 when the tiles alone
 // fill half the chip (every problem of the B = 4, 1024^2 step).
 int gemm_pick_splitk_small(int M, int N, int K) {     // K = the whole reduction length (taps x channels for a convolution)
-  if (M < 64 || K % 64) return 1;
+  // (rows < 64: the batch-sized time-embedding projections -- only the long ones: the dgrad of the 17 resnets' concatenated
+  //  time_emb_proj reduces over 13 760 columns with 4 rows: 8 workgroups x 215 K-steps = 0.3 ms at the very end of the backward)
+  if (K % 64 || (M < 64 && K < 2048)) return 1;
   const long tiles = (long)cdiv(M, 128) * cdiv(N, N % 160 == 0 ? 160 : 128);
   if (tiles >= 128) return 1;
   long s = 256 / tiles;
@@ -1039,7 +1041,14 @@ int launch_gemm_multi(const GemmP* ps, int n, hipStream_t st) {
   g_prof.recs.push_back({n > 1 ? 3 : ps[0].form, n, ps[0].M, ps[0].N, ps[0].K, 1});
   return rc;
 }
+// SDXL_LAUNCH_LOG=<path>: one line per GEMM / attention launch in host launch order (= rocprofv3's Dispatch_Id order), so that a
+// kernel trace can be joined with the problems' shapes (profiles/tools/phase_rate.py)
+FILE* launch_log() {
+  static FILE* f = []() -> FILE* { const char* p = getenv("SDXL_LAUNCH_LOG"); return p ? fopen(p, "w") : nullptr; }();
+  return f;
+}
 int launch_gemm(const GemmP& p, hipStream_t st) {
+  if (FILE* f = launch_log()) { fprintf(f, "G,%d,%d,%d,%d,%d,%d,%d\n", p.form, p.taps, p.M, p.N, p.K, p.splitk, p.group > 1 ? p.group : 1); fflush(f); }
   if (!g_prof.on) return launch_gemm_impl(p, st);
   while (g_prof.ev.size() < g_prof.used + 2) {
     hipEvent_t e;

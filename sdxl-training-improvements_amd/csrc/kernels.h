@@ -5,7 +5,7 @@
 #include "common.h"
 
 // experiment knobs (sdxl_set_knob; defaults = the shipped policy): 0 wave priority of the main-stream dgrad GEMMs in the backward,
-// 1 of the attention backward kernels, 2 of the LayerNorm / GroupNorm backward kernels
+// 1 of the attention backward kernels; 3.. see the uses of g_knobs in engine.hip / gemm.hip / capi.hip
 #define SDXL_NKNOBS 16
 extern int g_knobs[SDXL_NKNOBS];
 
@@ -120,6 +120,7 @@ int launch_wgrad256(const GemmP& p, hipStream_t st);
 void wgrad256_set_enabled(bool on);
 // per-launch HIP-event timing of every GEMM launch between begin and end (end synchronises the device)
 int gemm_profile_begin();
+FILE* launch_log();      // SDXL_LAUNCH_LOG (gemm.hip)
 bool gemm_profiling();   // true between begin and end: the engine then runs everything on one stream (clean durations)
 int gemm_profile_end(double* flops, double* ms, int* launches);
 

@@ -101,7 +101,7 @@ def test_gemm_nn_and_accumulate(L, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,splitk", [(256, 1280, 10240, 16), (256, 1280, 1280, 5), (77, 640, 2048, 4), (1000, 640, 2560, 3),
-                                          (256, 384, 320, 7), (128, 160, 64, 4)])
+                                          (256, 384, 320, 7), (128, 160, 64, 4), (4, 1280, 13760, 32), (4, 1280, 2816, 11)])
 def test_gemm_nt_nn_splitk_small_problems(L, M, N, K, splitk):
     """split-K of the bf16-output forms (small-M problems: batch 1 / 512^2): fp32 partial tiles per split, fixed-order sum +
     bias / residual / accumulate epilogue; a factor beyond K / 64 is clamped, ragged M and non-160 N go through."""
