@@ -632,7 +632,7 @@ int sdxl_op_conv3x3_fwd(const void* x, const void* w, const void* bias, void* y,
   g.b_tap_stride = Cin;
   g.bias = (const bf16*)bias;
   if (stride == 1 && Cin % 64 == 0) {     // as the plan does: small images split the (tap, channel) reduction
-    g.splitk = gemm_pick_splitk_small(g.M, Cout, 9 * Cin);
+    g.splitk = gemm_pick_splitk_small(g.M, Cout, 9 * Cin, 0);
     if (g.splitk > 1) CHK(test_slab(gemm_slab_floats(g.M, Cout, 1, g.splitk), &g.slab));
   }
   return launch_gemm(g, (hipStream_t)st);
@@ -649,7 +649,7 @@ int sdxl_op_conv3x3_dgrad(const void* dy, const void* w, void* dx, int B, int H,
   g.taps = 9; g.Hm = H; g.Wm = W; g.Hs = Ho; g.Ws = Wo; g.sm = 1; g.sd = stride;
   g.flip = 1; g.b_tap_stride = Cin;
   if (stride == 1 && Cout % 64 == 0) {
-    g.splitk = gemm_pick_splitk_small(g.M, Cin, 9 * Cout);
+    g.splitk = gemm_pick_splitk_small(g.M, Cin, 9 * Cout, 1);
     if (g.splitk > 1) CHK(test_slab(gemm_slab_floats(g.M, Cin, 1, g.splitk), &g.slab));
   }
   return launch_gemm(g, (hipStream_t)st);

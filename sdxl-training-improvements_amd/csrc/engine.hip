@@ -213,9 +213,9 @@ struct LinearOp : Op {
     if (wgrad256_policy(N, K, x->rows)) splitk = wgrad256_pick_splitk(N, K, x->rows);
     wgroup = gemm_pick_group(N, K, 1, x->rows, splitk);
     want_slab(p, N, K, 1, splitk);
-    if (!gact) { fsplit = gemm_pick_splitk_small((int)x->rows, N, K); want_slab_main(p, (int)x->rows, N, fsplit); }
+    if (!gact) { fsplit = gemm_pick_splitk_small((int)x->rows, N, K, 3); want_slab_main(p, (int)x->rows, N, fsplit); }
     if (!gu && x->need_grad) {
-      dsplit = gemm_pick_splitk_small((int)x->rows, K, N);
+      dsplit = gemm_pick_splitk_small((int)x->rows, K, N, 2);
       // knob 3 (experiment): split the reduction of the long-K dgrads (N >= knob 4) s ways although their tiles fill half the chip
       if (g_knobs[3] > 1 && N >= (g_knobs[4] > 0 ? g_knobs[4] : 8192) && N % (64 * g_knobs[3]) == 0 && dsplit == 1) dsplit = g_knobs[3];
       want_slab_main(p, (int)x->rows, K, dsplit);
@@ -321,9 +321,9 @@ struct ConvOp : Op {
     if (conv_wgrad3_policy(Cout, Cin, (long)Bn * Ho * Wo, Wo, stride)) splitk = conv_wgrad3_pick_splitk(Cout, Cin, (long)Bn * Ho * Wo);
     want_slab(p, Cout, Cin, 9, splitk);
     if (stride == 1 && Cin % 64 == 0) {
-      fsplit = gemm_pick_splitk_small(Bn * Ho * Wo, Cout, 9 * Cin);
+      fsplit = gemm_pick_splitk_small(Bn * Ho * Wo, Cout, 9 * Cin, 0);
       want_slab_main(p, Bn * Ho * Wo, Cout, fsplit);
-      if (x->need_grad && Cout % 64 == 0) { dsplit = gemm_pick_splitk_small(Bn * H * W, Cin, 9 * Cout); want_slab_main(p, Bn * H * W, Cin, dsplit); }
+      if (x->need_grad && Cout % 64 == 0) { dsplit = gemm_pick_splitk_small(Bn * H * W, Cin, 9 * Cout, 1); want_slab_main(p, Bn * H * W, Cin, dsplit); }
     }
   }
   int bwd(Plan& p, hipStream_t st, bool first) override {

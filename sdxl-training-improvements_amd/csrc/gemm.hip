@@ -989,11 +989,19 @@ int gemm_pick_splitk(int M, int N, int taps, long red) {
 // 1280-channel level -- 16 tiles of 128x160 for 256 CUs, each walking up to 160 K-steps at ~1 us: 58 us per dgrad launch,
 // 22 ms of a 59 ms step.  Enough splits to put ~one workgroup on every CU, at least 4 K-steps each; 1 when the tiles alone
 // fill half the chip (every problem of the B = 4, 1024^2 step).
-int gemm_pick_splitk_small(int M, int N, int K) {     // K = the whole reduction length (taps x channels for a convolution)
+int gemm_pick_splitk_small(int M, int N, int K, int kind) {     // K = the whole reduction length (taps x channels for a convolution)
   // (rows < 64: the batch-sized time-embedding projections -- only the long ones: the dgrad of the 17 resnets' concatenated
   //  time_emb_proj reduces over 13 760 columns with 4 rows: 8 workgroups x 215 K-steps = 0.3 ms at the very end of the backward)
   if (K % 64 || (M < 64 && K < 2048)) return 1;
   const long tiles = (long)cdiv(M, 128) * cdiv(N, N % 160 == 0 ? 160 : 128);
+  // 3x3 convolutions (kind 0 forward, 1 dgrad) whose tiles fill one round of one workgroup per CU (the 1280-channel level at B = 4,
+  // 1024^2: 256 tiles x 180-360 K-steps): two halves of the reduction as 512 co-resident 4-wave workgroups + the fixed-order
+  // sum -- 4 x 32 x 32, 1280 -> 1280: forward 170 (8-wave split-K groups) / 139 (8-wave 4 x 2) -> 117 us = 1 030 TFLOP/s, dgrad
+  // 171 -> 120; step -0.8 ms.  Not for the linear layers (kinds 2, 3; knob 2 bits, experiment): the forward FF2 projection loses
+  // 0.9 ms of the step to the slab round trip, the long dgrads are neutral beside the weight-gradient stream.
+  const bool conv_kind = (kind == 0 || kind == 1) && g_knobs[2] != 1;
+  const bool lin_kind = (kind == 2 || kind == 3) && g_knobs[2] > 1 && ((g_knobs[2] >> kind) & 1);
+  if ((conv_kind || lin_kind) && tiles > 128 && tiles <= 256 && K >= 5120) return 2;
   if (tiles >= 128) return 1;
   long s = 256 / tiles;
   const long maxs = K / 64 / 4;

@@ -93,7 +93,7 @@ bool gemm256_applicable(const GemmP& p);
 void gemm_set_mode(int mode);   // bits 0-1: 0 never / 1 policy / 2 wherever applicable; bits 2..: force a 128-row configuration
 bool gemm_use256(int form, int M, int N, int K, int splitk);   // the policy of mode 1
 int gemm_pick_splitk(int M, int N, int taps, long red);        // split-K factor the wgrad launchers should request
-int gemm_pick_splitk_small(int M, int N, int K);               // split-K factor for NT / NN (bf16 output) launches of small problems
+int gemm_pick_splitk_small(int M, int N, int K, int kind = -1);               // split-K factor for NT / NN (bf16 output) launches of small problems
 int launch_gemm256(const GemmP& p, hipStream_t st);
 void gemm256_set_tail(bool on);     // half-height workgroups for the last partial round (default on; A/B runs)
 // persistent stream-K kernel (gemm_sk.hip): up to 4 problems (M, N multiples of 256, K of 64, no gather) in ONE launch, their

@@ -341,7 +341,9 @@ def _conv_ref(x_nhwc, w_native, bias, stride):
                                                    # incremental (y, x) tracking wraps rows mid-K-step there
                                                    (2, 24, 42, 128, 64, 1), (1, 48, 84, 64, 128, 1), (3, 10, 42, 64, 64, 1),
                                                    # batch 1, 512^2 at the 1280-channel level: 256 pixels -> split (tap, channel) reduction
-                                                   (1, 16, 16, 1280, 1280, 1), (1, 32, 32, 640, 1280, 1)])
+                                                   (1, 16, 16, 1280, 1280, 1), (1, 32, 32, 640, 1280, 1),
+                                                   # B = 4, 1024^2 at the 1280-channel level: one round of 256 tiles -> two co-resident halves of the reduction
+                                                   (4, 32, 32, 1280, 1280, 1), (4, 32, 32, 1920, 1280, 1), (4, 32, 32, 640, 1280, 1)])
 def test_conv3x3_fwd_dgrad_wgrad(L, B, H, W, Cin, Cout, stride):
     x = rnd(B, H, W, Cin, seed=10)
     w = rnd(Cout, 9, Cin, seed=11, scale=(9 * Cin) ** -0.5)
