@@ -55,3 +55,13 @@ while a < t1:
     ph = 'F' if a < tb else 'B'
     print(f"{ph} {(a - t0) / 1e6:6.1f} ms: {fl / (b - a) / 1e3:6.0f} TFLOP/s  main {mb / (b - a):.2f} side {sb / (b - a):.2f}  " + " | ".join(f"{k} {v / (b - a):.2f}" for k, v in top.most_common(4)))
     a = b
+
+# per-problem table of the step as it ran (both streams overlapped): launches, total / mean duration, executed TFLOP/s
+agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+for k in step:
+    if k[4] <= 0: continue
+    key = ('F ' if k[0] < tb else 'B ') + ('M:' if k[2] == mainq else 'S:') + k[5]
+    a = agg[key]; a[0] += 1; a[1] += k[1] - k[0]; a[2] += k[4]
+print("\nproblem (phase stream form MxNxK)                   n    total ms   mean us   TFLOP/s")
+for key, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
+    print(f"{key:48s} {a[0]:4d} {a[1] / 1e6:9.2f} {a[1] / a[0] / 1e3:9.1f} {a[2] / a[1] / 1e3:8.0f}")
