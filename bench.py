@@ -331,7 +331,7 @@ def main():
                                  "profiles/tools/measure_step.sh" % traffic_commit) if stale else
                                 ("bytes per step over all launches of the family (fabric side, MALL hits included), PMC passes at commit %s; "
                                  "algorithmic operand + result bytes ~94e9" % traffic_commit),
-                "kernel": "gemm_kernel<NT|NN|TN, conv|linear> (128-row tiles) + gemm256_kernel (256x256 tiles) + conv_wgrad3_kernel (3x3 wgrad, three taps per workgroup): bf16 MFMA 16x16x32",
+                "kernel": "gemm_kernel<NT|NN|TN, conv|linear> (128-row tiles) + gemm256_kernel (256x256 tiles) + conv_wgrad3_kernel (3x3 wgrad, three taps per workgroup) + wgrad256_kernel (long-reduction linear wgrad, 256x160 tiles): bf16 MFMA 16x16x32",
                 "launches_per_step": n.value // args.profile_steps,
                 "gemm_ms_per_step": round(ms.value / args.profile_steps, 2),
                 "gemm_tflop_per_step": round(fl.value / args.profile_steps / 1e12, 2)}

@@ -30,7 +30,7 @@ import csv, glob, collections, json, os
 def fam(n):
     if 'gemm_kernel' in n or 'gemm256_kernel' in n or 'gemm_sk_kernel' in n or 'conv_wgrad3_kernel' in n: return 'gemm'
     if 'attn_' in n: return 'attention'
-    if 'splitk_reduce' in n: return 'splitk_reduce'
+    if 'splitk' in n: return 'splitk_reduce'
     if n.startswith('void at::') or 'at::native' in n or 'repack' in n or 'elementwise_kernel' in n or 'distribution' in n: return None
     return 'norm_elementwise_loss'
 out = {"workload": "ddpm_b4_1024", "commit": os.environ.get("SDXL_MEASURE_COMMIT", "unknown"), "note": "last step of `bench.py --steps 1 --warmup 1`; FETCH_SIZE / WRITE_SIZE are in KiB "
