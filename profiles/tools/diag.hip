@@ -5,10 +5,12 @@
 #include "../../sdxl-training-improvements_amd/csrc/gemm.hip"
 #include <stdio.h>
 void sdxl_set_error(const char* fmt, ...) {}
+int g_knobs[SDXL_NKNOBS];
 __global__ void null_kernel(int* p) { if (p && threadIdx.x == 9999) *p = 1; }
 int main(int argc, char** argv) {
   int form = argc > 1 ? atoi(argv[1]) : 0;
-  struct { int M, N, K; } shapes[] = {{1280, 1280, 4096}, {3840, 1280, 4096}, {10240, 1280, 4096}, {4096, 1280, 64}, {4096, 1280, 1280}, {4096, 1280, 5120}, {4096, 10240, 1280}, {8192, 8192, 4096}};
+  if (argc > 2) gemm_set_mode((atoi(argv[2]) << 2) | 1);      // force a configuration of the 128-row kernel
+  struct { int M, N, K; } shapes[] = {{1280, 1280, 4096}, {3840, 1280, 4096}, {10240, 1280, 4096}, {4096, 1280, 64}, {4096, 1280, 1280}, {4096, 1280, 5120}, {4096, 10240, 1280}, {4096, 1280, 10240}, {4096, 5120, 1280}, {8192, 8192, 4096}};
   bf16 *A, *B; void* C;
   size_t big = (size_t)8192 * 10240 * 2 * 2;
   hipMalloc(&A, big); hipMalloc(&B, big); hipMalloc(&C, big * 2);
