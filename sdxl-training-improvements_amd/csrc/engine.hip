@@ -102,7 +102,7 @@ static int on_side(Plan& p, hipStream_t main, F&& fn) {
 template <class F>
 static int side_leaf(Plan& p, hipStream_t main, F&& fn) {
   Engine& e = *p.eng;
-  if (!e.use_side || !e.side || gemm_profiling() || g_knobs[8] == 1) return on_side(p, main, fn);     // (knob 8 = 1: own event each, A/B runs)
+  if (!e.use_side || !e.side || gemm_profiling() || g_knobs[2] == 16) return on_side(p, main, fn);     // (knob 2 = 16: own event each, A/B runs)
   e.side_leaves.emplace_back(std::function<int(hipStream_t)>(fn));
   return 0;
 }

@@ -4,8 +4,15 @@
 #pragma once
 #include "common.h"
 
-// experiment knobs (sdxl_set_knob; defaults = the shipped policy): 0 wave priority of the main-stream dgrad GEMMs in the backward,
-// 1 of the attention backward kernels; 3.. see the uses of g_knobs in engine.hip / gemm.hip / capi.hip
+// experiment knobs (sdxl_set_knob / bench.py --knob id=value; 0 = the shipped policy everywhere):
+//   0 wave priority of the main-stream dgrad GEMMs in the backward, 1 of the attention backward kernels
+//   2 = 1: no split of the one-round 3x3 convolutions' reduction; = 16: every side-stream leaf behind its own fork event;
+//       = 4 / 8 / 12: the same split for the long linear dgrads / forward projections / both
+//   3, 4 split-K factor of the long linear dgrads and its N threshold; 5 = 80: GEGLU packed in groups of 80
+//   6, 7 forced configuration of the linear / conv dgrads, 8 N threshold of knob 6
+//   9 = 1: no wgrad256 kernel; 10 = 2: fused LayerNorm backward; 11 = 1: the round-2 LayerNorm dx kernel
+//   12 = 1: no three-tap conv weight gradient; 13 split-K workgroup target of conv_wgrad3 / wgrad256 (144); 14 = 2: its W = 32 form
+//   15 = 1: no half-height tail workgroups in the 256 x 256 kernel
 #define SDXL_NKNOBS 16
 extern int g_knobs[SDXL_NKNOBS];
 
