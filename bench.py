@@ -40,6 +40,10 @@ def kernels_changed_since(commit):
     None when git is not available (the GPU box's snapshot has no .git: the stamp is reported, the comparison is the reader's)."""
     try:
         import subprocess
+        # (outside a work tree -- the GPU box's snapshot -- `git diff --quiet` ALSO exits 1: ask for the commit first)
+        have = subprocess.run(["git", "-C", str(ROOT), "cat-file", "-e", commit + "^{commit}"], capture_output=True, timeout=20)
+        if have.returncode != 0:
+            return None
         r = subprocess.run(["git", "-C", str(ROOT), "diff", "--quiet", commit, "--", "sdxl-training-improvements_amd/csrc"],
                            capture_output=True, timeout=20)
         return None if r.returncode not in (0, 1) else r.returncode == 1
