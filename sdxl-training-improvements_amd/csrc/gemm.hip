@@ -992,7 +992,7 @@ int gemm_pick_splitk(int M, int N, int taps, long red) {
 int gemm_pick_splitk_small(int M, int N, int K, int kind) {     // K = the whole reduction length (taps x channels for a convolution)
   // (rows < 64: the batch-sized time-embedding projections -- only the long ones: the dgrad of the 17 resnets' concatenated
   //  time_emb_proj reduces over 13 760 columns with 4 rows: 8 workgroups x 215 K-steps = 0.3 ms at the very end of the backward)
-  if (K % 64 || (M < 64 && K < 2048)) return 1;
+  if (K % 64 || (M < 64 && K < 1024)) return 1;
   const long tiles = (long)cdiv(M, 128) * cdiv(N, N % 160 == 0 ? 160 : 128);
   // 3x3 convolutions (kind 0 forward, 1 dgrad) whose tiles fill one round of one workgroup per CU (the 1280-channel level at B = 4,
   // 1024^2: 256 tiles x 180-360 K-steps): two halves of the reduction as 512 co-resident 4-wave workgroups + the fixed-order
