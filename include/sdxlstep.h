@@ -161,6 +161,15 @@ int sdxl_op_wgrad_group(int n, const void* const* dy, const void* const* x, floa
 /* 3x3 conv, pad 1, token-major: x [B,H,W,Cin], w [Cout][9][Cin] ; y [B,Ho,Wo,Cout] */
 int sdxl_op_conv3x3_fwd(const void* x, const void* w, const void* bias, void* y, int B, int H, int W, int Cin,
                         int Cout, int stride, void* stream);
+/* conv3x3(nearest-2x upsample(x)) and its input gradient WITHOUT the upsampled image (the pair `Upsample2D` of diffusers =
+   F.interpolate(scale 2, nearest) + Conv2d 3x3, which the reference's UNet runs at the two up-level transitions): per output phase a
+   2 x 2 stencil on the low-resolution image with summed taps.  x [B][H][W][Cin], w [Cout][9][Cin], y / dy [B][2H][2W][Cout];
+   weff [Cout][16][Cin] and planar [4 * roundup(B*H*W, 128)][Cout] are bf16 scratch of the caller (weff: written by _fwd, read by _dgrad);
+   dx = addend (may be NULL) + gradient. */
+int sdxl_op_upconv3x3_fwd(const void* x, const void* w, const void* bias, void* weff, void* planar, void* y, int B, int H, int W,
+                          int Cin, int Cout, void* stream);
+int sdxl_op_upconv3x3_dgrad(const void* dy, const void* weff, void* planar, void* dx, const void* addend, int B, int H, int W, int Cin,
+                            int Cout, void* stream);
 int sdxl_op_conv3x3_dgrad(const void* dy, const void* w, void* dx, int B, int H, int W, int Cin, int Cout,
                           int stride, void* stream);
 int sdxl_op_conv3x3_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout,

@@ -637,6 +637,25 @@ int sdxl_op_conv3x3_fwd(const void* x, const void* w, const void* bias, void* y,
   }
   return launch_gemm(g, (hipStream_t)st);
 }
+// y = conv3x3(upsample2x(x)) and its input gradient without the upsampled image (GemmP::up2); weff [Cout][16][Cin] and planar
+// [4 B H W][Cout] bf16 are scratch of the caller (weff written by the forward, read by the dgrad)
+int sdxl_op_upconv3x3_fwd(const void* x, const void* w, const void* bias, void* weff, void* planar, void* y, int B, int H, int W,
+                          int Cin, int Cout, void* st) {
+  const int Mp = 4 * (int)upconv_plane_rows(B, H, W);
+  int splitk = gemm_pick_splitk_small(Mp, Cout, 4 * Cin, 0);
+  float* slab = nullptr;
+  if (splitk > 1) CHK(test_slab(gemm_slab_floats(Mp, Cout, 1, splitk), &slab));
+  return launch_upconv3x3_fwd((const bf16*)x, (const bf16*)w, (const bf16*)bias, (bf16*)weff, (bf16*)planar, (bf16*)y, B, H, W, Cin, Cout,
+                              splitk, slab, (hipStream_t)st);
+}
+int sdxl_op_upconv3x3_dgrad(const void* dy, const void* weff, void* planar, void* dx, const void* addend, int B, int H, int W, int Cin,
+                            int Cout, void* st) {
+  int splitk = gemm_pick_splitk_small(B * H * W, Cin, 16 * Cout, 1);
+  float* slab = nullptr;
+  if (splitk > 1) CHK(test_slab(gemm_slab_floats(B * H * W, Cin, 1, splitk), &slab));
+  return launch_upconv3x3_dgrad((const bf16*)dy, (const bf16*)weff, (bf16*)planar, (bf16*)dx, (const bf16*)addend, B, H, W, Cin, Cout, splitk,
+                                slab, 0, (hipStream_t)st);
+}
 int sdxl_op_conv3x3_dgrad(const void* dy, const void* w, void* dx, int B, int H, int W, int Cin, int Cout, int stride,
                           void* st) {
   int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;

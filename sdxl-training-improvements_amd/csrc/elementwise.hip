@@ -152,6 +152,70 @@ __global__ void upsample2x_bwd_kernel(const bf16* __restrict__ dy, bf16* dx, con
     *(bf16x8*)(dx + i * 8) = o;
   }
 }
+// ------------------------------------------------------------------ nearest-2x upsampling folded into the following 3x3 convolution
+// (GemmP::up2).  Weight entry e = 4 (2a + b) + 2u + v of output phase (a, b), stencil position (u, v): the sum of the taps (dy, dx) whose
+// high-resolution source row 2i + a + dy falls into low-resolution row i + u - (1 - a) (columns alike):
+//   a = 0: u = 0 <- {dy = -1}, u = 1 <- {0, +1};   a = 1: u = 0 <- {-1, 0}, u = 1 <- {+1}
+__global__ void upconv_fold_weights_kernel(const bf16* __restrict__ w, bf16* __restrict__ we, int Cout, int Cin) {
+  const int vpr = Cin / 8;
+  const long n = (long)Cout * 16 * vpr;
+  VEC_LOOP(i, n) {
+    const int v = (int)(i % vpr);
+    const long t = i / vpr;
+    const int e = (int)(t & 15);
+    const long co = t >> 4;
+    const int a = (e >> 3) & 1, b = (e >> 2) & 1, u = (e >> 1) & 1, vv = e & 1;
+    // rows / columns of the 3x3 kernel that fold onto (u | a) and (vv | b): index 0..2 = dy + 1
+    const int r0 = a == 0 ? (u == 0 ? 0 : 1) : (u == 0 ? 0 : 2), r1 = a == 0 ? (u == 0 ? 0 : 2) : (u == 0 ? 1 : 2);
+    const int c0 = b == 0 ? (vv == 0 ? 0 : 1) : (vv == 0 ? 0 : 2), c1 = b == 0 ? (vv == 0 ? 0 : 2) : (vv == 0 ? 1 : 2);
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = 0.f;
+    for (int r = r0; r <= r1; ++r)
+      for (int c = c0; c <= c1; ++c) {
+        const bf16x8 g = *(const bf16x8*)(w + ((co * 9 + r * 3 + c) * Cin) + v * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += (float)g[k];
+      }
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (bf16)s[k];
+    *(bf16x8*)(we + i * 8) = o;
+  }
+}
+int launch_upconv_fold_weights(const bf16* w, bf16* weff, int Cout, int Cin, hipStream_t st) {
+  ARG_CHECK(Cin % 8 == 0, "upconv: Cin=%d", Cin);
+  const long nv = (long)Cout * 16 * (Cin / 8);
+  hipLaunchKernelGGL(upconv_fold_weights_kernel, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, w, weff, Cout, Cin);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+// planar phase-major [4][plane rows >= B H W][C] <-> token-major high resolution [B][2H][2W][C] (TO_HI: planar -> high resolution)
+template <bool TO_HI>
+__global__ void pixel_shuffle2_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int B, int H, int W, int C, long plane) {
+  const int vpr = C / 8;
+  const long n = (long)B * 4 * H * W * vpr;
+  VEC_LOOP(i, n) {                                   // i runs over the high-resolution tensor
+    const long pix = i / vpr;
+    const int v = (int)(i - pix * vpr);
+    const int xo = (int)(pix % (2 * W));
+    const long t = pix / (2 * W);
+    const int yo = (int)(t % (2 * H));
+    const int b = (int)(t / (2 * H));
+    const int ph = (yo & 1) * 2 + (xo & 1);
+    const long pl = (long)ph * plane + ((long)b * H + (yo >> 1)) * W + (xo >> 1);
+    if (TO_HI) *(bf16x8*)(dst + i * 8) = *(const bf16x8*)(src + pl * C + v * 8);
+    else *(bf16x8*)(dst + pl * C + v * 8) = *(const bf16x8*)(src + i * 8);
+  }
+}
+int launch_pixel_shuffle2(const bf16* src, bf16* dst, int B, int H, int W, int C, int to_hi, hipStream_t st) {
+  ARG_CHECK(C % 8 == 0, "pixel shuffle: C=%d", C);
+  const long nv = (long)B * 4 * H * W * (C / 8);
+  if (to_hi) hipLaunchKernelGGL(pixel_shuffle2_kernel<true>, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, src, dst, B, H, W, C, upconv_plane_rows(B, H, W));
+  else hipLaunchKernelGGL(pixel_shuffle2_kernel<false>, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, src, dst, B, H, W, C, upconv_plane_rows(B, H, W));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
 int launch_upsample2x(const bf16* x, bf16* y, int B, int H, int W, int C, hipStream_t st) {
   ARG_CHECK(C % 8 == 0, "upsample: C=%d", C);
   long nv = (long)B * 4 * H * W * (C / 8);

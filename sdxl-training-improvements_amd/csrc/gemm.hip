@@ -153,6 +153,23 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
   long ua = 0, ub = 0;       // CF: uniform element offsets of the step being staged
   int s_tap = 0, s_c = 0;    // CF, NT / NN: (tap, channel step) of the step being staged
   const int tdy = tap_fixed / 3 - 1, tdx = tap_fixed - (tap_fixed / 3) * 3 - 1;   // CF, TN: this workgroup's tap
+  const int up_phase = (CF && FORM == GEMM_NT && p.up2) ? m0 / p.up_plane : 0;      // up2, NT: this workgroup's output phase
+  // CF, NT / NN: uniform element offsets of (tap s_tap, channel step s_c)
+  auto tap_offsets = [&]() {
+    int dy, dx, wtap;
+    long plane = 0;
+    if (p.up2) {
+      const int e = FORM == GEMM_NT ? up_phase * 4 + s_tap : s_tap;
+      dy = up2_dy(e); dx = up2_dx(e); wtap = e;
+      if (FORM == GEMM_NN) { dy = -dy; dx = -dx; plane = (long)(e >> 2) * p.up_plane * p.lda; }
+    } else {
+      dy = s_tap / 3 - 1; dx = s_tap - (s_tap / 3) * 3 - 1;
+      wtap = p.flip ? p.taps - 1 - s_tap : s_tap;
+    }
+    ua = plane + (long)(dy * p.Wm + dx) * p.lda + (long)s_c * BK;
+    if (FORM == GEMM_NT) ub = (long)wtap * p.b_tap_stride + (long)s_c * BK;
+    else ub = (long)wtap * p.b_tap_stride + (long)s_c * BK * p.ldb;
+  };
   if (FAST && !CONV) {
 #pragma unroll
     for (int j = 0; j < ACH; ++j) {
@@ -205,8 +222,21 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
       } else {
         const int row = c * KC_ROWS + kc_rowl;
         const int m = m0 + row;
+        int mask = 0, ml = m;
+        if (p.up2) {                               // (tap bit t = stencil entry: NT 4 up_phase + t, NN t)
+          ml = m - up_phase * p.up_plane;
+          const PixRow r = decode_pix(ml, p.up_rows, p.Hm, p.Wm);
+          if (c < NCA && r.ok) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+              if (t >= p.taps) break;
+              const int e = FORM == GEMM_NT ? up_phase * 4 + t : t;
+              const int ys = FORM == GEMM_NT ? r.y + up2_dy(e) : r.y - up2_dy(e), xs = FORM == GEMM_NT ? r.x + up2_dx(e) : r.x - up2_dx(e);
+              if (ys >= 0 && ys < p.Hm && xs >= 0 && xs < p.Wm) mask |= 1 << t;
+            }
+          }
+        } else {
         const PixRow r = decode_pix(m, p.M, p.Hm, p.Wm);
-        int mask = 0;
         if (c < NCA && r.ok) {
 #pragma unroll
           for (int t = 0; t < 9; ++t) {
@@ -214,8 +244,9 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
             if (ys >= 0 && ys < p.Hm && xs >= 0 && xs < p.Wm) mask |= 1 << t;
           }
         }
+        }
         amask[j] = mask;
-        pa[j] = p.A + (long)m * p.lda + ((kc_pv ^ kc_swz<BK>(row)) << 3);
+        pa[j] = p.A + (long)ml * p.lda + ((kc_pv ^ kc_swz<BK>(row)) << 3);
       }
     }
 #pragma unroll
@@ -246,11 +277,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
     if (FORM != GEMM_TN) {                                       // (tap, channel step) of this workgroup's first K-step
       s_tap = kt_begin / ktiles_per_tap;
       s_c = kt_begin - s_tap * ktiles_per_tap;
-      const int dy = s_tap / 3 - 1, dx = s_tap - (s_tap / 3) * 3 - 1;
-      const int wtap = p.flip ? p.taps - 1 - s_tap : s_tap;
-      ua = (long)(dy * p.Wm + dx) * p.lda + (long)s_c * BK;
-      if (FORM == GEMM_NT) ub = (long)wtap * p.b_tap_stride + (long)s_c * BK;
-      else ub = (long)wtap * p.b_tap_stride + (long)s_c * BK * p.ldb;
+      tap_offsets();
     }
   }
   // CF: move the uniform state to the next K-step (called once all pieces of a step have been issued)
@@ -269,11 +296,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
       }
     } else {
       if (++s_c == ktiles_per_tap) { s_c = 0; ++s_tap; }
-      const int dy = s_tap / 3 - 1, dx = s_tap - (s_tap / 3) * 3 - 1;
-      const int wtap = p.flip ? p.taps - 1 - s_tap : s_tap;
-      ua = (long)(dy * p.Wm + dx) * p.lda + (long)s_c * BK;
-      if (FORM == GEMM_NT) ub = (long)wtap * p.b_tap_stride + (long)s_c * BK;
-      else ub = (long)wtap * p.b_tap_stride + (long)s_c * BK * p.ldb;
+      tap_offsets();
     }
   };
   // FAST: DMA piece `pc` (A chunks first, then B chunks) of the step being staged into ring slot `buf`;
@@ -846,7 +869,7 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
   constexpr bool KS_OK = KSP && FORM != GEMM_TN;     // (the split-K groups exist for the FAST staging of the NT / NN forms)
   if (!CONV && p.K % BK == 0) return launch_k<FORM, false, BN, S, BK, true, NW, KS_OK>(p, st);
   // same-size stride-1 3x3 convolutions (all but the two downsamplers, their transposed dgrads and conv_in)
-  if (CONV && p.taps == 9 && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws && p.K % BK == 0)
+  if (CONV && (p.taps == 9 || p.up2) && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws && p.K % BK == 0)
     return launch_k<FORM, true, BN, S, BK, true, NW, KS_OK>(p, st);
   return launch_k<FORM, CONV, BN, S, BK, false, NW>(p, st);
 }
@@ -1077,6 +1100,12 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
   ARG_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
   ARG_CHECK(p.N % 8 == 0, "gemm: N=%d must be a multiple of 8", p.N);
   ARG_CHECK(p.lda % 8 == 0 && p.ldb % 8 == 0, "gemm: lda=%ld ldb=%ld must be multiples of 8", p.lda, p.ldb);
+  if (p.up2) {
+    ARG_CHECK(p.form != GEMM_TN && p.taps == (p.form == GEMM_NT ? 4 : 16) && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws &&
+              p.K % 64 == 0 && !p.geglu && p.up_plane % 128 == 0 && p.up_rows <= p.up_plane && p.up_rows % (p.Hm * p.Wm) == 0 &&
+              p.M == (p.form == GEMM_NT ? 4 * p.up_plane : p.up_rows),
+              "gemm: up2 needs the fast same-size gather (K %% 64 == 0), taps 4 (NT, M = 4 planes of a multiple of 128 rows) / 16 (NN)");
+  } else
   ARG_CHECK(p.taps == 1 || p.taps == 9, "gemm: taps=%d", p.taps);
   ARG_CHECK(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0 && ((uintptr_t)p.C & 15) == 0,
             "gemm: operands must be 16-byte aligned");
@@ -1088,7 +1117,7 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
     ARG_CHECK(p.K % 8 == 0, "gemm: K=%d must be a multiple of 8", p.K);
     ARG_CHECK(!p.out_f32, "gemm NT/NN: bf16 output");
     // split-K of the bf16-output forms: plain linear problems whose K is a whole number of 64-element steps
-    const bool conv_fast = p.taps == 9 && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws;
+    const bool conv_fast = (p.taps == 9 || p.up2) && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws;
     if (p.splitk > 1 && (!(p.taps == 1 || conv_fast) || p.geglu || p.K % 64 != 0 || p.N % 8 != 0)) p.splitk = 1;
     ARG_CHECK(p.ldc % 8 == 0, "gemm: ldc=%ld must be a multiple of 8", p.ldc);
     if (p.accumulate) { p.resid = (const bf16*)p.C; p.ldr = p.ldc; }
@@ -1137,7 +1166,7 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
     if (p.form != GEMM_TN && p.splitk > p.K / 64 * p.taps) p.splitk = p.K / 64 * p.taps;
     p.slab_ld = p.form == GEMM_TN ? (long)p.N * p.taps : (long)p.N;
   }
-  const bool conv = p.taps == 9;
+  const bool conv = p.taps != 1;
   int rc;
   if (g_sk_mode && !(p.form != GEMM_TN && p.splitk > 1) && (g_sk_mode == 2 ? gemm_sk_applicable(p) : gemm_use_sk(p))) {
     GemmP q = p;
@@ -1198,3 +1227,46 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
   }
   ARG_CHECK(false, "gemm: unknown form %d", p.form);
 }
+
+// ---- 3x3 convolution of a nearest-2x upsampled image without the upsampled image (GemmP::up2) ----
+// x [B][H][W][Cin] low resolution, w [Cout][9][Cin]; weff [Cout][16][Cin] and planar [4][upconv_plane_rows(B, H, W)][Cout] are caller-provided scratch
+// (weff is what the dgrad multiplies by: keep it until then); y [B][2H][2W][Cout].  16 instead of 36 tap-pixels per output pixel quad.
+int launch_upconv3x3_fwd(const bf16* x, const bf16* w, const bf16* bias, bf16* weff, bf16* planar, bf16* y, int B, int H, int W,
+                         int Cin, int Cout, int splitk, float* slab, hipStream_t st) {
+  if (int e = launch_upconv_fold_weights(w, weff, Cout, Cin, st)) return e;
+  GemmP g;
+  gemm_defaults(&g);
+  g.form = GEMM_NT;
+  g.up2 = 1; g.taps = 4;
+  g.A = x; g.B = weff; g.C = planar;
+  g.up_rows = B * H * W; g.up_plane = (int)upconv_plane_rows(B, H, W);
+  g.M = 4 * g.up_plane; g.N = Cout; g.K = Cin;
+  g.lda = Cin; g.ldb = 16L * Cin; g.ldc = Cout;
+  g.Hm = H; g.Wm = W; g.Hs = H; g.Ws = W;
+  g.b_tap_stride = Cin;
+  g.bias = bias;
+  if (splitk > 1) { g.splitk = splitk; g.slab = slab; }
+  if (int e = launch_gemm(g, st)) return e;
+  return launch_pixel_shuffle2(planar, y, B, H, W, Cout, 1, st);
+}
+// dx [B][H][W][Cin] (= resid + ...) from dy [B][2H][2W][Cout]: the high-resolution gradient is de-interleaved into its four phases,
+// one NN product over the 16 (phase, stencil) entries gathers them at the mirrored offsets
+int launch_upconv3x3_dgrad(const bf16* dy, const bf16* weff, bf16* planar, bf16* dx, const bf16* addend, int B, int H, int W, int Cin,
+                           int Cout, int splitk, float* slab, int prio, hipStream_t st) {
+  if (int e = launch_pixel_shuffle2(dy, planar, B, H, W, Cout, 0, st)) return e;
+  GemmP g;
+  gemm_defaults(&g);
+  g.form = GEMM_NN;
+  g.up2 = 1; g.taps = 16;
+  g.A = planar; g.B = weff; g.C = dx;
+  g.up_rows = B * H * W; g.up_plane = (int)upconv_plane_rows(B, H, W);
+  g.M = B * H * W; g.N = Cin; g.K = Cout;
+  g.lda = Cout; g.ldb = 16L * Cin; g.ldc = Cin;
+  g.Hm = H; g.Wm = W; g.Hs = H; g.Ws = W;
+  g.b_tap_stride = Cin;
+  if (addend) { g.resid = addend; g.ldr = Cin; }
+  if (splitk > 1) { g.splitk = splitk; g.slab = slab; }
+  g.prio = prio;
+  return launch_gemm(g, st);
+}
+

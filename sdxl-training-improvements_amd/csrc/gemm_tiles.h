@@ -72,6 +72,9 @@ __device__ __forceinline__ PixRow decode_pix(int m, int Mlimit, int Hm, int Wm) 
   r.x = rem - r.y * Wm;
   return r;
 }
+// GemmP::up2: row / column offset of stencil entry e = 4 (2a + b) + 2u + v on the low-resolution image
+__device__ __forceinline__ int up2_dy(int e) { return ((e >> 1) & 1) - (1 - ((e >> 3) & 1)); }
+__device__ __forceinline__ int up2_dx(int e) { return (e & 1) - (1 - ((e >> 2) & 1)); }
 // source pixel index (in pixels) for tap (dy,dx) or -1
 __device__ __forceinline__ long gather_src(const PixRow& r, int dy, int dx, const GemmP& p) {
   int ys = r.y * p.sm + dy - 1;

@@ -39,6 +39,14 @@ struct GemmP {
   int taps;
   int Hm, Wm, Hs, Ws, sm, sd;
   int flip;            // NT/NN: weight tap index = flip ? 8-tap : tap
+  // up2 (NT / NN, same-size stride-1 gather): a nearest-2x upsampling folded into the 3x3 convolution that follows it.  Output pixel
+  // (2i + a, 2j + b) = phase 2a + b sees a 2 x 2 stencil (u, v) of the LOW-resolution input at (i + u - (1 - a), j + v - (1 - b)) whose
+  // weights are sums of the nine taps (elementwise.hip: launch_upconv_fold_weights): weight entry e = 4 phase + 2u + v of a
+  // [Cout][16][Cin] matrix (ldb = 16 Cin, b_tap_stride = Cin).  NT (forward): taps = 4, M = 4 x up_plane rows in PLANAR phase-major order
+  // (row m: phase m / up_plane, low-resolution pixel m % up_plane; rows >= up_rows of a plane are padding), A = the low-resolution image.  NN (dgrad):
+  // taps = 16, M = up_rows low-resolution pixels, A = the planar phase-major output gradient [4][up_plane][K], gathered at the mirrored offsets.
+  int up2;
+  int up_plane, up_rows;      // up2: rows per phase plane of the planar matrix (a multiple of 128, >= up_rows) and low-resolution pixels B Hm Wm
   long b_tap_stride;   // NT/NN: elements added to B per weight tap
   long c_tap_stride;   // TN: elements added to C per tap
   // epilogue, bf16 output:  C = acc + bias[n] + rowvec[m / rows_per_batch][n] + resid[m][n]
@@ -201,6 +209,14 @@ int launch_concat(const bf16* a, int Ca, const bf16* b, int Cb, bf16* o, long ro
 int launch_split_add(const bf16* g, bf16* ga, int Ca, const bf16* add_a, bf16* gb, int Cb, const bf16* add_b,
                      long rows, hipStream_t st);                                                  // concat backward
 int launch_upsample2x(const bf16* x, bf16* y, int B, int H, int W, int C, hipStream_t st);
+// GemmP::up2 companions: the [Cout][16][Cin] stencil weights of a [Cout][9][Cin] kernel; planar phase-major <-> high-resolution layout
+int launch_upconv_fold_weights(const bf16* w, bf16* weff, int Cout, int Cin, hipStream_t st);
+int launch_pixel_shuffle2(const bf16* src, bf16* dst, int B, int H, int W, int C, int to_hi, hipStream_t st);   // plane stride = upconv_plane_rows
+static inline long upconv_plane_rows(int B, int H, int W) { return ((long)B * H * W + 127) / 128 * 128; }
+int launch_upconv3x3_fwd(const bf16* x, const bf16* w, const bf16* bias, bf16* weff, bf16* planar, bf16* y, int B, int H, int W, int Cin,
+                         int Cout, int splitk, float* slab, hipStream_t st);          // gemm.hip
+int launch_upconv3x3_dgrad(const bf16* dy, const bf16* weff, bf16* planar, bf16* dx, const bf16* addend, int B, int H, int W, int Cin,
+                           int Cout, int splitk, float* slab, int prio, hipStream_t st);
 int launch_upsample2x_bwd(const bf16* dy, bf16* dx, const bf16* addend, int B, int H, int W, int C, hipStream_t st);
 // sinusoidal embedding, cos first: out[r][0:half]=cos(t*f_i), out[r][half:]=sin ; out row stride ldo
 int launch_sincos(const float* t, bf16* out, int rows, int dim, long ldo, hipStream_t st);

@@ -75,6 +75,8 @@ SIGNATURES = {
     "sdxl_op_gemm": [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp],
     "sdxl_op_wgrad_group": [_i, _P(_vp), _P(_vp), _P(_vp), _P(_vp), _i, _i, _i, _i, _vp],
     "sdxl_op_conv3x3_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "sdxl_op_upconv3x3_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "sdxl_op_upconv3x3_dgrad": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "sdxl_op_conv3x3_dgrad": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "sdxl_op_conv3x3_wgrad": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "sdxl_op_conv3x3_wgrad2": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

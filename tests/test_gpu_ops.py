@@ -366,6 +366,29 @@ def test_conv3x3_fwd_dgrad_wgrad(L, B, H, W, Cin, Cout, stride):
         report(f"conv wgrad splitk={splitk}", dw, wr.grad, 1e-4 * math.sqrt(B * Ho * Wo) / 8 + 1e-5)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 16, 16, 128, 64), (4, 32, 32, 1280, 1280), (4, 64, 64, 640, 640), (2, 24, 42, 64, 192), (1, 32, 32, 320, 640)])
+def test_upsample_conv3x3_without_the_upsampled_image(L, B, H, W, Cin, Cout):
+    """conv3x3(nearest-2x(x)) as four 2 x 2 phase stencils on the low-resolution image (GemmP::up2) against conv2d(interpolate(x)) in fp32:
+    forward (+ bias) and the input gradient (+ addend), borders included; the headline shapes of the two up-level transitions."""
+    x = rnd(B, H, W, Cin, seed=20)
+    w = rnd(Cout, 9, Cin, seed=21, scale=(9 * Cin) ** -0.5)
+    bias = rnd(Cout, seed=22)
+    weff = torch.empty(Cout, 16, Cin, dtype=torch.bfloat16, device=dev())
+    planar = torch.empty(4 * ((B * H * W + 127) // 128 * 128), Cout, dtype=torch.bfloat16, device=dev())
+    y = torch.empty(B, 2 * H, 2 * W, Cout, dtype=torch.bfloat16, device=dev())
+    lib.check(L.sdxl_op_upconv3x3_fwd(ptr(x), ptr(w), ptr(bias), ptr(weff), ptr(planar), ptr(y), B, H, W, Cin, Cout, stream()))
+    xr = x.float().requires_grad_(True)
+    up = torch.nn.functional.interpolate(xr.permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest")
+    ref = torch.nn.functional.conv2d(up, w.float().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), bias.float(), padding=1).permute(0, 2, 3, 1)
+    report(f"upconv fwd {B}x{H}x{W} {Cin}->{Cout}", y, ref.detach(), 8e-3)
+    dy = rnd(B, 2 * H, 2 * W, Cout, seed=23)
+    ref.backward(dy.float())
+    addend = rnd(B, H, W, Cin, seed=24)
+    dx = torch.empty(B, H, W, Cin, dtype=torch.bfloat16, device=dev())
+    lib.check(L.sdxl_op_upconv3x3_dgrad(ptr(dy), ptr(weff), ptr(planar), ptr(dx), ptr(addend), B, H, W, Cin, Cout, stream()))
+    report("upconv dgrad", dx, xr.grad + addend.float(), 8e-3)
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 128, 128, 320, 320), (4, 64, 64, 640, 320), (2, 128, 128, 192, 200), (1, 128, 128, 8, 320),
                                             (5, 64, 64, 64, 64),
                                             # W = 32 (the 1280-channel level at 1024^2): a K-step is two image rows, each with its own halo
