@@ -283,6 +283,25 @@ struct ConvOp : Op {
   long rv32_ld = 0;
   size_t dy_off = NONE;
   Plan::GradDst dx, dres, drv;
+  // x is the nearest-2x upsampling of x_low (the `Upsample2D` pair): forward and dgrad run on x_low with 2 x 2 phase stencils
+  // (GemmP::up2, 16 instead of 36 tap-pixels per output quad); the upsampled image is still produced, on the side stream, for the
+  // weight gradient only.  knob 2 = 64: the plain path (A/B runs).
+  Act* x_low = nullptr;
+  Plan::GradDst* up_dx = nullptr;       // the UpsampleOp's input-gradient destination: this op writes it
+  size_t weff_off = NONE, planar_off = NONE;
+  int up_fs = 1, up_ds = 1;
+  bool up2() const { return x_low != nullptr && g_knobs[2] != 64; }
+  void enable_up2(Plan& p, Act* xl, Plan::GradDst* udx) {
+    if (stride != 1 || Cin % 64 || Cout % 64 || resid || rowvec) return;
+    x_low = xl; up_dx = udx;
+    const long plane = upconv_plane_rows(Bn, H / 2, W / 2);
+    weff_off = p.alloc(sizeof(bf16) * (size_t)Cout * 16 * Cin);
+    planar_off = p.alloc(sizeof(bf16) * (size_t)4 * plane * (Cout > Cin ? Cout : Cin));
+    up_fs = gemm_pick_splitk_small((int)(4 * plane), Cout, 4 * Cin, 0);
+    want_slab_main(p, (int)(4 * plane), Cout, up_fs);
+    up_ds = gemm_pick_splitk_small(Bn * (H / 2) * (W / 2), Cin, 16 * Cout, 1);
+    want_slab_main(p, Bn * (H / 2) * (W / 2), Cin, up_ds);
+  }
   ConvOp(Act* x_, Act* y_, PRef w_, PRef b_, int B_, int H_, int W_, int Cin_, int Cout_, int stride_, Act* resid_,
          Act* rowvec_)
       : x(x_), y(y_), resid(resid_), rowvec(rowvec_), w(w_), b(b_), Bn(B_), H(H_), W(W_), Cin(Cin_), Cout(Cout_),
@@ -291,6 +310,9 @@ struct ConvOp : Op {
     Wo = (W - 1) / stride + 1;
   }
   int fwd(Plan& p, hipStream_t st) override {
+    if (up2())
+      return launch_upconv3x3_fwd(p.P(x_low), p.eng->Wp(w), p.eng->Wp(b), (bf16*)p.F(weff_off), (bf16*)p.F(planar_off), p.P(y), Bn, H / 2,
+                                  W / 2, Cin, Cout, up_fs, p.F(p.slab_main_off), st);
     GemmP g;
     gemm_defaults(&g);
     g.form = GEMM_NT;
@@ -352,6 +374,11 @@ struct ConvOp : Op {
       if (drv.addend != NONE) { sdxl_set_error("conv: time-embedding row vector has another gradient writer"); return 3; }
       CHK(launch_colsum_f32_batched(dy, p.F(rv32_off), Bn, Ho * Wo, Cout, Cout, rv32_ld, st));
     }
+    if (x->need_grad && up2()) {      // straight into the low-resolution gradient (the UpsampleOp's backward is a no-op then)
+      CHK(launch_upconv3x3_dgrad(dy, (const bf16*)p.F(weff_off), (bf16*)p.F(planar_off), p.GP(up_dx->out),
+                                 up_dx->addend != NONE ? p.GP(up_dx->addend) : nullptr, Bn, H / 2, W / 2, Cin, Cout, up_ds,
+                                 p.F(p.slab_main_off), g_knobs[0], st));
+    } else
     if (x->need_grad) {
       GemmP g;
       gemm_defaults(&g);
@@ -538,10 +565,20 @@ struct UpsampleOp : Op {
   int Bn, H, W, C;
   size_t dy_off = NONE;
   Plan::GradDst dx;
+  ConvOp* fused = nullptr;     // the convolution that consumes y works on x directly (ConvOp::up2): y is its weight gradient's operand only
   UpsampleOp(Act* x_, Act* y_, int B_, int H_, int W_, int C_) : x(x_), y(y_), Bn(B_), H(H_), W(W_), C(C_) {}
-  int fwd(Plan& p, hipStream_t st) override { return launch_upsample2x(p.P(x), p.P(y), Bn, H, W, C, st); }
+  int fwd(Plan& p, hipStream_t st) override {
+    if (fused && fused->up2() && !p.eng->use_graphs) {   // off the critical stream: nothing reads y before the backward's side-stream weight gradient
+                                                         // (not under graph capture: the forward's capture ends with nothing to join the side stream)
+      const bf16* xp = p.P(x); bf16* yp = p.P(y);
+      const int b = Bn, h = H, w = W, c = C;
+      return on_side(p, st, [=](hipStream_t s2) -> int { return launch_upsample2x(xp, yp, b, h, w, c, s2); });
+    }
+    return launch_upsample2x(p.P(x), p.P(y), Bn, H, W, C, st);
+  }
   void plan_bwd(Plan& p) override { dy_off = y->goff; dx = p.grad_dst(x); }
   int bwd(Plan& p, hipStream_t st, bool) override {
+    if (fused && fused->up2() && y->need_grad) return 0;      // the convolution's dgrad wrote dx
     return launch_upsample2x_bwd(p.GP(dy_off), p.GP(dx.out), p.GP(dx.addend), Bn, H, W, C, st);
   }
 };
@@ -886,13 +923,19 @@ struct Builder {
       }
       if (ui < 2) {
         Act* up = nullptr;
+        UpsampleOp* uop = nullptr;
+        Act* xlow = x;
         if (pl) {
           up = pl->new_act((long)B * 4 * h * w, prev);
-          tagseg(pl->add<UpsampleOp>(x, up, B, h, w, prev), PRef());
+          uop = tagseg(pl->add<UpsampleOp>(x, up, B, h, w, prev), PRef());
         }
         h *= 2;
         w *= 2;
         x = conv(p + ".upsamplers.0.conv", up, h, w, prev, prev, 1, nullptr, nullptr);
+        if (pl) {
+          ConvOp* cop = dynamic_cast<ConvOp*>(pl->ops.back().get());
+          if (cop) { cop->enable_up2(*pl, xlow, &uop->dx); if (cop->x_low) uop->fused = cop; }
+        }
       }
     }
     Act* no = groupnorm("conv_norm_out", x, h * w, prev, c.resnet_eps, 1);
