@@ -170,6 +170,10 @@ int sdxl_op_upconv3x3_fwd(const void* x, const void* w, const void* bias, void* 
                           int Cin, int Cout, void* stream);
 int sdxl_op_upconv3x3_dgrad(const void* dy, const void* weff, void* planar, void* dx, const void* addend, int B, int H, int W, int Cin,
                             int Cout, void* stream);
+/* ... and its weight / bias gradient: `planar` as _dgrad left it (dy de-interleaved into its four phases), x the low-resolution input;
+   dweff [Cout][16][Cin] fp32 scratch; dw [Cout][9][Cin] fp32 (accumulate 0: =, 1: +=), dbias[Cout] += (may be NULL); splitk >= 1. */
+int sdxl_op_upconv3x3_wgrad(const void* planar, const void* x, float* dweff, float* dw, float* dbias, int accumulate, int B, int H,
+                            int W, int Cin, int Cout, int splitk, void* stream);
 int sdxl_op_conv3x3_dgrad(const void* dy, const void* w, void* dx, int B, int H, int W, int Cin, int Cout,
                           int stride, void* stream);
 int sdxl_op_conv3x3_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout,

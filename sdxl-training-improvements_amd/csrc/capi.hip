@@ -656,6 +656,15 @@ int sdxl_op_upconv3x3_dgrad(const void* dy, const void* weff, void* planar, void
   return launch_upconv3x3_dgrad((const bf16*)dy, (const bf16*)weff, (bf16*)planar, (bf16*)dx, (const bf16*)addend, B, H, W, Cin, Cout, splitk,
                                 slab, 0, (hipStream_t)st);
 }
+// the weight / bias gradient of the same pair from `planar` as sdxl_op_upconv3x3_dgrad left it (the de-interleaved dy) and the
+// low-resolution x; dweff [Cout][16][Cin] fp32 scratch; dw [Cout][9][Cin] (= or +=), dbias += (may be NULL)
+int sdxl_op_upconv3x3_wgrad(const void* planar, const void* x, float* dweff, float* dw, float* dbias, int accumulate, int B, int H, int W,
+                            int Cin, int Cout, int splitk, void* st) {
+  float* slab = nullptr;
+  if (splitk > 1) CHK(test_slab(gemm_slab_floats(Cout, Cin, 16, splitk), &slab));
+  return launch_upconv3x3_wgrad((const bf16*)planar, (const bf16*)x, dweff, dw, dbias, nullptr, 1.f, accumulate, B, H, W, Cin, Cout, splitk,
+                                slab, (hipStream_t)st);
+}
 int sdxl_op_conv3x3_dgrad(const void* dy, const void* w, void* dx, int B, int H, int W, int Cin, int Cout, int stride,
                           void* st) {
   int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;

@@ -190,6 +190,42 @@ int launch_upconv_fold_weights(const bf16* w, bf16* weff, int Cout, int Cin, hip
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
+// the transpose of the fold: dW[co][r][c][ci] (=, +=) sum over the four phases of dWeff[co][phase][u(a, r)][v(b, c)][ci]; optionally the
+// bf16 image of the result x scale (the data-parallel exchange arena, as the weight-gradient GEMM epilogues write it)
+__global__ void upconv_unfold_grads_kernel(const float* __restrict__ de, float* dw, bf16* emit, float scale, int accumulate, int Cout, int Cin) {
+  const int vpr = Cin / 4;
+  const long n = (long)Cout * 9 * vpr;
+  VEC_LOOP(i, n) {
+    const int v = (int)(i % vpr);
+    const long t = i / vpr;
+    const int tap = (int)(t % 9);
+    const long co = t / 9;
+    const int r = tap / 3, c = tap - r * 3;
+    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+      const int a = ph >> 1, b = ph & 1;
+      const int u = a == 0 ? (r == 0 ? 0 : 1) : (r == 2 ? 1 : 0), vv = b == 0 ? (c == 0 ? 0 : 1) : (c == 2 ? 1 : 0);
+      const f32x4 g = *(const f32x4*)(de + ((co * 16 + ph * 4 + u * 2 + vv) * Cin) + v * 4);
+      s[0] += g[0]; s[1] += g[1]; s[2] += g[2]; s[3] += g[3];
+    }
+    float* d = dw + i * 4;
+    if (accumulate) { const f32x4 o = *(const f32x4*)d; s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3]; }
+    *(f32x4*)d = s;
+    if (emit) {
+      bf16x4 o;
+      o[0] = (bf16)(s[0] * scale); o[1] = (bf16)(s[1] * scale); o[2] = (bf16)(s[2] * scale); o[3] = (bf16)(s[3] * scale);
+      *(bf16x4*)(emit + i * 4) = o;
+    }
+  }
+}
+int launch_upconv_unfold_grads(const float* dweff, float* dw, bf16* emit, float emit_scale, int accumulate, int Cout, int Cin, hipStream_t st) {
+  ARG_CHECK(Cin % 4 == 0, "upconv: Cin=%d", Cin);
+  const long nv = (long)Cout * 9 * (Cin / 4);
+  hipLaunchKernelGGL(upconv_unfold_grads_kernel, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, dweff, dw, emit, emit_scale, accumulate, Cout, Cin);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
 // planar phase-major [4][plane rows >= B H W][C] <-> token-major high resolution [B][2H][2W][C] (TO_HI: planar -> high resolution)
 template <bool TO_HI>
 __global__ void pixel_shuffle2_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int B, int H, int W, int C, long plane) {

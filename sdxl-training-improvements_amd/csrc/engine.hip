@@ -288,8 +288,9 @@ struct ConvOp : Op {
   // weight gradient only.  knob 2 = 64: the plain path (A/B runs).
   Act* x_low = nullptr;
   Plan::GradDst* up_dx = nullptr;       // the UpsampleOp's input-gradient destination: this op writes it
-  size_t weff_off = NONE, planar_off = NONE;
-  int up_fs = 1, up_ds = 1;
+  size_t weff_off = NONE, planar_off = NONE, dweff_off = NONE;
+  int up_fs = 1, up_ds = 1, up_ws = 1;
+  bool up_wg = false;       // the weight gradient too (needs whole 64-pixel reduction steps): the upsampled image is then not produced at all
   bool up2() const { return x_low != nullptr && g_knobs[2] != 64; }
   void enable_up2(Plan& p, Act* xl, Plan::GradDst* udx) {
     if (stride != 1 || Cin % 64 || Cout % 64 || resid || rowvec) return;
@@ -301,6 +302,12 @@ struct ConvOp : Op {
     want_slab_main(p, (int)(4 * plane), Cout, up_fs);
     up_ds = gemm_pick_splitk_small(Bn * (H / 2) * (W / 2), Cin, 16 * Cout, 1);
     want_slab_main(p, Bn * (H / 2) * (W / 2), Cin, up_ds);
+    up_wg = (Bn * (H / 2) * (W / 2)) % 64 == 0;
+    if (up_wg) {
+      dweff_off = p.alloc(sizeof(float) * (size_t)Cout * 16 * Cin);
+      up_ws = pick_splitk(Cout, Cin, 16, (long)Bn * (H / 2) * (W / 2));
+      want_slab(p, Cout, Cin, 16, up_ws);
+    }
   }
   ConvOp(Act* x_, Act* y_, PRef w_, PRef b_, int B_, int H_, int W_, int Cin_, int Cout_, int stride_, Act* resid_,
          Act* rowvec_)
@@ -352,6 +359,15 @@ struct ConvOp : Op {
     const bf16* dy = p.GP(dy_off);
     const long Mo = (long)Bn * Ho * Wo;
     if (resid && !resid_alias) CHK(launch_add(p.GP(dres.addend), dy, p.GP(dres.out), Mo * Cout, st));
+    const bool upw = up2() && up_wg && g_knobs[2] != 128;       // (knob 2 = 128: weight gradient on the upsampled image, A/B runs)
+    if (up2()) CHK(launch_pixel_shuffle2(dy, (bf16*)p.F(planar_off), Bn, H / 2, W / 2, Cout, 0, st));      // dy in its four phases: dgrad and weight gradient read it
+    if (upw) {
+      CHK(on_side(p, st, [&](hipStream_t s2) -> int {
+        return launch_upconv3x3_wgrad((const bf16*)p.F(planar_off), p.P(x_low), p.F(dweff_off), p.eng->Gp(w), p.eng->Gp(b),
+                                      p.eng->emit_base ? p.eng->emit_base + w.off : nullptr, p.eng->emit_scale, first ? 0 : 1, Bn, H / 2, W / 2,
+                                      Cin, Cout, up_ws, p.F(p.slab_off), s2);
+      }));
+    } else
     CHK(on_side(p, st, [&](hipStream_t s2) -> int {
       GemmP g;
       gemm_defaults(&g);
@@ -375,7 +391,7 @@ struct ConvOp : Op {
       CHK(launch_colsum_f32_batched(dy, p.F(rv32_off), Bn, Ho * Wo, Cout, Cout, rv32_ld, st));
     }
     if (x->need_grad && up2()) {      // straight into the low-resolution gradient (the UpsampleOp's backward is a no-op then)
-      CHK(launch_upconv3x3_dgrad(dy, (const bf16*)p.F(weff_off), (bf16*)p.F(planar_off), p.GP(up_dx->out),
+      CHK(launch_upconv3x3_dgrad(nullptr, (const bf16*)p.F(weff_off), (bf16*)p.F(planar_off), p.GP(up_dx->out),
                                  up_dx->addend != NONE ? p.GP(up_dx->addend) : nullptr, Bn, H / 2, W / 2, Cin, Cout, up_ds,
                                  p.F(p.slab_main_off), g_knobs[0], st));
     } else
@@ -568,6 +584,7 @@ struct UpsampleOp : Op {
   ConvOp* fused = nullptr;     // the convolution that consumes y works on x directly (ConvOp::up2): y is its weight gradient's operand only
   UpsampleOp(Act* x_, Act* y_, int B_, int H_, int W_, int C_) : x(x_), y(y_), Bn(B_), H(H_), W(W_), C(C_) {}
   int fwd(Plan& p, hipStream_t st) override {
+    if (fused && fused->up2() && fused->up_wg && g_knobs[2] != 128) return 0;      // nothing reads y
     if (fused && fused->up2() && !p.eng->use_graphs) {   // off the critical stream: nothing reads y before the backward's side-stream weight gradient
                                                          // (not under graph capture: the forward's capture ends with nothing to join the side stream)
       const bf16* xp = p.P(x); bf16* yp = p.P(y);

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
   int by_[BCH], bx_[BCH];    // CF, TN: (y, x) of the pixel this lane gathers at the step being staged
   long ua = 0, ub = 0;       // CF: uniform element offsets of the step being staged
   int s_tap = 0, s_c = 0;    // CF, NT / NN: (tap, channel step) of the step being staged
-  const int tdy = tap_fixed / 3 - 1, tdx = tap_fixed - (tap_fixed / 3) * 3 - 1;   // CF, TN: this workgroup's tap
+  const int tdy = p.up2 ? up2_dy(tap_fixed) : tap_fixed / 3 - 1, tdx = p.up2 ? up2_dx(tap_fixed) : tap_fixed - (tap_fixed / 3) * 3 - 1;   // CF, TN: this workgroup's tap
   const int up_phase = (CF && FORM == GEMM_NT && p.up2) ? m0 / p.up_plane : 0;      // up2, NT: this workgroup's output phase
   // CF, NT / NN: uniform element offsets of (tap s_tap, channel step s_c)
   auto tap_offsets = [&]() {
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
         const int krow = c * 4 + (lane >> 4);
         const int m = m0 + (nc_logical<128>(krow, lane & 15) << 3);
         amask[j] = (c < NCA && m < p.M) ? 1 : 0;
-        pa[j] = p.A + ((long)kt_begin * BK + krow) * p.lda + m;
+        pa[j] = p.A + ((long)kt_begin * BK + krow + (p.up2 ? (long)(tap_fixed >> 2) * p.up_plane : 0)) * p.lda + m;      // (up2: the phase plane of dY)
       } else {
         const int row = c * KC_ROWS + kc_rowl;
         const int m = m0 + row;
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
     for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // bias gradient (TN): column sums of the A operand = A^T . ones, on the matrix pipe, by one wave column of the
   // workgroups that own n-tile 0 (and tap 0)
-  const bool do_bias = FORM == GEMM_TN && p.bias_grad != nullptr && bx == 0 && tap_fixed == 0 && wn == 0;
+  const bool do_bias = FORM == GEMM_TN && p.bias_grad != nullptr && bx == 0 && (p.up2 ? (tap_fixed & 3) == 0 : tap_fixed == 0) && wn == 0;      // (up2: once per phase plane)
   f32x4 accb[MI];
   bf16x8 ones;
 #pragma unroll
@@ -1101,10 +1101,10 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
   ARG_CHECK(p.N % 8 == 0, "gemm: N=%d must be a multiple of 8", p.N);
   ARG_CHECK(p.lda % 8 == 0 && p.ldb % 8 == 0, "gemm: lda=%ld ldb=%ld must be multiples of 8", p.lda, p.ldb);
   if (p.up2) {
-    ARG_CHECK(p.form != GEMM_TN && p.taps == (p.form == GEMM_NT ? 4 : 16) && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws &&
-              p.K % 64 == 0 && !p.geglu && p.up_plane % 128 == 0 && p.up_rows <= p.up_plane && p.up_rows % (p.Hm * p.Wm) == 0 &&
-              p.M == (p.form == GEMM_NT ? 4 * p.up_plane : p.up_rows),
-              "gemm: up2 needs the fast same-size gather (K %% 64 == 0), taps 4 (NT, M = 4 planes of a multiple of 128 rows) / 16 (NN)");
+    ARG_CHECK(p.taps == (p.form == GEMM_NT ? 4 : 16) && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws &&
+              p.K % 64 == 0 && !p.geglu && p.group <= 1 && p.up_plane % 128 == 0 && p.up_rows <= p.up_plane && p.up_rows % (p.Hm * p.Wm) == 0 &&
+              (p.form == GEMM_NT ? p.M == 4 * p.up_plane : p.form == GEMM_NN ? p.M == p.up_rows : p.K == p.up_rows),
+              "gemm: up2 needs the fast same-size gather (reduction %% 64 == 0), taps 4 (NT, M = 4 planes of a multiple of 128 rows) / 16 (NN, TN)");
   } else
   ARG_CHECK(p.taps == 1 || p.taps == 9, "gemm: taps=%d", p.taps);
   ARG_CHECK(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0 && ((uintptr_t)p.C & 15) == 0,
@@ -1253,7 +1253,7 @@ int launch_upconv3x3_fwd(const bf16* x, const bf16* w, const bf16* bias, bf16* w
 // one NN product over the 16 (phase, stencil) entries gathers them at the mirrored offsets
 int launch_upconv3x3_dgrad(const bf16* dy, const bf16* weff, bf16* planar, bf16* dx, const bf16* addend, int B, int H, int W, int Cin,
                            int Cout, int splitk, float* slab, int prio, hipStream_t st) {
-  if (int e = launch_pixel_shuffle2(dy, planar, B, H, W, Cout, 0, st)) return e;
+  if (dy) { if (int e = launch_pixel_shuffle2(dy, planar, B, H, W, Cout, 0, st)) return e; }      // (dy == nullptr: `planar` is ready)
   GemmP g;
   gemm_defaults(&g);
   g.form = GEMM_NN;
@@ -1270,3 +1270,26 @@ int launch_upconv3x3_dgrad(const bf16* dy, const bf16* weff, bf16* planar, bf16*
   return launch_gemm(g, st);
 }
 
+
+// dW [Cout][9][Cin] (fp32, = or +=; optionally also bf16 x scale into `emit`) and dbias from dy [B][2H][2W][Cout] ALREADY de-interleaved
+// into `planar` (launch_upconv3x3_dgrad does that) and the low-resolution x: 16 (phase, stencil) products into dweff [Cout][16][Cin]
+// fp32 scratch, folded back onto the nine taps
+int launch_upconv3x3_wgrad(const bf16* planar, const bf16* x, float* dweff, float* dw, float* dbias, bf16* emit, float emit_scale,
+                           int accumulate, int B, int H, int W, int Cin, int Cout, int splitk, float* slab, hipStream_t st) {
+  GemmP g;
+  gemm_defaults(&g);
+  g.form = GEMM_TN;
+  g.up2 = 1; g.taps = 16;
+  g.up_rows = B * H * W; g.up_plane = (int)upconv_plane_rows(B, H, W);
+  g.A = planar; g.B = x; g.C = dweff;
+  g.M = Cout; g.N = Cin; g.K = B * H * W;
+  g.lda = Cout; g.ldb = Cin; g.ldc = 16L * Cin;
+  g.Hm = H; g.Wm = W; g.Hs = H; g.Ws = W;
+  g.c_tap_stride = Cin;
+  g.out_f32 = 1;
+  g.splitk = splitk < 1 ? 1 : splitk;
+  g.slab = slab;
+  g.bias_grad = dbias;
+  if (int e = launch_gemm(g, st)) return e;
+  return launch_upconv_unfold_grads(dweff, dw, emit, emit_scale, accumulate, Cout, Cin, st);
+}

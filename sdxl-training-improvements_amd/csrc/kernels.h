@@ -215,6 +215,9 @@ int launch_pixel_shuffle2(const bf16* src, bf16* dst, int B, int H, int W, int C
 static inline long upconv_plane_rows(int B, int H, int W) { return ((long)B * H * W + 127) / 128 * 128; }
 int launch_upconv3x3_fwd(const bf16* x, const bf16* w, const bf16* bias, bf16* weff, bf16* planar, bf16* y, int B, int H, int W, int Cin,
                          int Cout, int splitk, float* slab, hipStream_t st);          // gemm.hip
+int launch_upconv_unfold_grads(const float* dweff, float* dw, bf16* emit, float emit_scale, int accumulate, int Cout, int Cin, hipStream_t st);
+int launch_upconv3x3_wgrad(const bf16* planar, const bf16* x, float* dweff, float* dw, float* dbias, bf16* emit, float emit_scale,
+                           int accumulate, int B, int H, int W, int Cin, int Cout, int splitk, float* slab, hipStream_t st);
 int launch_upconv3x3_dgrad(const bf16* dy, const bf16* weff, bf16* planar, bf16* dx, const bf16* addend, int B, int H, int W, int Cin,
                            int Cout, int splitk, float* slab, int prio, hipStream_t st);
 int launch_upsample2x_bwd(const bf16* dy, bf16* dx, const bf16* addend, int B, int H, int W, int C, hipStream_t st);

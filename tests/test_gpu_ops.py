@@ -366,7 +366,7 @@ def test_conv3x3_fwd_dgrad_wgrad(L, B, H, W, Cin, Cout, stride):
         report(f"conv wgrad splitk={splitk}", dw, wr.grad, 1e-4 * math.sqrt(B * Ho * Wo) / 8 + 1e-5)
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 16, 16, 128, 64), (4, 32, 32, 1280, 1280), (4, 64, 64, 640, 640), (2, 24, 42, 64, 192), (1, 32, 32, 320, 640)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 16, 16, 128, 64), (4, 32, 32, 1280, 1280), (4, 64, 64, 640, 640), (2, 24, 42, 64, 192), (4, 24, 42, 128, 64), (1, 32, 32, 320, 640)])
 def test_upsample_conv3x3_without_the_upsampled_image(L, B, H, W, Cin, Cout):
     """conv3x3(nearest-2x(x)) as four 2 x 2 phase stencils on the low-resolution image (GemmP::up2) against conv2d(interpolate(x)) in fp32:
     forward (+ bias) and the input gradient (+ addend), borders included; the headline shapes of the two up-level transitions."""
@@ -387,6 +387,21 @@ def test_upsample_conv3x3_without_the_upsampled_image(L, B, H, W, Cin, Cout):
     dx = torch.empty(B, H, W, Cin, dtype=torch.bfloat16, device=dev())
     lib.check(L.sdxl_op_upconv3x3_dgrad(ptr(dy), ptr(weff), ptr(planar), ptr(dx), ptr(addend), B, H, W, Cin, Cout, stream()))
     report("upconv dgrad", dx, xr.grad + addend.float(), 8e-3)
+    if (B * H * W) % 64:          # the weight-gradient form needs whole 64-pixel reduction steps (the plan falls back to the plain path otherwise)
+        return
+    wr = w.float().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    br = bias.float().clone().requires_grad_(True)
+    torch.nn.functional.conv2d(torch.nn.functional.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest"), wr, br,
+                               padding=1).backward(dy.float().permute(0, 3, 1, 2))
+    dw_ref = wr.grad.permute(0, 2, 3, 1).reshape(Cout, 9, Cin)
+    dweff = torch.empty(Cout, 16, Cin, dtype=torch.float32, device=dev())
+    for splitk, acc in ((1, 0), (3, 1)):
+        base = torch.randn(Cout, 9, Cin, device=dev()) if acc else torch.zeros(Cout, 9, Cin, device=dev())
+        dw = base.clone()
+        db = torch.zeros(Cout, dtype=torch.float32, device=dev())
+        lib.check(L.sdxl_op_upconv3x3_wgrad(ptr(planar), ptr(x), ptr(dweff), ptr(dw), ptr(db), acc, B, H, W, Cin, Cout, splitk, stream()))
+        report(f"upconv wgrad splitk={splitk} acc={acc}", dw - base, dw_ref, 1e-4 * math.sqrt(4 * B * H * W) / 8 + 1e-5)
+        report("upconv bias grad", db, br.grad, 1e-4 * math.sqrt(4 * B * H * W) / 8 + 1e-5)
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 128, 128, 320, 320), (4, 64, 64, 640, 320), (2, 128, 128, 192, 200), (1, 128, 128, 8, 320),
