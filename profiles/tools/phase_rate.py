@@ -26,7 +26,7 @@ for r in rows:
         if f == 'G':
             form, taps, M, N, K, sk, grp = map(int, rec[1:8])
             fl = 2.0 * M * N * K * taps * grp
-            lab = f"{['NT','NN','TN'][form]}{'9' if taps == 9 else ''} {M}x{N}x{K}" + (f" g{grp}" if grp > 1 else "")
+            lab = f"{['NT','NN','TN'][form]}{taps if taps > 1 else ''} {M}x{N}x{K}" + (f" g{grp}" if grp > 1 else "")      # (taps 4 / 16: GemmP::up2)
         else:
             kind, B, H, Nq, Nk = map(int, rec[1:6])
             fl = 4.0 * B * H * Nq * Nk * 64 * {0: 1.0, 1: 1.5, 2: 2.0}[kind]      # executed: 2 / 3 / 4 products of Nq x Nk x 64
