@@ -170,6 +170,11 @@ int sdxl_op_upconv3x3_fwd(const void* x, const void* w, const void* bias, void* 
                           int Cin, int Cout, void* stream);
 int sdxl_op_upconv3x3_dgrad(const void* dy, const void* weff, void* planar, void* dx, const void* addend, int B, int H, int W, int Cin,
                             int Cout, void* stream);
+/* Input gradient of the stride-2 3x3 convolution (the two `Downsample2D` convs; pad 1, H and W even) by output phase: input pixel
+   (2r + a, 2c + b) receives 1 / 2 / 2 / 4 of the nine taps.  dy [B][H/2][W/2][Cout], w [Cout][9][Cin], dx [B][H][W][Cin] = addend
+   (may be NULL) + gradient; planar [4 * roundup(B*(H/2)*(W/2), 128)][Cin] bf16 scratch. */
+int sdxl_op_conv3x3_s2_dgrad(const void* dy, const void* w, void* planar, void* dx, const void* addend, int B, int H, int W, int Cin,
+                             int Cout, void* stream);
 /* ... and its weight / bias gradient: `planar` as _dgrad left it (dy de-interleaved into its four phases), x the low-resolution input;
    dweff [Cout][16][Cin] fp32 scratch; dw [Cout][9][Cin] fp32 (accumulate 0: =, 1: +=), dbias[Cout] += (may be NULL); splitk >= 1. */
 int sdxl_op_upconv3x3_wgrad(const void* planar, const void* x, float* dweff, float* dw, float* dbias, int accumulate, int B, int H,

@@ -656,6 +656,12 @@ int sdxl_op_upconv3x3_dgrad(const void* dy, const void* weff, void* planar, void
   return launch_upconv3x3_dgrad((const bf16*)dy, (const bf16*)weff, (bf16*)planar, (bf16*)dx, (const bf16*)addend, B, H, W, Cin, Cout, splitk,
                                 slab, 0, (hipStream_t)st);
 }
+// input gradient of the stride-2 3x3 convolution by output phase (GemmP::up2 == 2); planar [4 * roundup(B*(H/2)*(W/2), 128)][Cin] scratch
+int sdxl_op_conv3x3_s2_dgrad(const void* dy, const void* w, void* planar, void* dx, const void* addend, int B, int H, int W, int Cin,
+                             int Cout, void* st) {
+  return launch_conv3x3_s2_dgrad((const bf16*)dy, (const bf16*)w, (bf16*)planar, (bf16*)dx, (const bf16*)addend, B, H, W, Cin, Cout, 0,
+                                 (hipStream_t)st);
+}
 // the weight / bias gradient of the same pair from `planar` as sdxl_op_upconv3x3_dgrad left it (the de-interleaved dy) and the
 // low-resolution x; dweff [Cout][16][Cin] fp32 scratch; dw [Cout][9][Cin] (= or +=), dbias += (may be NULL)
 int sdxl_op_upconv3x3_wgrad(const void* planar, const void* x, float* dweff, float* dw, float* dbias, int accumulate, int B, int H, int W,

@@ -228,7 +228,7 @@ int launch_upconv_unfold_grads(const float* dweff, float* dw, bf16* emit, float 
 }
 // planar phase-major [4][plane rows >= B H W][C] <-> token-major high resolution [B][2H][2W][C] (TO_HI: planar -> high resolution)
 template <bool TO_HI>
-__global__ void pixel_shuffle2_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int B, int H, int W, int C, long plane) {
+__global__ void pixel_shuffle2_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int B, int H, int W, int C, long plane, const bf16* addend) {
   const int vpr = C / 8;
   const long n = (long)B * 4 * H * W * vpr;
   VEC_LOOP(i, n) {                                   // i runs over the high-resolution tensor
@@ -240,15 +240,23 @@ __global__ void pixel_shuffle2_kernel(const bf16* __restrict__ src, bf16* __rest
     const int b = (int)(t / (2 * H));
     const int ph = (yo & 1) * 2 + (xo & 1);
     const long pl = (long)ph * plane + ((long)b * H + (yo >> 1)) * W + (xo >> 1);
-    if (TO_HI) *(bf16x8*)(dst + i * 8) = *(const bf16x8*)(src + pl * C + v * 8);
+    if (TO_HI) {
+      bf16x8 o = *(const bf16x8*)(src + pl * C + v * 8);
+      if (addend) {
+        const bf16x8 ad = *(const bf16x8*)(addend + i * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (bf16)((float)o[k] + (float)ad[k]);
+      }
+      *(bf16x8*)(dst + i * 8) = o;
+    }
     else *(bf16x8*)(dst + pl * C + v * 8) = *(const bf16x8*)(src + i * 8);
   }
 }
-int launch_pixel_shuffle2(const bf16* src, bf16* dst, int B, int H, int W, int C, int to_hi, hipStream_t st) {
+int launch_pixel_shuffle2(const bf16* src, bf16* dst, int B, int H, int W, int C, int to_hi, hipStream_t st, const bf16* addend) {
   ARG_CHECK(C % 8 == 0, "pixel shuffle: C=%d", C);
   const long nv = (long)B * 4 * H * W * (C / 8);
-  if (to_hi) hipLaunchKernelGGL(pixel_shuffle2_kernel<true>, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, src, dst, B, H, W, C, upconv_plane_rows(B, H, W));
-  else hipLaunchKernelGGL(pixel_shuffle2_kernel<false>, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, src, dst, B, H, W, C, upconv_plane_rows(B, H, W));
+  if (to_hi) hipLaunchKernelGGL(pixel_shuffle2_kernel<true>, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, src, dst, B, H, W, C, upconv_plane_rows(B, H, W), addend);
+  else hipLaunchKernelGGL(pixel_shuffle2_kernel<false>, dim3(ew_grid(nv)), dim3(EW_BLOCK), 0, st, src, dst, B, H, W, C, upconv_plane_rows(B, H, W), addend);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

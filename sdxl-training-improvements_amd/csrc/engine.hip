@@ -289,6 +289,7 @@ struct ConvOp : Op {
   Act* x_low = nullptr;
   Plan::GradDst* up_dx = nullptr;       // the UpsampleOp's input-gradient destination: this op writes it
   size_t weff_off = NONE, planar_off = NONE, dweff_off = NONE;
+  size_t s2_planar_off = NONE;     // stride 2: the input gradient by output phase (GemmP::up2 == 2; knob 2 = 256: the general gather)
   int up_fs = 1, up_ds = 1, up_ws = 1;
   bool up_wg = false;       // the weight gradient too (needs whole 64-pixel reduction steps): the upsampled image is then not produced at all
   bool up2() const { return x_low != nullptr && g_knobs[2] != 64; }
@@ -346,6 +347,8 @@ struct ConvOp : Op {
       rv32_ld = rowvec->ld();
     }
     if (x->need_grad) dx = p.grad_dst(x);
+    if (x->need_grad && stride == 2 && H % 2 == 0 && W % 2 == 0 && Cout % 64 == 0 && Cin % 8 == 0)
+      s2_planar_off = p.alloc(sizeof(bf16) * (size_t)4 * upconv_plane_rows(Bn, Ho, Wo) * Cin);
     splitk = pick_splitk(Cout, Cin, 9, (long)Bn * Ho * Wo);
     if (conv_wgrad3_policy(Cout, Cin, (long)Bn * Ho * Wo, Wo, stride)) splitk = conv_wgrad3_pick_splitk(Cout, Cin, (long)Bn * Ho * Wo);
     want_slab(p, Cout, Cin, 9, splitk);
@@ -390,6 +393,10 @@ struct ConvOp : Op {
       if (drv.addend != NONE) { sdxl_set_error("conv: time-embedding row vector has another gradient writer"); return 3; }
       CHK(launch_colsum_f32_batched(dy, p.F(rv32_off), Bn, Ho * Wo, Cout, Cout, rv32_ld, st));
     }
+    if (x->need_grad && s2_planar_off != NONE && g_knobs[2] != 256) {
+      CHK(launch_conv3x3_s2_dgrad(dy, p.eng->Wp(w), (bf16*)p.F(s2_planar_off), p.GP(dx.out), dx.addend != NONE ? p.GP(dx.addend) : nullptr, Bn, H, W,
+                                  Cin, Cout, g_knobs[0], st));
+    } else
     if (x->need_grad && up2()) {      // straight into the low-resolution gradient (the UpsampleOp's backward is a no-op then)
       CHK(launch_upconv3x3_dgrad(nullptr, (const bf16*)p.F(weff_off), (bf16*)p.F(planar_off), p.GP(up_dx->out),
                                  up_dx->addend != NONE ? p.GP(up_dx->addend) : nullptr, Bn, H / 2, W / 2, Cin, Cout, up_ds,

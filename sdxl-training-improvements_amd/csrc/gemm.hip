@@ -125,6 +125,10 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
   } else {
     kt_end = ktiles_per_tap * p.taps;
   }
+  // up2 == 2 (NN: input gradient of a stride-2 3x3 convolution by output phase): this workgroup's phase has 1, 2, 2 or 4 taps
+  const int dn_phase = (FORM == GEMM_NN && CONV && p.up2 == 2) ? m0 / p.up_plane : 0;
+  const int dn_nb = (dn_phase & 1) ? 2 : 1;
+  if (FORM == GEMM_NN && CONV && p.up2 == 2) kt_end = ktiles_per_tap * ((dn_phase >> 1) ? 2 : 1) * dn_nb;
 
   // ---- per-lane LDS-DMA descriptors ----
   // K-contiguous tile: chunk c = rows KC_ROWS*c .. ; lane -> row KC_ROWS*c + lane/VR, physical vector lane%VR
@@ -153,11 +157,18 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
   long ua = 0, ub = 0;       // CF: uniform element offsets of the step being staged
   int s_tap = 0, s_c = 0;    // CF, NT / NN: (tap, channel step) of the step being staged
   const int tdy = p.up2 ? up2_dy(tap_fixed) : tap_fixed / 3 - 1, tdx = p.up2 ? up2_dx(tap_fixed) : tap_fixed - (tap_fixed / 3) * 3 - 1;   // CF, TN: this workgroup's tap
-  const int up_phase = (CF && FORM == GEMM_NT && p.up2) ? m0 / p.up_plane : 0;      // up2, NT: this workgroup's output phase
+  const int up_phase = (CF && FORM == GEMM_NT && p.up2) ? m0 / p.up_plane : dn_phase;      // up2, NT (and NN of mode 2): this workgroup's output phase
   // CF, NT / NN: uniform element offsets of (tap s_tap, channel step s_c)
   auto tap_offsets = [&]() {
     int dy, dx, wtap;
     long plane = 0;
+    if (FORM == GEMM_NN && p.up2 == 2) {         // tap s_tap of phase (a, b): (ry, rx) over the rows / columns that reach this phase
+      const int a = dn_phase >> 1, b = dn_phase & 1;
+      const int ry = s_tap / dn_nb, rx = s_tap - ry * dn_nb;
+      const int ky = a ? (ry == 0 ? 0 : 2) : 1, kx = b ? (rx == 0 ? 0 : 2) : 1;       // kernel row / column
+      dy = a ? (ry == 0 ? 1 : 0) : 0; dx = b ? (rx == 0 ? 1 : 0) : 0;                   // offset on the low-resolution gradient image
+      wtap = ky * 3 + kx;
+    } else
     if (p.up2) {
       const int e = FORM == GEMM_NT ? up_phase * 4 + s_tap : s_tap;
       dy = up2_dy(e); dx = up2_dx(e); wtap = e;
@@ -230,8 +241,16 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
               if (t >= p.taps) break;
-              const int e = FORM == GEMM_NT ? up_phase * 4 + t : t;
-              const int ys = FORM == GEMM_NT ? r.y + up2_dy(e) : r.y - up2_dy(e), xs = FORM == GEMM_NT ? r.x + up2_dx(e) : r.x - up2_dx(e);
+              int ys, xs;
+              if (FORM == GEMM_NN && p.up2 == 2) {
+                const int ry = t / dn_nb, rx = t - ry * dn_nb;
+                ys = r.y + ((dn_phase >> 1) ? (ry == 0 ? 1 : 0) : 0);
+                xs = r.x + ((dn_phase & 1) ? (rx == 0 ? 1 : 0) : 0);
+              } else {
+                const int e = FORM == GEMM_NT ? up_phase * 4 + t : t;
+                ys = FORM == GEMM_NT ? r.y + up2_dy(e) : r.y - up2_dy(e);
+                xs = FORM == GEMM_NT ? r.x + up2_dx(e) : r.x - up2_dx(e);
+              }
               if (ys >= 0 && ys < p.Hm && xs >= 0 && xs < p.Wm) mask |= 1 << t;
             }
           }
@@ -1090,7 +1109,7 @@ int launch_gemm(const GemmP& p, hipStream_t st) {
   int rc = launch_gemm_impl(p, st);
   HIP_CHECK_RET(hipEventRecord(g_prof.ev[g_prof.used + 1], st));
   g_prof.used += 2;
-  g_prof.flops.push_back(2.0 * (double)p.M * (double)p.N * (double)p.K * (double)p.taps * (p.group > 1 ? p.group : 1));
+  g_prof.flops.push_back(2.0 * (double)p.M * (double)p.N * (double)p.K * (p.up2 == 2 ? 2.25 : (double)p.taps) * (p.group > 1 ? p.group : 1));      // (up2 == 2: 1 + 2 + 2 + 4 taps over four planes)
   g_prof.recs.push_back({p.form, p.taps, p.M, p.N, p.K, p.splitk});
   return rc;
 }
@@ -1101,9 +1120,10 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
   ARG_CHECK(p.N % 8 == 0, "gemm: N=%d must be a multiple of 8", p.N);
   ARG_CHECK(p.lda % 8 == 0 && p.ldb % 8 == 0, "gemm: lda=%ld ldb=%ld must be multiples of 8", p.lda, p.ldb);
   if (p.up2) {
-    ARG_CHECK(p.taps == (p.form == GEMM_NT ? 4 : 16) && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws &&
+    ARG_CHECK(p.taps == (p.form == GEMM_NT || p.up2 == 2 ? 4 : 16) && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws &&
               p.K % 64 == 0 && !p.geglu && p.group <= 1 && p.up_plane % 128 == 0 && p.up_rows <= p.up_plane && p.up_rows % (p.Hm * p.Wm) == 0 &&
-              (p.form == GEMM_NT ? p.M == 4 * p.up_plane : p.form == GEMM_NN ? p.M == p.up_rows : p.K == p.up_rows),
+              (p.up2 == 2 ? (p.form == GEMM_NN && p.M == 4 * p.up_plane && p.splitk <= 1)
+                          : p.form == GEMM_NT ? p.M == 4 * p.up_plane : p.form == GEMM_NN ? p.M == p.up_rows : p.K == p.up_rows),
               "gemm: up2 needs the fast same-size gather (reduction %% 64 == 0), taps 4 (NT, M = 4 planes of a multiple of 128 rows) / 16 (NN, TN)");
   } else
   ARG_CHECK(p.taps == 1 || p.taps == 9, "gemm: taps=%d", p.taps);
@@ -1292,4 +1312,27 @@ int launch_upconv3x3_wgrad(const bf16* planar, const bf16* x, float* dweff, floa
   g.bias_grad = dbias;
   if (int e = launch_gemm(g, st)) return e;
   return launch_upconv_unfold_grads(dweff, dw, emit, emit_scale, accumulate, Cout, Cin, st);
+}
+
+// dx [B][H][W][Cin] (= addend + ...) of a stride-2 3x3 convolution (pad 1, H and W even) from dy [B][H/2][W/2][Cout]: input pixel
+// (2r + a, 2c + b) only receives the taps whose parity matches -- 1, 2, 2, 4 of the nine for the four phases (9 / 4 per pixel instead
+// of 9 masked ones through the general gather): one NN launch over the four phase planes into `planar` [4][plane][Cin], then the
+// pixel shuffle (+ addend) into dx.  w [Cout][9][Cin] as the forward uses it.
+int launch_conv3x3_s2_dgrad(const bf16* dy, const bf16* w, bf16* planar, bf16* dx, const bf16* addend, int B, int H, int W, int Cin,
+                            int Cout, int prio, hipStream_t st) {
+  ARG_CHECK(H % 2 == 0 && W % 2 == 0, "stride-2 dgrad by phases: H=%d W=%d must be even", H, W);
+  const int Hl = H / 2, Wl = W / 2;
+  GemmP g;
+  gemm_defaults(&g);
+  g.form = GEMM_NN;
+  g.up2 = 2; g.taps = 4;
+  g.up_rows = B * Hl * Wl; g.up_plane = (int)upconv_plane_rows(B, Hl, Wl);
+  g.A = dy; g.B = w; g.C = planar;
+  g.M = 4 * g.up_plane; g.N = Cin; g.K = Cout;
+  g.lda = Cout; g.ldb = 9L * Cin; g.ldc = Cin;
+  g.Hm = Hl; g.Wm = Wl; g.Hs = Hl; g.Ws = Wl;
+  g.b_tap_stride = Cin;
+  g.prio = prio;
+  if (int e = launch_gemm(g, st)) return e;
+  return launch_pixel_shuffle2(planar, dx, B, Hl, Wl, Cin, 1, st, addend);
 }

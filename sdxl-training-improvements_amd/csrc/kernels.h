@@ -45,7 +45,8 @@ struct GemmP {
   // [Cout][16][Cin] matrix (ldb = 16 Cin, b_tap_stride = Cin).  NT (forward): taps = 4, M = 4 x up_plane rows in PLANAR phase-major order
   // (row m: phase m / up_plane, low-resolution pixel m % up_plane; rows >= up_rows of a plane are padding), A = the low-resolution image.  NN (dgrad):
   // taps = 16, M = up_rows low-resolution pixels, A = the planar phase-major output gradient [4][up_plane][K], gathered at the mirrored offsets.
-  int up2;
+  int up2;             // 1: as above.  2 (NN only): the input gradient of a STRIDE-2 3x3 convolution by output phase -- M = 4 x up_plane planar
+                       // rows, A = the low-resolution output gradient, plain [Cout][9][Cin] weights, taps = 4 (1 / 2 / 2 / 4 used by phase)
   int up_plane, up_rows;      // up2: rows per phase plane of the planar matrix (a multiple of 128, >= up_rows) and low-resolution pixels B Hm Wm
   long b_tap_stride;   // NT/NN: elements added to B per weight tap
   long c_tap_stride;   // TN: elements added to C per tap
@@ -211,10 +212,12 @@ int launch_split_add(const bf16* g, bf16* ga, int Ca, const bf16* add_a, bf16* g
 int launch_upsample2x(const bf16* x, bf16* y, int B, int H, int W, int C, hipStream_t st);
 // GemmP::up2 companions: the [Cout][16][Cin] stencil weights of a [Cout][9][Cin] kernel; planar phase-major <-> high-resolution layout
 int launch_upconv_fold_weights(const bf16* w, bf16* weff, int Cout, int Cin, hipStream_t st);
-int launch_pixel_shuffle2(const bf16* src, bf16* dst, int B, int H, int W, int C, int to_hi, hipStream_t st);   // plane stride = upconv_plane_rows
+int launch_pixel_shuffle2(const bf16* src, bf16* dst, int B, int H, int W, int C, int to_hi, hipStream_t st, const bf16* addend = nullptr);   // plane stride = upconv_plane_rows
 static inline long upconv_plane_rows(int B, int H, int W) { return ((long)B * H * W + 127) / 128 * 128; }
 int launch_upconv3x3_fwd(const bf16* x, const bf16* w, const bf16* bias, bf16* weff, bf16* planar, bf16* y, int B, int H, int W, int Cin,
                          int Cout, int splitk, float* slab, hipStream_t st);          // gemm.hip
+int launch_conv3x3_s2_dgrad(const bf16* dy, const bf16* w, bf16* planar, bf16* dx, const bf16* addend, int B, int H, int W, int Cin,
+                            int Cout, int prio, hipStream_t st);      // gemm.hip (GemmP::up2 == 2)
 int launch_upconv_unfold_grads(const float* dweff, float* dw, bf16* emit, float emit_scale, int accumulate, int Cout, int Cin, hipStream_t st);
 int launch_upconv3x3_wgrad(const bf16* planar, const bf16* x, float* dweff, float* dw, float* dbias, bf16* emit, float emit_scale,
                            int accumulate, int B, int H, int W, int Cin, int Cout, int splitk, float* slab, hipStream_t st);

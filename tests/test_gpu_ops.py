@@ -366,6 +366,23 @@ def test_conv3x3_fwd_dgrad_wgrad(L, B, H, W, Cin, Cout, stride):
         report(f"conv wgrad splitk={splitk}", dw, wr.grad, 1e-4 * math.sqrt(B * Ho * Wo) / 8 + 1e-5)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 16, 16, 64, 64), (4, 128, 128, 320, 320), (4, 64, 64, 640, 640), (2, 48, 84, 64, 128), (3, 12, 20, 72, 64)])
+def test_conv3x3_stride2_dgrad_by_output_phase(L, B, H, W, Cin, Cout):
+    """The input gradient of the stride-2 convolution from 1 / 2 / 2 / 4 taps per output phase (GemmP::up2 == 2) against autograd in fp32,
+    with and without an addend; the two downsampler shapes of the headline step and the 1344 x 768 bucket's level included."""
+    x = rnd(B, H, W, Cin, seed=30)
+    w = rnd(Cout, 9, Cin, seed=31, scale=(9 * Cin) ** -0.5)
+    xr = x.float().requires_grad_(True)
+    ref = _conv_ref(xr, w, None, 2)
+    dy = rnd(B, H // 2, W // 2, Cout, seed=32)
+    ref.backward(dy.float())
+    planar = torch.empty(4 * ((B * (H // 2) * (W // 2) + 127) // 128 * 128), Cin, dtype=torch.bfloat16, device=dev())
+    for addend in (None, rnd(B, H, W, Cin, seed=33)):
+        dx = torch.empty(B, H, W, Cin, dtype=torch.bfloat16, device=dev())
+        lib.check(L.sdxl_op_conv3x3_s2_dgrad(ptr(dy), ptr(w), ptr(planar), ptr(dx), ptr(addend) if addend is not None else None, B, H, W, Cin, Cout, stream()))
+        report(f"conv s2 dgrad by phase {B}x{H}x{W} {Cin}->{Cout} addend={addend is not None}", dx, xr.grad + (addend.float() if addend is not None else 0), 8e-3)
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 16, 16, 128, 64), (4, 32, 32, 1280, 1280), (4, 64, 64, 640, 640), (2, 24, 42, 64, 192), (4, 24, 42, 128, 64), (1, 32, 32, 320, 640)])
 def test_upsample_conv3x3_without_the_upsampled_image(L, B, H, W, Cin, Cout):
     """conv3x3(nearest-2x(x)) as four 2 x 2 phase stencils on the low-resolution image (GemmP::up2) against conv2d(interpolate(x)) in fp32:
