@@ -170,6 +170,13 @@ int sdxl_op_upconv3x3_fwd(const void* x, const void* w, const void* bias, void* 
                           int Cin, int Cout, void* stream);
 int sdxl_op_upconv3x3_dgrad(const void* dy, const void* weff, void* planar, void* dx, const void* addend, int B, int H, int W, int Cin,
                             int Cout, void* stream);
+/* The stride-2 3x3 convolution (pad 1, H and W even) on the four phase planes of its input, and its weight / bias gradient from the
+   same planes: xplanar [4 * roundup(B*(H/2)*(W/2), 128)][Cin] bf16 is written by _fwd and read by _wgrad; y / dy [B][H/2][W/2][Cout];
+   dw [Cout][9][Cin] fp32 (accumulate 0: =, 1: +=), dbias += (may be NULL). */
+int sdxl_op_conv3x3_s2_fwd(const void* x, const void* w, const void* bias, void* xplanar, void* y, int B, int H, int W, int Cin,
+                           int Cout, void* stream);
+int sdxl_op_conv3x3_s2_wgrad(const void* dy, const void* xplanar, float* dw, float* dbias, int accumulate, int B, int H, int W, int Cin,
+                             int Cout, int splitk, void* stream);
 /* Input gradient of the stride-2 3x3 convolution (the two `Downsample2D` convs; pad 1, H and W even) by output phase: input pixel
    (2r + a, 2c + b) receives 1 / 2 / 2 / 4 of the nine taps.  dy [B][H/2][W/2][Cout], w [Cout][9][Cin], dx [B][H][W][Cin] = addend
    (may be NULL) + gradient; planar [4 * roundup(B*(H/2)*(W/2), 128)][Cin] bf16 scratch. */

@@ -656,6 +656,19 @@ int sdxl_op_upconv3x3_dgrad(const void* dy, const void* weff, void* planar, void
   return launch_upconv3x3_dgrad((const bf16*)dy, (const bf16*)weff, (bf16*)planar, (bf16*)dx, (const bf16*)addend, B, H, W, Cin, Cout, splitk,
                                 slab, 0, (hipStream_t)st);
 }
+// stride-2 3x3 convolution through the fast gather on the four phase planes of x (GemmP::up2 == 3); xplanar [4 * roundup(B*(H/2)*(W/2), 128)][Cin]
+// bf16: written by _fwd, read by _wgrad
+int sdxl_op_conv3x3_s2_fwd(const void* x, const void* w, const void* bias, void* xplanar, void* y, int B, int H, int W, int Cin, int Cout,
+                           void* st) {
+  return launch_conv3x3_s2_fwd((const bf16*)x, (const bf16*)w, (const bf16*)bias, (bf16*)xplanar, (bf16*)y, B, H, W, Cin, Cout, (hipStream_t)st);
+}
+int sdxl_op_conv3x3_s2_wgrad(const void* dy, const void* xplanar, float* dw, float* dbias, int accumulate, int B, int H, int W, int Cin,
+                             int Cout, int splitk, void* st) {
+  float* slab = nullptr;
+  if (splitk > 1) CHK(test_slab(gemm_slab_floats(Cout, Cin, 9, splitk), &slab));
+  return launch_conv3x3_s2_wgrad((const bf16*)dy, (const bf16*)xplanar, dw, dbias, nullptr, 1.f, accumulate, B, H, W, Cin, Cout, splitk, slab,
+                                 (hipStream_t)st);
+}
 // input gradient of the stride-2 3x3 convolution by output phase (GemmP::up2 == 2); planar [4 * roundup(B*(H/2)*(W/2), 128)][Cin] scratch
 int sdxl_op_conv3x3_s2_dgrad(const void* dy, const void* w, void* planar, void* dx, const void* addend, int B, int H, int W, int Cin,
                              int Cout, void* st) {

@@ -249,7 +249,7 @@ void conv_wgrad3_set_enabled(bool on) { g_w3_enabled = on; }
 // p as normalised by launch_gemm (TN, taps == 9, fp32 output, slab_ld set)
 bool conv_wgrad3_applicable(const GemmP& p) {
   if (!g_w3_enabled) return false;
-  if (p.form != GEMM_TN || p.taps != 9 || p.group > 1) return false;
+  if (p.form != GEMM_TN || p.taps != 9 || p.group > 1 || p.up2) return false;
   if (p.sm != 1 || p.sd != 1 || p.Hm != p.Hs || p.Wm != p.Ws) return false;      // same-size stride-1
   if ((p.Wm % W3_BK != 0 && !(p.Wm == 32 && p.Hm % 2 == 0)) || p.K % W3_BK != 0 || p.K % ((long)p.Hm * p.Wm) != 0) return false;
   if (p.M % 8 || p.N % 8 || p.lda % 8 || p.ldb % 8 || p.ldc % 4) return false;

@@ -289,6 +289,7 @@ struct ConvOp : Op {
   Act* x_low = nullptr;
   Plan::GradDst* up_dx = nullptr;       // the UpsampleOp's input-gradient destination: this op writes it
   size_t weff_off = NONE, planar_off = NONE, dweff_off = NONE;
+  size_t s2x_off = NONE;           // stride 2: the four phase planes of x (forward and weight gradient through the fast gather, GemmP::up2 == 3)
   size_t s2_planar_off = NONE;     // stride 2: the input gradient by output phase (GemmP::up2 == 2; knob 2 = 256: the general gather)
   int up_fs = 1, up_ds = 1, up_ws = 1;
   bool up_wg = false;       // the weight gradient too (needs whole 64-pixel reduction steps): the upsampled image is then not produced at all
@@ -318,6 +319,8 @@ struct ConvOp : Op {
     Wo = (W - 1) / stride + 1;
   }
   int fwd(Plan& p, hipStream_t st) override {
+    if (s2x_off != NONE && g_knobs[2] == 512)      // (knob 2 = 512, experiment: measured neutral in the step -- 114.0-114.4 on, 113.8-114.3 off -- the general strided gather stays)
+      return launch_conv3x3_s2_fwd(p.P(x), p.eng->Wp(w), p.eng->Wp(b), (bf16*)p.F(s2x_off), p.P(y), Bn, H, W, Cin, Cout, st);
     if (up2())
       return launch_upconv3x3_fwd(p.P(x_low), p.eng->Wp(w), p.eng->Wp(b), (bf16*)p.F(weff_off), (bf16*)p.F(planar_off), p.P(y), Bn, H / 2,
                                   W / 2, Cin, Cout, up_fs, p.F(p.slab_main_off), st);
@@ -347,6 +350,8 @@ struct ConvOp : Op {
       rv32_ld = rowvec->ld();
     }
     if (x->need_grad) dx = p.grad_dst(x);
+    if (stride == 2 && H % 2 == 0 && W % 2 == 0 && Cin % 64 == 0 && Cout % 8 == 0 && !resid && !rowvec && (Bn * Ho * Wo) % 64 == 0)
+      s2x_off = p.alloc(sizeof(bf16) * (size_t)4 * upconv_plane_rows(Bn, Ho, Wo) * Cin);
     if (x->need_grad && stride == 2 && H % 2 == 0 && W % 2 == 0 && Cout % 64 == 0 && Cin % 8 == 0)
       s2_planar_off = p.alloc(sizeof(bf16) * (size_t)4 * upconv_plane_rows(Bn, Ho, Wo) * Cin);
     splitk = pick_splitk(Cout, Cin, 9, (long)Bn * Ho * Wo);
@@ -364,6 +369,12 @@ struct ConvOp : Op {
     if (resid && !resid_alias) CHK(launch_add(p.GP(dres.addend), dy, p.GP(dres.out), Mo * Cout, st));
     const bool upw = up2() && up_wg && g_knobs[2] != 128;       // (knob 2 = 128: weight gradient on the upsampled image, A/B runs)
     if (up2()) CHK(launch_pixel_shuffle2(dy, (bf16*)p.F(planar_off), Bn, H / 2, W / 2, Cout, 0, st));      // dy in its four phases: dgrad and weight gradient read it
+    if (s2x_off != NONE && g_knobs[2] == 512) {
+      CHK(on_side(p, st, [&](hipStream_t s2) -> int {
+        return launch_conv3x3_s2_wgrad(dy, (const bf16*)p.F(s2x_off), p.eng->Gp(w), p.eng->Gp(b), p.eng->emit_base ? p.eng->emit_base + w.off : nullptr,
+                                       p.eng->emit_scale, first ? 0 : 1, Bn, H, W, Cin, Cout, splitk, p.F(p.slab_off), s2);
+      }));
+    } else
     if (upw) {
       CHK(on_side(p, st, [&](hipStream_t s2) -> int {
         return launch_upconv3x3_wgrad((const bf16*)p.F(planar_off), p.P(x_low), p.F(dweff_off), p.eng->Gp(w), p.eng->Gp(b),

@@ -156,12 +156,21 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
   int by_[BCH], bx_[BCH];    // CF, TN: (y, x) of the pixel this lane gathers at the step being staged
   long ua = 0, ub = 0;       // CF: uniform element offsets of the step being staged
   int s_tap = 0, s_c = 0;    // CF, NT / NN: (tap, channel step) of the step being staged
-  const int tdy = p.up2 ? up2_dy(tap_fixed) : tap_fixed / 3 - 1, tdx = p.up2 ? up2_dx(tap_fixed) : tap_fixed - (tap_fixed / 3) * 3 - 1;   // CF, TN: this workgroup's tap
+  // CF, TN: this workgroup's tap.  (up2 == 3: stride-2 gather from the four phase planes of the input: kernel row 0 reads plane row i - 1)
+  const int tdy = p.up2 == 3 ? (tap_fixed / 3 == 0 ? -1 : 0) : p.up2 ? up2_dy(tap_fixed) : tap_fixed / 3 - 1;
+  const int tdx = p.up2 == 3 ? (tap_fixed % 3 == 0 ? -1 : 0) : p.up2 ? up2_dx(tap_fixed) : tap_fixed - (tap_fixed / 3) * 3 - 1;
+  const long s3_plane = p.up2 == 3 ? (long)(((tap_fixed / 3 != 1) ? 2 : 0) + ((tap_fixed % 3 != 1) ? 1 : 0)) * p.up_plane : 0;      // TN: phase plane of this tap's source pixels
   const int up_phase = (CF && FORM == GEMM_NT && p.up2) ? m0 / p.up_plane : dn_phase;      // up2, NT (and NN of mode 2): this workgroup's output phase
   // CF, NT / NN: uniform element offsets of (tap s_tap, channel step s_c)
   auto tap_offsets = [&]() {
     int dy, dx, wtap;
     long plane = 0;
+    if (FORM == GEMM_NT && p.up2 == 3) {         // stride-2 forward on the four phase planes of the input: kernel row 0 / 1 / 2 = plane row i - 1 (a = 1) / i (0) / i (1)
+      const int ky = s_tap / 3, kx = s_tap - ky * 3;
+      dy = ky == 0 ? -1 : 0; dx = kx == 0 ? -1 : 0;
+      wtap = s_tap;
+      plane = (long)((ky != 1 ? 2 : 0) + (kx != 1 ? 1 : 0)) * p.up_plane * p.lda;
+    } else
     if (FORM == GEMM_NN && p.up2 == 2) {         // tap s_tap of phase (a, b): (ry, rx) over the rows / columns that reach this phase
       const int a = dn_phase >> 1, b = dn_phase & 1;
       const int ry = s_tap / dn_nb, rx = s_tap - ry * dn_nb;
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
         const int krow = c * 4 + (lane >> 4);
         const int m = m0 + (nc_logical<128>(krow, lane & 15) << 3);
         amask[j] = (c < NCA && m < p.M) ? 1 : 0;
-        pa[j] = p.A + ((long)kt_begin * BK + krow + (p.up2 ? (long)(tap_fixed >> 2) * p.up_plane : 0)) * p.lda + m;      // (up2: the phase plane of dY)
+        pa[j] = p.A + ((long)kt_begin * BK + krow + (p.up2 == 1 ? (long)(tap_fixed >> 2) * p.up_plane : 0)) * p.lda + m;      // (up2 == 1: the phase plane of dY)
       } else {
         const int row = c * KC_ROWS + kc_rowl;
         const int m = m0 + row;
@@ -242,7 +251,10 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
             for (int t = 0; t < 16; ++t) {
               if (t >= p.taps) break;
               int ys, xs;
-              if (FORM == GEMM_NN && p.up2 == 2) {
+              if (FORM == GEMM_NT && p.up2 == 3) {
+                ys = r.y + (t / 3 == 0 ? -1 : 0);
+                xs = r.x + (t % 3 == 0 ? -1 : 0);
+              } else if (FORM == GEMM_NN && p.up2 == 2) {
                 const int ry = t / dn_nb, rx = t - ry * dn_nb;
                 ys = r.y + ((dn_phase >> 1) ? (ry == 0 ? 1 : 0) : 0);
                 xs = r.x + ((dn_phase & 1) ? (rx == 0 ? 1 : 0) : 0);
@@ -289,7 +301,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
           const PixRow r = decode_pix((int)kk0, p.K, p.Hm, p.Wm);
           by_[j] = r.y;
           bx_[j] = r.x;
-          pb[j] = p.B + (kk0 + tdy * p.Wm + tdx) * p.ldb + n;    // only dereferenced where the tap is in bounds
+          pb[j] = p.B + (s3_plane + kk0 + tdy * p.Wm + tdx) * p.ldb + n;    // only dereferenced where the tap is in bounds
         }
       }
     }
@@ -448,7 +460,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
     for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // bias gradient (TN): column sums of the A operand = A^T . ones, on the matrix pipe, by one wave column of the
   // workgroups that own n-tile 0 (and tap 0)
-  const bool do_bias = FORM == GEMM_TN && p.bias_grad != nullptr && bx == 0 && (p.up2 ? (tap_fixed & 3) == 0 : tap_fixed == 0) && wn == 0;      // (up2: once per phase plane)
+  const bool do_bias = FORM == GEMM_TN && p.bias_grad != nullptr && bx == 0 && (p.up2 == 1 ? (tap_fixed & 3) == 0 : tap_fixed == 0) && wn == 0;      // (up2 == 1: once per phase plane)
   f32x4 accb[MI];
   bf16x8 ones;
 #pragma unroll
@@ -1120,9 +1132,10 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
   ARG_CHECK(p.N % 8 == 0, "gemm: N=%d must be a multiple of 8", p.N);
   ARG_CHECK(p.lda % 8 == 0 && p.ldb % 8 == 0, "gemm: lda=%ld ldb=%ld must be multiples of 8", p.lda, p.ldb);
   if (p.up2) {
-    ARG_CHECK(p.taps == (p.form == GEMM_NT || p.up2 == 2 ? 4 : 16) && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws &&
+    ARG_CHECK(p.taps == (p.up2 == 3 ? 9 : p.form == GEMM_NT || p.up2 == 2 ? 4 : 16) && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws &&
               p.K % 64 == 0 && !p.geglu && p.group <= 1 && p.up_plane % 128 == 0 && p.up_rows <= p.up_plane && p.up_rows % (p.Hm * p.Wm) == 0 &&
-              (p.up2 == 2 ? (p.form == GEMM_NN && p.M == 4 * p.up_plane && p.splitk <= 1)
+              (p.up2 == 3 ? (p.form == GEMM_NT ? p.M == p.up_rows : p.form == GEMM_TN && p.K == p.up_rows) :
+               p.up2 == 2 ? (p.form == GEMM_NN && p.M == 4 * p.up_plane && p.splitk <= 1)
                           : p.form == GEMM_NT ? p.M == 4 * p.up_plane : p.form == GEMM_NN ? p.M == p.up_rows : p.K == p.up_rows),
               "gemm: up2 needs the fast same-size gather (reduction %% 64 == 0), taps 4 (NT, M = 4 planes of a multiple of 128 rows) / 16 (NN, TN)");
   } else
@@ -1335,4 +1348,47 @@ int launch_conv3x3_s2_dgrad(const bf16* dy, const bf16* w, bf16* planar, bf16* d
   g.prio = prio;
   if (int e = launch_gemm(g, st)) return e;
   return launch_pixel_shuffle2(planar, dx, B, Hl, Wl, Cin, 1, st, addend);
+}
+
+// Stride-2 3x3 convolution (pad 1, H and W even) through the fast same-size gather: x [B][H][W][Cin] is de-interleaved into its four
+// phase planes once (`xplanar` [4][plane][Cin], kept for the weight gradient), tap (ky, kx) then reads ONE plane at row offset -1 / 0
+int launch_conv3x3_s2_fwd(const bf16* x, const bf16* w, const bf16* bias, bf16* xplanar, bf16* y, int B, int H, int W, int Cin, int Cout,
+                          hipStream_t st) {
+  ARG_CHECK(H % 2 == 0 && W % 2 == 0, "stride-2 conv by phases: H=%d W=%d must be even", H, W);
+  const int Hl = H / 2, Wl = W / 2;
+  if (int e = launch_pixel_shuffle2(x, xplanar, B, Hl, Wl, Cin, 0, st)) return e;
+  GemmP g;
+  gemm_defaults(&g);
+  g.form = GEMM_NT;
+  g.up2 = 3; g.taps = 9;
+  g.up_rows = B * Hl * Wl; g.up_plane = (int)upconv_plane_rows(B, Hl, Wl);
+  g.A = xplanar; g.B = w; g.C = y;
+  g.M = B * Hl * Wl; g.N = Cout; g.K = Cin;
+  g.lda = Cin; g.ldb = 9L * Cin; g.ldc = Cout;
+  g.Hm = Hl; g.Wm = Wl; g.Hs = Hl; g.Ws = Wl;
+  g.b_tap_stride = Cin;
+  g.bias = bias;
+  return launch_gemm(g, st);
+}
+// ... and its weight / bias gradient from the same planes: dw [Cout][9][Cin] fp32
+int launch_conv3x3_s2_wgrad(const bf16* dy, const bf16* xplanar, float* dw, float* dbias, bf16* emit, float emit_scale, int accumulate, int B,
+                            int H, int W, int Cin, int Cout, int splitk, float* slab, hipStream_t st) {
+  const int Hl = H / 2, Wl = W / 2;
+  GemmP g;
+  gemm_defaults(&g);
+  g.form = GEMM_TN;
+  g.up2 = 3; g.taps = 9;
+  g.up_rows = B * Hl * Wl; g.up_plane = (int)upconv_plane_rows(B, Hl, Wl);
+  g.A = dy; g.B = xplanar; g.C = dw;
+  g.M = Cout; g.N = Cin; g.K = B * Hl * Wl;
+  g.lda = Cout; g.ldb = Cin; g.ldc = 9L * Cin;
+  g.Hm = Hl; g.Wm = Wl; g.Hs = Hl; g.Ws = Wl;
+  g.c_tap_stride = Cin;
+  g.out_f32 = 1;
+  g.splitk = splitk < 1 ? 1 : splitk;
+  g.slab = slab;
+  g.accumulate = accumulate;
+  g.bias_grad = dbias;
+  if (emit) { g.Cb = emit; g.cb_scale = emit_scale; }
+  return launch_gemm(g, st);
 }

@@ -8,6 +8,8 @@
 //   0 wave priority of the main-stream dgrad GEMMs in the backward, 1 of the attention backward kernels
 //   2 = 1: no split of the one-round 3x3 convolutions' reduction; = 16: every side-stream leaf behind its own fork event;
 //       = 4 / 8 / 12: the same split for the long linear dgrads / forward projections / both
+//       = 64: upsampler convolutions on the upsampled image; = 128: only their weight gradient; = 256: stride-2 dgrad through the general
+//       gather; = 512: stride-2 forward / weight gradient on phase planes (OFF by default: neutral in the step)
 //   3, 4 split-K factor of the long linear dgrads and its N threshold; 5 = 80: GEGLU packed in groups of 80
 //   6, 7 forced configuration of the linear / conv dgrads, 8 N threshold of knob 6
 //   9 = 1: no wgrad256 kernel; 10 = 2: fused LayerNorm backward; 11 = 1: the round-2 LayerNorm dx kernel
@@ -45,7 +47,9 @@ struct GemmP {
   // [Cout][16][Cin] matrix (ldb = 16 Cin, b_tap_stride = Cin).  NT (forward): taps = 4, M = 4 x up_plane rows in PLANAR phase-major order
   // (row m: phase m / up_plane, low-resolution pixel m % up_plane; rows >= up_rows of a plane are padding), A = the low-resolution image.  NN (dgrad):
   // taps = 16, M = up_rows low-resolution pixels, A = the planar phase-major output gradient [4][up_plane][K], gathered at the mirrored offsets.
-  int up2;             // 1: as above.  2 (NN only): the input gradient of a STRIDE-2 3x3 convolution by output phase -- M = 4 x up_plane planar
+  int up2;             // 1: as above.  3 (NT, TN): a STRIDE-2 3x3 convolution on the four phase planes of its input (A resp. B = [4][up_plane][Cin]): tap
+                       // (ky, kx) reads plane (ky != 1, kx != 1) at row / column offset -1 (ky, kx = 0) or 0; M resp. K = up_rows output pixels.
+                       //  2 (NN only): the input gradient of a STRIDE-2 3x3 convolution by output phase -- M = 4 x up_plane planar
                        // rows, A = the low-resolution output gradient, plain [Cout][9][Cin] weights, taps = 4 (1 / 2 / 2 / 4 used by phase)
   int up_plane, up_rows;      // up2: rows per phase plane of the planar matrix (a multiple of 128, >= up_rows) and low-resolution pixels B Hm Wm
   long b_tap_stride;   // NT/NN: elements added to B per weight tap
@@ -216,6 +220,10 @@ int launch_pixel_shuffle2(const bf16* src, bf16* dst, int B, int H, int W, int C
 static inline long upconv_plane_rows(int B, int H, int W) { return ((long)B * H * W + 127) / 128 * 128; }
 int launch_upconv3x3_fwd(const bf16* x, const bf16* w, const bf16* bias, bf16* weff, bf16* planar, bf16* y, int B, int H, int W, int Cin,
                          int Cout, int splitk, float* slab, hipStream_t st);          // gemm.hip
+int launch_conv3x3_s2_fwd(const bf16* x, const bf16* w, const bf16* bias, bf16* xplanar, bf16* y, int B, int H, int W, int Cin, int Cout,
+                          hipStream_t st);      // gemm.hip (GemmP::up2 == 3)
+int launch_conv3x3_s2_wgrad(const bf16* dy, const bf16* xplanar, float* dw, float* dbias, bf16* emit, float emit_scale, int accumulate, int B,
+                            int H, int W, int Cin, int Cout, int splitk, float* slab, hipStream_t st);
 int launch_conv3x3_s2_dgrad(const bf16* dy, const bf16* w, bf16* planar, bf16* dx, const bf16* addend, int B, int H, int W, int Cin,
                             int Cout, int prio, hipStream_t st);      // gemm.hip (GemmP::up2 == 2)
 int launch_upconv_unfold_grads(const float* dweff, float* dw, bf16* emit, float emit_scale, int accumulate, int Cout, int Cin, hipStream_t st);

@@ -381,6 +381,24 @@ def test_conv3x3_stride2_dgrad_by_output_phase(L, B, H, W, Cin, Cout):
         dx = torch.empty(B, H, W, Cin, dtype=torch.bfloat16, device=dev())
         lib.check(L.sdxl_op_conv3x3_s2_dgrad(ptr(dy), ptr(w), ptr(planar), ptr(dx), ptr(addend) if addend is not None else None, B, H, W, Cin, Cout, stream()))
         report(f"conv s2 dgrad by phase {B}x{H}x{W} {Cin}->{Cout} addend={addend is not None}", dx, xr.grad + (addend.float() if addend is not None else 0), 8e-3)
+    if Cin % 64 or (B * (H // 2) * (W // 2)) % 64:
+        return
+    # forward and weight gradient of the same convolution on the four phase planes of x (GemmP::up2 == 3)
+    bias = rnd(Cout, seed=34)
+    xplanar = torch.empty(4 * ((B * (H // 2) * (W // 2) + 127) // 128 * 128), Cin, dtype=torch.bfloat16, device=dev())
+    y = torch.empty(B, H // 2, W // 2, Cout, dtype=torch.bfloat16, device=dev())
+    lib.check(L.sdxl_op_conv3x3_s2_fwd(ptr(x), ptr(w), ptr(bias), ptr(xplanar), ptr(y), B, H, W, Cin, Cout, stream()))
+    wr = w.float().requires_grad_(True)
+    ref2 = _conv_ref(x.float(), wr, bias, 2)
+    report("conv s2 fwd on phase planes", y, ref2.detach(), 8e-3)
+    ref2.backward(dy.float())
+    for splitk, acc in ((1, 0), (3, 1)):
+        base = torch.randn(Cout, 9, Cin, device=dev()) if acc else torch.zeros(Cout, 9, Cin, device=dev())
+        dw = base.clone()
+        db = torch.zeros(Cout, dtype=torch.float32, device=dev())
+        lib.check(L.sdxl_op_conv3x3_s2_wgrad(ptr(dy), ptr(xplanar), ptr(dw), ptr(db), acc, B, H, W, Cin, Cout, splitk, stream()))
+        report(f"conv s2 wgrad on phase planes splitk={splitk}", dw - base, wr.grad, 1e-4 * math.sqrt(B * H * W / 4) / 8 + 1e-5)
+        report("conv s2 bias grad", db, dy.float().sum((0, 1, 2)), 1e-4 * math.sqrt(B * H * W / 4) / 8 + 1e-5)
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 16, 16, 128, 64), (4, 32, 32, 1280, 1280), (4, 64, 64, 640, 640), (2, 24, 42, 64, 192), (4, 24, 42, 128, 64), (1, 32, 32, 320, 640)])
