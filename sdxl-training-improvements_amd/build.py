@@ -16,7 +16,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OBJ = HERE / "build"
 LIB = HERE / "libsdxlstep.so"
-SOURCES = ["gemm.hip", "gemm256.hip", "gemm_sk.hip", "conv_wgrad3.hip", "wgrad256.hip", "attention.hip", "norm.hip", "elementwise.hip", "loss.hip", "optimizer.hip", "engine.hip", "capi.hip"]
+SOURCES = ["gemm.hip", "gemm256.hip", "gemm_sk.hip", "conv_wgrad3.hip", "wgrad256.hip", "gemm_cr256.hip", "attention.hip", "norm.hip", "elementwise.hip", "loss.hip", "optimizer.hip", "engine.hip", "capi.hip"]
 HEADERS = ["common.h", "kernels.h", "gemm_tiles.h", "engine.h", "../../include/sdxlstep.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -890,7 +890,7 @@ int sdxl_probe_layout(void* out, void* st) { return probe_layout(out, (hipStream
 int sdxl_profile_gemm_begin(void) { return gemm_profile_begin(); }
 int sdxl_set_gemm_mode(int mode) {
   const int cfg = mode >> 2;
-  ARG_CHECK(mode >= 0 && (mode & 3) <= 2 && (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 3 || cfg == 13 || cfg == 23), "gemm mode %d", mode);
+  ARG_CHECK(mode >= 0 && (mode & 3) <= 2 && (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 3 || cfg == 13 || cfg == 23 || cfg == 31 || cfg == 32), "gemm mode %d", mode);
   gemm_set_mode(mode);
   return 0;
 }

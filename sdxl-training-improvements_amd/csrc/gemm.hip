@@ -1201,6 +1201,21 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
   }
   const bool conv = p.taps != 1;
   int rc;
+  {   // co-resident 256-row kernel (gemm_cr256.hip): forced configurations 31 (160-column tiles) / 32 (128)
+    const int fc = p.cfg > 0 ? p.cfg : g_force_cfg;
+    if ((fc == 31 || fc == 32) && cr256_applicable(p)) {
+      rc = launch_cr256(p, fc == 31 ? 160 : 128, st);
+      if (rc == 0 && p.form == GEMM_TN && p.splitk > 1) {
+        const long nv = (long)p.M * (p.N / 4);
+        int g = (int)((nv + 255) / 256);
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, st, p.slab, (float*)p.C, p.M, p.N, p.ldc, p.slab_ld,
+                           p.splitk, p.accumulate, p.Cb, p.cb_scale);
+        HIP_CHECK_RET(hipGetLastError());
+      }
+      return rc;
+    }
+  }
   if (g_sk_mode && !(p.form != GEMM_TN && p.splitk > 1) && (g_sk_mode == 2 ? gemm_sk_applicable(p) : gemm_use_sk(p))) {
     GemmP q = p;
     q.splitk = 1;

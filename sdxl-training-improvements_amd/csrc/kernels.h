@@ -15,7 +15,9 @@
 //   9 = 1: no wgrad256 kernel; 10 = 2: fused LayerNorm backward; 11 = 1: the round-2 LayerNorm dx kernel
 //   12 = 1: no three-tap conv weight gradient; 13 split-K workgroup target of conv_wgrad3 / wgrad256 (144); 14 = 2: its W = 32 form
 //   15 = 1: no half-height tail workgroups in the 256 x 256 kernel
-#define SDXL_NKNOBS 16
+//   16 co-resident 256-row kernel for the level-2 linear weight gradients: 0 policy, 1 off, 2 / 3 = 128 / 160-column tiles wherever allowed;
+//   17 its split-K workgroup target (0: none)
+#define SDXL_NKNOBS 24
 extern int g_knobs[SDXL_NKNOBS];
 
 // ------------------------------------------------------------------------------------------------
@@ -138,6 +140,10 @@ bool wgrad256_policy(int M, int N, long red);
 int wgrad256_pick_splitk(int M, int N, long red);
 int launch_wgrad256(const GemmP& p, hipStream_t st);
 void wgrad256_set_enabled(bool on);
+// co-resident 256-row tile, 8 waves, <= 78 KiB LDS, <= 128 registers (gemm_cr256.hip): linear NT / NN / TN problems, K % 32 == 0
+bool cr256_applicable(const GemmP& p);
+int launch_cr256(const GemmP& p, int bn, hipStream_t st);      // bn = 160 / 128 / 0 (pick)
+int cr256_wgrad_cfg(int M, int N, long red, bool bias);        // the plan's choice for a linear weight gradient [M][N] over `red` rows: 0 / 31 / 32 (GemmP::cfg)
 // per-launch HIP-event timing of every GEMM launch between begin and end (end synchronises the device)
 int gemm_profile_begin();
 FILE* launch_log();      // SDXL_LAUNCH_LOG (gemm.hip)

@@ -220,6 +220,66 @@ def test_gemm_tn_long_reduction_wgrad256(L, M, N, K, splitk):
     report("wgrad256 vs 128x160 kernel", out * 0.5, o1, tol)
 
 
+@pytest.fixture(params=[31, 32])
+def cr256(L, request):
+    """force the co-resident 256-row kernel (gemm_cr256.hip; 31: 256 x 160 tiles, 32: 256 x 128) wherever it is applicable"""
+    lib.check(L.sdxl_set_gemm_mode(4 * request.param))
+    yield L
+    lib.check(L.sdxl_set_gemm_mode(1))
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 160, 32), (256, 320, 64), (256, 128, 96), (512, 640, 160), (300, 200, 128), (1000, 640, 2560),
+                                   (4096, 1280, 1280), (8, 1288, 320)])
+def test_gemm_cr256_nt_nn(cr256, M, N, K):
+    """256 x 160 / 256 x 128 x 32 tiles, 3-deep ring: 1, 2, 3, 4, 5 K-steps exercise the prologue / dummy-tail arithmetic, ragged M and N the
+    out-of-range buffer offsets and the guarded stores; every bf16 epilogue input; result against fp32 and against the 128-row kernel."""
+    L = cr256
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    lib.check(L.sdxl_op_gemm(0, ptr(a), ptr(w), ptr(out), M, N, K, ptr(bias), ptr(res), 0, 1, stream()))
+    report(f"cr256 nt {M}x{N}x{K}", out, a.float() @ w.float().t() + bias.float() + res.float(), 6e-3)
+    wn = rnd(K, N, seed=6, scale=K ** -0.5)
+    lib.check(L.sdxl_op_gemm(1, ptr(a), ptr(wn), ptr(out), M, N, K, None, None, 0, 1, stream()))
+    ref = a.float() @ wn.float()
+    report(f"cr256 nn {M}x{N}x{K}", out, ref, 6e-3)
+    base = rnd(M, N, seed=7)
+    out2 = base.clone()
+    lib.check(L.sdxl_op_gemm(1, ptr(a), ptr(wn), ptr(out2), M, N, K, None, None, 1, 1, stream()))
+    report(f"cr256 nn+= {M}x{N}x{K}", out2, ref + base.float(), 6e-3)
+    lib.check(L.sdxl_set_gemm_mode(0))
+    out3 = torch.empty_like(out)
+    lib.check(L.sdxl_op_gemm(1, ptr(a), ptr(wn), ptr(out3), M, N, K, None, None, 0, 1, stream()))
+    report("cr256 vs gemm128", out, out3.float(), 8e-3)
+
+
+@pytest.mark.parametrize("M,N,K,splitk", [(256, 160, 32, 1), (256, 128, 64, 1), (512, 320, 96, 1), (1280, 1280, 4096, 3), (3840, 1280, 4096, 1),
+                                          (200, 72, 1024, 4), (640, 640, 16384, 5)])
+def test_gemm_cr256_tn_wgrad_bias(cr256, M, N, K, splitk):
+    L = cr256
+    a, b = rnd(K, M, seed=8), rnd(K, N, seed=9)
+    tol = 2e-5 * math.sqrt(K) + 1e-5
+    out = torch.zeros(M, N, dtype=torch.float32, device=dev())
+    bg = torch.zeros(M, dtype=torch.float32, device=dev())
+    lib.check(L.sdxl_op_gemm(2, ptr(a), ptr(b), ptr(out), M, N, K, ptr(bg), None, 1, splitk, stream()))
+    ref = a.float().t() @ b.float()
+    report(f"cr256 tn {M}x{N}x{K} splitk={splitk}", out, ref, tol)
+    report("cr256 tn bias grad", bg, a.float().sum(0), tol)
+    lib.check(L.sdxl_op_gemm(2, ptr(a), ptr(b), ptr(out), M, N, K, None, None, 1, splitk, stream()))    # accumulate, no bias: the 160-column form
+    report("cr256 tn +=", out, 2 * ref, tol)
+    lib.check(L.sdxl_op_gemm(2, ptr(a), ptr(b), ptr(out), M, N, K, None, None, 0, splitk, stream()))    # overwrite
+    report("cr256 tn =", out, ref, tol)
+
+
+def test_gemm_cr256_grouped_wgrad_and_geglu_backward(cr256):
+    test_wgrad_group(cr256, 3, 1280, 1280, 4096)
+    test_wgrad_group(cr256, 2, 320, 640, 1000)      # (rows % 32 != 0: not applicable, stays on the 128-row kernel)
+    test_wgrad_group(cr256, 4, 128, 160, 64)
+    _ff_geglu_case(cr256, 308, 320, 1280, 64)
+    _ff_geglu_case(cr256, 4096, 1280, 5120, 64)
+    _ff_geglu_case(cr256, 100, 128, 160, 80)
+
+
 @pytest.fixture
 def g256(L):
     """force the 256 x 256 / 8-phase kernel (gemm256.hip) wherever it is applicable, restore the default policy after"""
