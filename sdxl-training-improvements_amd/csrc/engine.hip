@@ -195,10 +195,10 @@ struct LinearOp : Op {
     g.form = GEMM_NT;
     g.A = p.P(x); g.B = p.eng->Wp(w); g.C = p.P(y);
     g.M = (int)x->rows; g.N = N; g.K = K;
-    g.lda = K; g.ldb = K; g.ldc = N;
+    g.lda = x->ld(); g.ldb = K; g.ldc = y->ld();
     g.bias = b.off == NONE ? nullptr : p.eng->Wp(b);
-    if (resid) { g.resid = p.P(resid); g.ldr = N; }
-    if (gact) { g.geglu = 1; g.geglu_group = ggroup; g.aux = p.P(gact); g.ldaux = N / 2; }
+    if (resid) { g.resid = p.P(resid); g.ldr = resid->ld(); }
+    if (gact) { g.geglu = 1; g.geglu_group = ggroup; g.aux = p.P(gact); g.ldaux = gact->ld(); }
     if (fsplit > 1 && !hoist_fwd) { g.splitk = fsplit; g.slab = p.F(p.slab_main_off); }     // (the hoisted projection runs on the side stream)
     return launch_gemm(g, st);
   }
@@ -235,7 +235,7 @@ struct LinearOp : Op {
       g.form = GEMM_TN;
       g.A = dy; g.B = p.P(x); g.C = p.eng->Gp(w);
       g.M = N; g.N = K; g.K = M;
-      g.lda = N; g.ldb = K; g.ldc = K;
+      g.lda = y->ld(); g.ldb = x->ld(); g.ldc = K;
       g.out_f32 = 1;
       g.splitk = splitk;
       g.slab = p.F(p.slab_off);
@@ -264,9 +264,9 @@ struct LinearOp : Op {
       g.form = GEMM_NN;
       g.A = dy; g.B = p.eng->Wp(w); g.C = p.GP(dx.out);
       g.M = M; g.N = K; g.K = N;
-      g.lda = N; g.ldb = K; g.ldc = K;
-      if (gu) { g.geglu = 2; g.geglu_group = ggroup; g.aux = p.P(gu); g.ldaux = 2L * K; g.ldc = 2L * K; }
-      else if (dx.addend != NONE) { g.resid = p.GP(dx.addend); g.ldr = K; }
+      g.lda = y->ld(); g.ldb = K; g.ldc = x->ld();
+      if (gu) { g.geglu = 2; g.geglu_group = ggroup; g.aux = p.P(gu); g.ldaux = gu->ld(); g.ldc = gu->ld(); }
+      else if (dx.addend != NONE) { g.resid = p.GP(dx.addend); g.ldr = x->ld(); }
       if (dsplit > 1) { g.splitk = dsplit; g.slab = p.F(p.slab_main_off); }
       g.prio = g_knobs[0];
       if (g_knobs[6] > 0 && !gu && (g_knobs[8] <= 0 || N >= g_knobs[8])) g.cfg = g_knobs[6];     // experiment: configuration of the linear dgrads
@@ -712,10 +712,18 @@ struct Builder {
     PRef b;
     if (bias) { b = e.param(N, true); e.map_src(name + ".bias", {N}, b, kind, 0, group); }
     if (!pl) return nullptr;
-    Act* y = pl->new_act(x->rows, N);
+    Act* y = kind == 2 ? wide_act(x->rows, N) : pl->new_act(x->rows, N);
     LinearOp* op = tagseg(pl->add<LinearOp>(x, y, w, b, K, N, resid), w);
     if (op_out) *op_out = op;
     return y;
+  }
+  // The feed-forward hidden tensors ([rows][8C] pre-activation, [rows][4C] activation): a row stride that is a multiple of 1 KiB puts the
+  // 16 rows of a K-contiguous LDS-DMA piece (and the 32 k-rows of an N-contiguous one) on 1, 2 or 4 of the 16 L2 channels of an XCD
+  // (256-byte interleave); 64 padding columns spread them (NN 4096 x 1280 x 10240: DMA-only loop 172 -> 133 us,
+  // profiles/r04a_cr256_ld_sensitivity.txt).  The padded tensor is the parent of a column view, as the grouped K | V projection's slices are.
+  Act* wide_act(long rows, int cols) {
+    if (g_knobs[18] == 1 || cols % 512) return pl->new_act(rows, cols);
+    return pl->view(pl->new_act(rows, cols + 64), 0, cols);
   }
   // fused projection of several [Ni, K] source matrices into one [sum Ni, K] native matrix (no bias)
   Act* linear_fused(const std::vector<std::string>& names, Act* x, int K, int Neach) {
@@ -809,7 +817,7 @@ struct Builder {
     const int group = (g_knobs[5] == 80 && (4 * C) % 80 == 0) ? 80 : 64;
     LinearOp *ff1 = nullptr, *ff2 = nullptr;
     Act* u = linear(b + ".ff.net.0.proj", l3, C, 8 * C, true, nullptr, false, 2, &ff1, group);
-    Act* g = pl ? pl->new_act(x->rows, 4 * C) : nullptr;
+    Act* g = pl ? wide_act(x->rows, 4 * C) : nullptr;
     if (ff1) { ff1->gact = g; ff1->ggroup = group; }
     Act* y = linear(b + ".ff.net.2", g, 4 * C, C, true, x2, false, 0, &ff2);
     if (ff2) { ff2->gu = u; ff2->ggroup = group; }

@@ -16,7 +16,7 @@
 //   12 = 1: no three-tap conv weight gradient; 13 split-K workgroup target of conv_wgrad3 / wgrad256 (144); 14 = 2: its W = 32 form
 //   15 = 1: no half-height tail workgroups in the 256 x 256 kernel
 //   16 co-resident 256-row kernel for the level-2 linear weight gradients: 0 policy, 1 off, 2 / 3 = 128 / 160-column tiles wherever allowed;
-//   17 its split-K workgroup target (0: none)
+//   17 its split-K workgroup target (0: none); 18 = 1: no padding columns on the feed-forward hidden tensors
 #define SDXL_NKNOBS 24
 extern int g_knobs[SDXL_NKNOBS];
 
