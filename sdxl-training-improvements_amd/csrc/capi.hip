@@ -64,6 +64,9 @@ int sdxl_create(const sdxl_unet_config* cfg, int device, sdxl_handle** out) {
   const char* ns = getenv("SDXL_NO_SIDE_STREAM");     // measurement mode: everything on the caller's stream (clean per-kernel
   h->e.use_side = !(ns && ns[0] == '1');              // durations for the serialized rocprof summaries under profiles/)
   if (h->e.use_side) {
+    if (const char* sp = getenv("SDXL_SIDE_PRIO")) {   // measurement only: queue priority of the side stream (1 low, 0 normal, -1 high)
+      HIP_CHECK_RET(hipStreamCreateWithPriority(&h->e.side, hipStreamNonBlocking, atoi(sp)));
+    } else
     HIP_CHECK_RET(hipStreamCreateWithFlags(&h->e.side, hipStreamNonBlocking));   // (stream priorities: measured, neutral)
     HIP_CHECK_RET(hipStreamCreateWithFlags(&h->e.gstream, hipStreamNonBlocking));
     HIP_CHECK_RET(hipEventCreateWithFlags(&h->e.ev_gin, hipEventDisableTiming));

@@ -131,21 +131,28 @@ class ShardedGradSync(GradSync):
         self.buckets.clear()
         self._cursor = 0
 
+    @staticmethod
+    def slice_of(offset: int, count: int, world: int, rank: int):
+        """(arena offset, elements) of rank `rank`'s slice of the bucket [offset, offset + count): equal slices of whole 16-byte
+        vectors (count % (8 * world) == 0, checked up front by make_grad_sync), in rank order -- what reduce-scatter delivers."""
+        if count % (8 * world):
+            raise ValueError(f"bucket of {count} elements does not split into {world} slices of whole 16-byte vectors")
+        n = count // world
+        return offset + rank * n, n
+
     def on_segment(self, k: int, offset: int, count: int) -> None:
         if self.world < 2 or not self.enabled:
             return
         if k == 0:
             self.begin()
-        if count % (8 * self.world):     # (make_grad_sync checks the segment sizes up front and falls back to GradSync)
-            raise ValueError(f"bucket of {count} elements does not split into {self.world} slices of whole 16-byte vectors")
-        n = count // self.world
+        poff, n = self.slice_of(offset, count, self.world, self.rank)     # (make_grad_sync checks the sizes up front and falls back)
         buf = self.comm[offset:offset + count]
         self.cast(offset, count, buf)
         out = self.gshard[self._cursor:self._cursor + n]
         w = _via_host(dist.reduce_scatter_tensor, out, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if w is not None:
             self.pending.append(w)
-        self.pieces.append((offset + self.rank * n, n, self._cursor))
+        self.pieces.append((poff, n, self._cursor))
         self.buckets.append((offset, count))
         self._cursor += n
 

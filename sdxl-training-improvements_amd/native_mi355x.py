@@ -57,17 +57,17 @@ class NativeMI355XTrainer(NativeSDXLTrainer):
         super().__init__(model, native_opt, train_dataloader, device, wandb_logger, cfg, **kwargs)
 
     def save_checkpoint(self, epoch_or_path=0, is_final: bool = False):
+        """No collective (the reference calls this on rank 0 only): under ZeRO-1 every rank calls prepare_checkpoint() first."""
         self.sync_to_model()
-        if self.parent_trainer is not None and callable(getattr(self.parent_trainer, "save_checkpoint", None)) \
-                and not isinstance(epoch_or_path, (str, bytes)) and not hasattr(epoch_or_path, "__fspath__"):
+        is_path = isinstance(epoch_or_path, (str, bytes)) or hasattr(epoch_or_path, "__fspath__")
+        if self.parent_trainer is not None and callable(getattr(self.parent_trainer, "save_checkpoint", None)) and not is_path:
             out = self.parent_trainer.save_checkpoint(epoch_or_path, is_final)       # ddpm_trainer.py:236-253
             # the parent wrote ITS optimizer's state (the reference's torch AdamWBF16, which never stepped); the state that
-            # trained the weights is the fused optimizer's: replace optimizer.pt in the directory the parent used
-            # (sdxl_trainer.py:171-178: outputs/final_checkpoint or outputs/checkpoint-XXXX)
+            # trained the weights is the fused optimizer's: replace optimizer.pt in the directory the parent reports, else in
+            # the reference's own layout (trainer.checkpoint_dir = sdxl_trainer.py:171-178)
             from pathlib import Path
-            save_dir = Path("outputs") / ("final_checkpoint" if is_final else f"checkpoint-{int(epoch_or_path):04d}")
-            if isinstance(out, (str, Path)):
-                save_dir = Path(out)
+            from .trainer import checkpoint_dir
+            save_dir = Path(out) if isinstance(out, (str, Path)) else checkpoint_dir(epoch_or_path, is_final)
             save_dir.mkdir(parents=True, exist_ok=True)
             self.save_optimizer_state(save_dir)
             return out

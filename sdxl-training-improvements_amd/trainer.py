@@ -319,10 +319,16 @@ class NativeSDXLTrainer:
                             print({k: (round(v, 6) if isinstance(v, float) else v) for k, v in eff.items()}, flush=True)
                     acc_loss, acc_metrics = 0.0, defaultdict(float)
                 global_step += 1
-            if save_checkpoints and ep_n and ep_loss / ep_n < best:
-                best = ep_loss / ep_n
-                self.save_checkpoint(epoch + 1, is_final=False)
+            if save_checkpoints and ep_n:
+                # the decision must be the same on every rank (each sees its own data): the epoch's mean loss averaged over ranks.
+                # prepare_checkpoint() is the collective part (every rank), save_checkpoint() itself has none (rank 0 writes).
+                mean = D.reduce_dict({"loss": ep_loss / ep_n})["loss"]
+                if mean < best:
+                    best = mean
+                    self.prepare_checkpoint()
+                    self.save_checkpoint(epoch + 1, is_final=False)
         if save_checkpoints:
+            self.prepare_checkpoint()
             self.save_checkpoint(num_epochs, is_final=True)
 
     # -------------------------------------------------------------------------------- weights out (row f4)
@@ -341,15 +347,13 @@ class NativeSDXLTrainer:
         directory instead of an epoch: accepted too); the model through `model.save_pretrained(dir, safe_serialization=True)`
         when the caller's model has it (weights synced back first), else the UNet as diffusers-keyed safetensors;
         `optimizer.pt` = optimizer.state_dict(); `config.json` = the training config."""
-        # ZeRO-1: each rank has updated exp_avg / exp_avg_sq / shift on its own slices only -- gather them (collective, every
-        # rank calls save_checkpoint) so that optimizer.pt holds the complete state, whichever rank writes it
-        self._gather_optimizer_state()
+        # No collective in here: the reference calls save_checkpoint on rank 0 only (main.py:110-111, flow_matching_trainer.py:218-219,
+        # ddpm_trainer.py:235-237), so a gather at this point would leave rank 0 alone in it.  Under ZeRO-1 the complete optimizer
+        # state needs prepare_checkpoint() on EVERY rank first (train() does that); without it optimizer.pt holds rank 0's slices of
+        # exp_avg / exp_avg_sq / shift and says so (`zero1_partial`).
         if not D.is_main_process():
             return None
-        if isinstance(epoch_or_path, (str, Path)):
-            save_dir = Path(epoch_or_path)
-        else:
-            save_dir = Path("outputs") / ("final_checkpoint" if is_final else f"checkpoint-{int(epoch_or_path):04d}")
+        save_dir = checkpoint_dir(epoch_or_path, is_final)
         save_dir.mkdir(parents=True, exist_ok=True)
         self.sync_to_model()
         if self._torch_unet is not None and callable(getattr(self.model, "save_pretrained", None)):
@@ -360,34 +364,58 @@ class NativeSDXLTrainer:
             save_file({k: v.cpu().contiguous() for k, v in self.net.state_dict().items()},
                       str(save_dir / "unet" / "diffusion_pytorch_model.safetensors"))
         if self.optimizer is not None and callable(getattr(self.optimizer, "state_dict", None)):
-            osd = self.optimizer.state_dict()
-            if isinstance(osd.get("state"), dict):
-                osd["state"] = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in osd["state"].items()}
-            torch.save(osd, str(save_dir / "optimizer.pt"))
+            torch.save(self._optimizer_state_for_save(), str(save_dir / "optimizer.pt"))
         with open(save_dir / "config.json", "w") as f:
             json.dump(self.config.to_dict(), f, indent=2)
         return save_dir
 
-    def _gather_optimizer_state(self) -> None:
-        if self.sharded and self.sync.world > 1 and isinstance(self.optimizer, AdamWBF16) and self.sync.buckets:
+    def _zero1_active(self) -> bool:
+        return bool(self.sharded and self.sync.world > 1 and isinstance(self.optimizer, AdamWBF16) and getattr(self.sync, "buckets", None))
+
+    def prepare_checkpoint(self) -> None:
+        """COLLECTIVE -- every rank calls it, at the same point of its loop, before rank 0 calls save_checkpoint().  Under ZeRO-1
+        each rank has updated exp_avg / exp_avg_sq / shift on its own slices only: all-gather them so that the optimizer.pt rank 0
+        writes holds the complete state.  No-op otherwise.  The gathered state stays valid until the next optimizer step."""
+        if self._zero1_active():
             for arena in (self.optimizer.exp_avg, self.optimizer.exp_avg_sq, self.optimizer.shift):
                 self.sync.gather_arena(arena)
+        self._opt_state_step = self._step_counter()
 
-    def save_optimizer_state(self, save_dir) -> None:
-        """optimizer.pt of the NATIVE fused optimizer (complete state under ZeRO-1: collective, every rank calls it)."""
-        self._gather_optimizer_state()
-        if not D.is_main_process() or self.optimizer is None or not callable(getattr(self.optimizer, "state_dict", None)):
-            return
+    def _step_counter(self):
+        return getattr(self.optimizer, "step_count", None) if self.optimizer is not None else None
+
+    def _optimizer_state_for_save(self) -> dict:
         osd = self.optimizer.state_dict()
         if isinstance(osd.get("state"), dict):
             osd["state"] = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in osd["state"].items()}
-        torch.save(osd, str(Path(save_dir) / "optimizer.pt"))
+        if self._zero1_active() and getattr(self, "_opt_state_step", object()) != self._step_counter():
+            import warnings
+            warnings.warn("save_checkpoint under ZeRO-1 without prepare_checkpoint() on every rank: optimizer.pt holds this rank's "
+                          "slices of the moments only (zero1_partial)")
+            osd["zero1_partial"] = {"rank": int(self.sync.rank), "world": int(self.sync.world),
+                                    "pieces": [(int(a), int(n)) for a, n, _ in self.sync.pieces]}
+        return osd
+
+    def save_optimizer_state(self, save_dir) -> None:
+        """optimizer.pt of the NATIVE fused optimizer.  No collective (see save_checkpoint): complete under ZeRO-1 after
+        prepare_checkpoint() on every rank."""
+        if not D.is_main_process() or self.optimizer is None or not callable(getattr(self.optimizer, "state_dict", None)):
+            return
+        torch.save(self._optimizer_state_for_save(), str(Path(save_dir) / "optimizer.pt"))
 
     def load_optimizer_state(self, checkpoint_dir) -> None:
         """resume: optimizer.pt written by save_checkpoint (the UNet weights come back through the model object).  The state
         holds tensors, numbers and dicts only, so the safe loader is enough."""
         sd = torch.load(str(Path(checkpoint_dir) / "optimizer.pt"), map_location="cpu", weights_only=True)
         self.optimizer.load_state_dict(sd)
+
+
+def checkpoint_dir(epoch_or_path, is_final: bool = False) -> Path:
+    """The directory sdxl_trainer.py:171-178 writes a checkpoint to: `outputs/final_checkpoint` or `outputs/checkpoint-<epoch:04d>`
+    (relative to the working directory, as in the reference); a path is taken as it is (main.py:111)."""
+    if isinstance(epoch_or_path, (str, bytes, Path)) or hasattr(epoch_or_path, "__fspath__"):
+        return Path(epoch_or_path)
+    return Path("outputs") / ("final_checkpoint" if is_final else f"checkpoint-{int(epoch_or_path):04d}")
 
 
 def create_trainer(model, optimizer=None, train_dataloader=None, device=None, wandb_logger=None, config=None, **kw):

@@ -172,6 +172,213 @@ def _worker_state_and_emit(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _spawn(target, world, timeout=180, extra=()):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(extra)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=timeout) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(res)
+
+
+def _worker_checkpoint(rank, world, port, q, tmp):
+    """save_checkpoint must not contain a collective (the reference calls it on rank 0 only), the loop's save
+    decision must be the same on every rank although their losses differ, and the optimizer.pt rank 0 writes under ZeRO-1 must
+    hold every rank's moments once prepare_checkpoint() ran on all ranks."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.chdir(tmp)
+    import importlib
+    import warnings
+    from types import SimpleNamespace
+    D = importlib.import_module("sdxl-training-improvements_amd.distributed")
+    T = importlib.import_module("sdxl-training-improvements_amd.trainer")
+    O = importlib.import_module("sdxl-training-improvements_amd.optimizer")
+    CFG = importlib.import_module("sdxl-training-improvements_amd.config")
+    D.init_process_group("gloo")
+    total = 128
+
+    class Net:                                            # stand-in for NativeUNet
+        L = None
+        h = None
+        def __init__(self):
+            self.param_elems, self.device = total, "cpu"
+            self.weights = torch.zeros(total, dtype=torch.bfloat16)
+            self.grads = torch.zeros(total)
+            self.step = 0
+        def segment_ranges(self): return [(64, 64), (0, 64)]
+        def zero_grads(self): pass
+        def forward_loss(self, *a, **k): self.step += 1
+        # epoch 1 (steps 1, 2): rank 0 sees 1.0, rank 1 sees 0.2 -> mean 0.6; epoch 2: 0.5 / 2.0 -> mean 1.25.  Local decisions would
+        # differ in epoch 2 (rank 0 improves on its own 1.0, rank 1 does not improve on its 0.2): the ranks must agree NOT to save.
+        def read_loss(self):
+            ep = (self.step - 1) // 2
+            return [[1.0, 0.2][rank] if ep == 0 else [0.5, 2.0][rank], 0, 8.0, 16.0, 4.0, 9.0, 25.0, 1.0]
+        def set_grad_emit(self, arena, scale=1.0): pass
+        def cast_small(self, off, n, dst, scale=1.0): dst.fill_(1.0)
+        def backward(self, scale, first, on_segment=None, segment_stream=False):
+            if on_segment is not None:
+                for k, (off, n) in enumerate(self.segment_ranges()):
+                    on_segment(k, off, n)
+        def state_dict(self, dtype=torch.bfloat16): return {"w": self.weights.clone()}
+
+    class FakeFused(O.AdamWBF16):                         # the fused optimizer's host surface without libsdxlstep
+        def __init__(self, net):
+            self.net, self.L = net, None
+            self.param_groups = [dict(lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)]
+            self.exp_avg = torch.full((total,), -1.0, dtype=torch.bfloat16)
+            self.exp_avg_sq = torch.full((total,), -1.0, dtype=torch.bfloat16)
+            self.shift = torch.full((total,), -1.0, dtype=torch.bfloat16)
+            self.step_count, self.accumulated_decay, self._post_step_hooks = 0, {}, []
+        def step(self, grads=None, grad_scale=None, pieces=None, **kw):
+            self.step_count += 1
+            for off, n, _g in pieces:                     # this rank's slices only: what the sharded update touches
+                for t in (self.exp_avg, self.exp_avg_sq, self.shift):
+                    t[off:off + n] = float(10 * self.step_count + rank)
+            for fn in self._post_step_hooks:
+                fn(self)
+
+    cfg = CFG.Config()
+    cfg.training.method = "ddpm"
+    cfg.training.gradient_accumulation_steps = 1
+    cfg.training.clip_grad_norm = 0
+    net = Net()
+    b = {"vae_latents": torch.randn(2, 4, 8, 8), "prompt_embeds": torch.randn(2, 77, 16), "pooled_prompt_embeds": torch.randn(2, 8),
+         "time_ids": torch.zeros(2, 1, 6), "metadata": {}}
+    tr = T.NativeSDXLTrainer(net, optimizer=FakeFused(net), train_dataloader=[b, b], device="cpu", config=cfg)
+    tr._cast = lambda off, n, dst: dst.fill_(1.0)
+    tr.sync.cast = tr._cast
+    ok = tr.sharded and isinstance(tr.sync, D.ShardedGradSync)
+    saved = []
+    orig = tr.save_checkpoint
+    tr.save_checkpoint = lambda e=0, is_final=False: (saved.append((e, is_final)), orig(e, is_final))[1]
+    tr.wandb_logger = SimpleNamespace(log_metrics=lambda *a, **k: None)
+    tr.train(2, save_checkpoints=True)                    # would hang (mismatched collectives) with per-rank decisions
+    ok = ok and saved == [(1, False), (2, True)]          # epoch 1 improves on inf, epoch 2 does not improve on the MEAN, then the final one
+    if rank == 0:
+        from pathlib import Path
+        sd = torch.load(str(Path("outputs") / "final_checkpoint" / "optimizer.pt"), weights_only=True)
+        st = sd["state"]
+        exp = torch.empty(total)
+        for off, cnt in net.segment_ranges():
+            n = cnt // world
+            for r in range(world):
+                exp[off + r * n: off + (r + 1) * n] = 10.0 * 4 + r           # 4 optimizer steps; every rank's slices present
+        ok = ok and "zero1_partial" not in sd and all(torch.equal(st[k].float(), exp) for k in ("exp_avg", "exp_avg_sq", "shift"))
+    dist.barrier()
+    # rank 0 alone, as the reference calls it (no prepare on the others): returns, flags the partial state; the other ranks do nothing
+    tr.optimizer.step(pieces=tr.sync.pieces)
+    if rank == 0:
+        with warnings.catch_warnings(record=True) as wl:
+            warnings.simplefilter("always")
+            d = orig(7, False)
+        sd = torch.load(str(d / "optimizer.pt"), weights_only=True)
+        ok = ok and sd.get("zero1_partial", {}).get("world") == world and len(wl) == 1
+    else:
+        ok = ok and orig(7, False) is None
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_checkpoint_no_collective_and_rank_consistent_decision_world2_gloo(tmp_path):
+    assert _spawn(_worker_checkpoint, 2, extra=(str(tmp_path),)) == [(0, True), (1, True)]
+
+
+def _sdxl_segments():
+    import json
+    from pathlib import Path
+    d = json.loads((Path(__file__).parent / "golden" / "sdxl_segments.json").read_text())
+    return int(d["param_elems"]), [(int(o), int(n)) for o, n in d["segments"]]
+
+
+def test_world8_slices_of_the_real_sdxl_segments():
+    """The ZeRO-1 slicing arithmetic over the REAL SDXL-base segment sizes (tests/golden/sdxl_segments.json, written on a GPU by
+    profiles/tools/dump_segments.py and pinned against the live engine by tests/test_gpu_model.py) at world = 2, 4, 8: every
+    segment splits into `world` slices of whole 16-byte vectors (no all-reduce fallback), the slices tile the arena exactly, each
+    starts on a 16-byte boundary of the bf16 exchange arena, and a rank's shard fits the `gshard` buffer the class allocates."""
+    import importlib
+    D = importlib.import_module("sdxl-training-improvements_amd.distributed")
+    total, segs = _sdxl_segments()
+    assert total == 2567486784 or total > 2_567_463_684          # parameters + 64-element padding
+    assert sorted(o for o, _n in segs)[0] == 0 and sum(n for _o, n in segs) == total
+    for world in (2, 4, 8):
+        assert all(n % (8 * world) == 0 for _o, n in segs), "make_grad_sync would fall back to all-reduce"
+        cover = []
+        for rank in range(world):
+            shard = 0
+            for off, cnt in segs:
+                poff, n = D.ShardedGradSync.slice_of(off, cnt, world, rank)
+                assert (poff * 2) % 16 == 0 and (n * 2) % 16 == 0 and n == cnt // world
+                cover.append((poff, n))
+                shard += n
+            assert shard <= (total + world - 1) // world + 8      # the gshard allocation of ShardedGradSync.__init__
+        cover.sort()
+        pos = 0
+        for poff, n in cover:
+            assert poff == pos
+            pos += n
+        assert pos == total
+
+
+def _worker_world8(rank, world, port, q):
+    """the collectives themselves at world = 8 (gloo): the real segment list scaled down 4096 x (multiples of 64 elements kept),
+    through make_grad_sync / on_segment / finish / global_sumsq / gather_arena, against locally recomputed expectations."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import importlib
+    import warnings
+    D = importlib.import_module("sdxl-training-improvements_amd.distributed")
+    D.init_process_group("gloo")
+    _total, real = _sdxl_segments()
+    sizes = [max(64, n // 4096 // 64 * 64) for _o, n in real]          # exchange order preserved
+    total = sum(sizes)
+    offs, pos = [], total
+    for n in sizes:                                                      # reverse execution order: the last parameters first
+        pos -= n
+        offs.append(pos)
+    segs = list(zip(offs, sizes))
+    grads = [torch.randn(total, generator=torch.Generator().manual_seed(500 + r)) for r in range(world)]
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        sync = D.make_grad_sync(total, lambda off, n, dst: dst.copy_(grads[rank][off:off + n] / world), torch.float32, "cpu",
+                                sharded=True, segment_sizes=sizes)
+    ok = isinstance(sync, D.ShardedGradSync) and len(wl) == 0
+    for k, (off, n) in enumerate(segs):
+        sync.on_segment(k, off, n)
+    sync.finish()
+    mean = sum(grads) / world
+    red = sync.reduced()
+    for poff, n, goff in sync.pieces:
+        ok = ok and torch.allclose(red[goff:goff + n], mean[poff:poff + n], atol=1e-5)
+    sq = sync.global_sumsq(red.double().pow(2).sum().float().reshape(1))
+    ok = ok and abs(float(sq) - float(mean.double().pow(2).sum())) < 1e-3 * float(mean.double().pow(2).sum())
+    w = torch.full((total,), -1.0)
+    for poff, n, _g in sync.pieces:
+        w[poff:poff + n] = float(rank)
+    sync.gather_params(w)
+    for off, cnt in segs:
+        n = cnt // world
+        for r in range(world):
+            ok = ok and bool((w[off + r * n: off + (r + 1) * n] == float(r)).all())
+    # the all-reduce path over the same buckets
+    ar = D.GradSync(total, lambda off, n, dst: dst.copy_(grads[rank][off:off + n] / world), comm_dtype=torch.float32, device="cpu")
+    for k, (off, n) in enumerate(segs):
+        ar.on_segment(k, off, n)
+    ar.finish()
+    ok = ok and torch.allclose(ar.reduced(), mean, atol=1e-5)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradsync_world8_gloo_over_the_sdxl_segment_list():
+    assert _spawn(_worker_world8, 8, timeout=300) == [(r, True) for r in range(8)]
+
+
 def test_optimizer_state_gather_fallback_and_emit_gating_world2_gloo():
     world = 2
     ctx = mp.get_context("spawn")

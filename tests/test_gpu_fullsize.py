@@ -74,6 +74,15 @@ def test_full_state_dict_round_trip_bit_exact(full):
         net.load_weight(name, old)
 
 
+def test_segment_fixture_is_the_live_segment_list(full):
+    """tests/golden/sdxl_segments.json (the world-8 slicing test on CPU runs over it) == what the engine reports"""
+    import json
+    from pathlib import Path
+    d = json.loads((Path(__file__).parent / "golden" / "sdxl_segments.json").read_text())
+    assert int(d["param_elems"]) == int(full.param_elems)
+    assert [(int(o), int(n)) for o, n in d["segments"]] == [(int(o), int(n)) for o, n in full.segment_ranges()]
+
+
 def test_cfg1_loss_matches_cpu_oracle(full, oracle_w):
     net = full
     x = _inputs(1, 64, 64, seed=101)

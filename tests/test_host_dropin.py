@@ -171,7 +171,7 @@ def test_optimizer_post_step_hook_ends_cycle():
     assert [c[2] for c in tr.net.calls if c[0] == "bwd"] == [True, False, True]
 
 
-def test_native_mi355x_method_module():
+def test_native_mi355x_method_module(tmp_path, monkeypatch):
     """constructed exactly like sdxl_trainer.py:130-150 builds its method trainers, from a reference-style config object"""
     ref_cfg = SimpleNamespace(model=SimpleNamespace(model_type="sdxl", min_snr_gamma=5.0, use_ztsnr=True),
                               optimizer=SimpleNamespace(learning_rate=4e-7, weight_decay=0.01),
@@ -187,8 +187,10 @@ def test_native_mi355x_method_module():
     assert (g["lr"], g["betas"], g["eps"], g["weight_decay"]) == (2e-6, (0.8, 0.95), 1e-7, 0.02)
     out = tr.compute_loss(tr.model, _batch(), torch.Generator().manual_seed(0))
     assert set(out["metrics"]) == {"loss", "x0_norm", "x1_norm", "time_mean", "time_std", "velocity_norm", "batch_size", "lr"}
+    monkeypatch.chdir(tmp_path)                           # (the reference's checkpoint directories are relative to the working directory)
     tr.save_checkpoint(2, False)                          # ddpm_trainer.py:236-253: through the parent trainer, weights synced first
     assert parent.saved == [(2, False)]
+    assert (tmp_path / "outputs" / "checkpoint-0002" / "optimizer.pt").exists()      # the fused optimizer's state, in the reference's layout
 
 
 def test_config_from_unet_shapes():
