@@ -221,6 +221,9 @@ def main():
         lib.LIB_PATH = Path(args.lib).resolve()
         probe = ctypes.CDLL(str(lib.LIB_PATH))
         lib.SIGNATURES = {k: v for k, v in lib.SIGNATURES.items() if hasattr(probe, k)}
+        lib.TEST_HOOK_SIGNATURES = {k: v for k, v in lib.TEST_HOOK_SIGNATURES.items() if hasattr(probe, k)}
+    if args.knob:
+        lib.use_diag()          # knobs exist in the diagnostics build only (build.py --diag; include/sdxlstep_diag.h)
     if args.gemm_mode is not None:
         lib.check(lib.load().sdxl_set_gemm_mode(args.gemm_mode))
     for kv in args.knob:

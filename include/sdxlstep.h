@@ -170,13 +170,6 @@ int sdxl_op_upconv3x3_fwd(const void* x, const void* w, const void* bias, void* 
                           int Cin, int Cout, void* stream);
 int sdxl_op_upconv3x3_dgrad(const void* dy, const void* weff, void* planar, void* dx, const void* addend, int B, int H, int W, int Cin,
                             int Cout, void* stream);
-/* The stride-2 3x3 convolution (pad 1, H and W even) on the four phase planes of its input, and its weight / bias gradient from the
-   same planes: xplanar [4 * roundup(B*(H/2)*(W/2), 128)][Cin] bf16 is written by _fwd and read by _wgrad; y / dy [B][H/2][W/2][Cout];
-   dw [Cout][9][Cin] fp32 (accumulate 0: =, 1: +=), dbias += (may be NULL). */
-int sdxl_op_conv3x3_s2_fwd(const void* x, const void* w, const void* bias, void* xplanar, void* y, int B, int H, int W, int Cin,
-                           int Cout, void* stream);
-int sdxl_op_conv3x3_s2_wgrad(const void* dy, const void* xplanar, float* dw, float* dbias, int accumulate, int B, int H, int W, int Cin,
-                             int Cout, int splitk, void* stream);
 /* Input gradient of the stride-2 3x3 convolution (the two `Downsample2D` convs; pad 1, H and W even) by output phase: input pixel
    (2r + a, 2c + b) receives 1 / 2 / 2 / 4 of the nine taps.  dy [B][H/2][W/2][Cout], w [Cout][9][Cin], dx [B][H][W][Cin] = addend
    (may be NULL) + gradient; planar [4 * roundup(B*(H/2)*(W/2), 128)][Cin] bf16 scratch. */
@@ -248,33 +241,14 @@ int sdxl_adamw_bf16_step(void* p, const void* grad, int grad_dtype, void* m, voi
                          void* stream);
 int sdxl_adamw_decay(void* shift, const void* p, size_t n, float decay, void* stream);
 
-/* debug: run ds_read_b64_tr_b16 / MFMA layout probes (used by tests/test_gpu_layout.py) */
-int sdxl_probe_layout(void* out_dev, void* stream);
 /* measurement: between begin and end every launch of the bf16 MFMA GEMM family (Linear / conv fwd, dgrad, wgrad) is
  * bracketed by HIP events on its launch stream; end synchronises and returns the summed algorithmic FLOPs
- * (2*M*N*K*taps), the summed event time and the number of launches. */
+ * (2*M*N*K*taps), the summed event time and the number of launches (bench.py's roofline block). */
 int sdxl_profile_gemm_begin(void);
-/* tile-kernel selection of the GEMM family, for A/B measurements and parity tests: 0 = 128-row kernel only,
- * 1 = 256 x 256 kernel where its grid fills the chip (default), 2 = 256 x 256 kernel wherever it is applicable;
- * + 4 * c forces configuration c (1, 2, 3 or 13) of the 128-row kernel. */
-int sdxl_set_gemm_mode(int mode);
 int sdxl_profile_gemm_end(double* flops, double* ms, int* launches);
-/* Persistent stream-K GEMM (csrc/gemm_sk.hip; 256 x 256 tiles, one workgroup per CU, the K-steps of ALL problems of a launch
- * cut evenly over the CUs).  sdxl_set_sk_mode: mode 0 = never, 1 = the plan's policy (default), 2 = wherever a problem is
- * applicable (M, N multiples of 256, K of 64); workers > 0 forces the worker count (microbenchmarks), 0 = policy.
- * sdxl_sk_error: *out != 0 iff an owner workgroup ever gave up waiting for a partial tile on that stream (results invalid).
- * sdxl_op_gemm_sk: n (<= 4) problems in ONE launch, arguments per problem as sdxl_op_gemm (form 2: bias[i] = fp32 bias
- * gradient accumulator or NULL, C fp32); this is how the plan launches a layer's dgrad and wgrad together. */
-/* experiment knobs of the plan (A/B runs; defaults are the shipped policy): see csrc/kernels.h */
-int sdxl_set_knob(int id, int value);
-int sdxl_set_sk_mode(int mode, int workers);
-int sdxl_sk_error(void* stream, unsigned* out);
-int sdxl_op_gemm_sk(int n, const int* form, const void* const* A, const void* const* B, void* const* C, const int* M,
-                    const int* N, const int* K, const void* const* bias, const void* const* resid, const int* accumulate,
-                    void* stream);
-/* debug: checksum of every activation (grads != 0: of every activation gradient) of the current plan, in creation
- * order; synchronises the device.  n_out receives the number of activations. */
-int sdxl_debug_act_checksums(sdxl_handle* h, unsigned long long* out_host, int cap, int* n_out, int grads);
+
+/* Test hooks (layout probe, forced kernel configurations, activation checksums) and the experiment ABI of the diagnostics build
+ * (knobs, stream-K, phase-plane stride-2 convolution) are NOT part of this boundary: include/sdxlstep_diag.h. */
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 #!/bin/bash
 # same-box A/B of knob settings: bash profiles/tools/ab.sh <rounds> "<knobs A>" "<knobs B>" ...   (each a space-separated list of id=value, "-" = none)
 R=$1; shift
+export SDXL_DIAG=1
 B="python bench.py --no-cpu-baseline --no-optimizer --profile-steps 0 --steps 15 --warmup 4"
 for i in $(seq 1 $R); do
   for k in "$@"; do

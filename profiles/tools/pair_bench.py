@@ -17,6 +17,8 @@ import sdxl_amd  # noqa: E402,F401
 from sdxl_amd import lib  # noqa: E402
 
 dev = torch.device("cuda:0")
+if "--lib" in sys.argv:       # diagnostics: a knock-out library (profiles/tools/build_diag_cr.sh), same C ABI
+    lib.LIB_PATH = Path(sys.argv[sys.argv.index("--lib") + 1]).resolve()
 L = lib.load()
 arg = lambda k, d: sys.argv[sys.argv.index(k) + 1] if k in sys.argv else d
 # mode pairs "dgrad:wgrad" (sdxl_set_gemm_mode values: 1 policy, 4*31 = 124 (256x160), 4*32 = 128 (256x128), 52 = cfg 13)

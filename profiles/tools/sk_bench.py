@@ -15,6 +15,8 @@ sys.path.insert(0, str(ROOT))
 import sdxl_amd  # noqa: E402,F401
 from sdxl_amd import lib  # noqa: E402
 
+lib.use_diag()      # the stream-K kernel lives in the diagnostics build (build.py --diag)
+
 dev = torch.device("cuda:0")
 L = lib.load()
 FORMS = {"NT": 0, "NN": 1, "TN": 2}

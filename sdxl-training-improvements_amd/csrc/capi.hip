@@ -1,6 +1,7 @@
 // extern "C" surface of libsdxlstep (see include/sdxlstep.h for the contract of every entry point).
 #include <math.h>
 #include "engine.h"
+#include "../../include/sdxlstep_diag.h"
 #include <functional>
 
 #include <stdlib.h>
@@ -659,6 +660,7 @@ int sdxl_op_upconv3x3_dgrad(const void* dy, const void* weff, void* planar, void
   return launch_upconv3x3_dgrad((const bf16*)dy, (const bf16*)weff, (bf16*)planar, (bf16*)dx, (const bf16*)addend, B, H, W, Cin, Cout, splitk,
                                 slab, 0, (hipStream_t)st);
 }
+#ifdef SDXL_DIAG
 // stride-2 3x3 convolution through the fast gather on the four phase planes of x (GemmP::up2 == 3); xplanar [4 * roundup(B*(H/2)*(W/2), 128)][Cin]
 // bf16: written by _fwd, read by _wgrad
 int sdxl_op_conv3x3_s2_fwd(const void* x, const void* w, const void* bias, void* xplanar, void* y, int B, int H, int W, int Cin, int Cout,
@@ -672,6 +674,7 @@ int sdxl_op_conv3x3_s2_wgrad(const void* dy, const void* xplanar, float* dw, flo
   return launch_conv3x3_s2_wgrad((const bf16*)dy, (const bf16*)xplanar, dw, dbias, nullptr, 1.f, accumulate, B, H, W, Cin, Cout, splitk, slab,
                                  (hipStream_t)st);
 }
+#endif
 // input gradient of the stride-2 3x3 convolution by output phase (GemmP::up2 == 2); planar [4 * roundup(B*(H/2)*(W/2), 128)][Cin] scratch
 int sdxl_op_conv3x3_s2_dgrad(const void* dy, const void* w, void* planar, void* dx, const void* addend, int B, int H, int W, int Cin,
                              int Cout, void* st) {
@@ -783,7 +786,7 @@ int sdxl_op_layernorm_bwd(const void* x, const void* dy, const void* gamma, cons
     return launch_layernorm_bwd((const bf16*)x, (const bf16*)dy, (const bf16*)gamma, stats, (bf16*)dx,
                                 accumulate ? (const bf16*)dx : nullptr, nullptr, nullptr, M, C, (hipStream_t)st);
   ARG_CHECK(dbeta, "layernorm bwd: dgamma and dbeta go together");
-  if (g_knobs[10] != 2) {     // the plan's default: lean dx kernel + parameter gradients as a pass of their own
+  if (KNOB(10) != 2) {     // the plan's default: lean dx kernel + parameter gradients as a pass of their own
     CHK(launch_layernorm_bwd((const bf16*)x, (const bf16*)dy, (const bf16*)gamma, stats, (bf16*)dx,
                              accumulate ? (const bf16*)dx : nullptr, nullptr, nullptr, M, C, (hipStream_t)st));
     return launch_layernorm_param_grads((const bf16*)x, (const bf16*)dy, stats, dgamma, dbeta, M, C, (hipStream_t)st);
@@ -898,6 +901,9 @@ int sdxl_set_gemm_mode(int mode) {
   return 0;
 }
 int sdxl_profile_gemm_end(double* flops, double* ms, int* launches) { return gemm_profile_end(flops, ms, launches); }
+#ifdef SDXL_DIAG     // ---- experiment ABI of the diagnostics build (include/sdxlstep_diag.h): not in the product library ----
+// Knobs are process-global and read at plan-build, forward and backward time: set them BEFORE sdxl_plan / the first step of a handle and
+// leave them alone afterwards (A/B runs restart the process per setting, profiles/tools/ab.sh).
 int sdxl_set_knob(int id, int value) {
   ARG_CHECK(id >= 0 && id < SDXL_NKNOBS, "knob %d out of range", id);
   g_knobs[id] = value;
@@ -936,6 +942,7 @@ int sdxl_op_gemm_sk(int n, const int* form, const void* const* A, const void* co
   }
   return launch_gemm_multi(g, n, (hipStream_t)st);
 }
+#endif   // SDXL_DIAG
 
 // debug: order-independent checksum (sum of raw 16-bit patterns) of every activation of the current plan, in
 // creation order.  Synchronises.  Used to localise run-to-run differences.

@@ -251,7 +251,7 @@ bool conv_wgrad3_applicable(const GemmP& p) {
   if (!g_w3_enabled) return false;
   if (p.form != GEMM_TN || p.taps != 9 || p.group > 1 || p.up2) return false;
   if (p.sm != 1 || p.sd != 1 || p.Hm != p.Hs || p.Wm != p.Ws) return false;      // same-size stride-1
-  if ((p.Wm % W3_BK != 0 && !(p.Wm == 32 && p.Hm % 2 == 0)) || p.K % W3_BK != 0 || p.K % ((long)p.Hm * p.Wm) != 0) return false;
+  if ((p.Wm % W3_BK != 0 && !(SDXL_UP2_3 && p.Wm == 32 && p.Hm % 2 == 0)) || p.K % W3_BK != 0 || p.K % ((long)p.Hm * p.Wm) != 0) return false;
   if (p.M % 8 || p.N % 8 || p.lda % 8 || p.ldb % 8 || p.ldc % 4) return false;
   return true;
 }
@@ -260,7 +260,7 @@ bool conv_wgrad3_policy(int M, int N, long red, int Wm, int stride) {
   // the 128^2 / 64^2 levels (>= 16 384 pixels).  The W = 32 form (1280-channel level) is 1.3-1.4x faster standalone (1 112 vs 795 TFLOP/s)
   // but costs the step 0.3 ms: in the transformer-heavy stretch of the backward a workgroup that owns its CU displaces the
   // co-resident critical-path kernels, which the 4-wave one-tap kernel does not (knob 14 = 2 enables it: A/B runs)
-  const bool w32 = Wm == 32 && g_knobs[14] == 2;
+  const bool w32 = Wm == 32 && KNOB(14) == 2;
   return g_w3_enabled && stride == 1 && (Wm % W3_BK == 0 || w32) && red >= (w32 ? 4096 : 16384) && M % 8 == 0 && N % 8 == 0;
 }
 // split-K factor: the kernel owns its CUs, so aim at ~half the chip per launch (the other stream keeps the rest), at least 16
@@ -268,7 +268,7 @@ bool conv_wgrad3_policy(int M, int N, long red, int Wm, int stride) {
 int conv_wgrad3_pick_splitk(int M, int N, long red) {
   const long tiles = (long)cdiv(M, W3_BM) * cdiv(N, W3_BN) * 3;
   const long ktiles = red / W3_BK;
-  const long target = g_knobs[13] > 0 ? g_knobs[13] : 256;
+  const long target = KNOB(13) > 0 ? KNOB(13) : 256;
   long s = (target + tiles / 2) / tiles;
   if (s < 1) s = 1;
   while (s > 1 && ktiles / s < 16) --s;
@@ -281,12 +281,17 @@ int launch_conv_wgrad3(const GemmP& p, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_wgrad3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, w3_smem(1)));
+#ifdef SDXL_DIAG      // the W = 32 form (two image rows per K-step) exists in the diagnostics build only
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)conv_wgrad3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, w3_smem(2)));
+#endif
     attr_set = true;
   }
   dim3 grid(cdiv(p.N, W3_BN), cdiv(p.M, W3_BM), 3 * p.splitk);
+#ifdef SDXL_DIAG
   if (p.Wm == 32) hipLaunchKernelGGL(conv_wgrad3_kernel<2>, grid, dim3(512), w3_smem(2), st, p);
-  else hipLaunchKernelGGL(conv_wgrad3_kernel<1>, grid, dim3(512), w3_smem(1), st, p);
+  else
+#endif
+  hipLaunchKernelGGL(conv_wgrad3_kernel<1>, grid, dim3(512), w3_smem(1), st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

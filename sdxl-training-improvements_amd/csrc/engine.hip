@@ -6,7 +6,9 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#ifdef SDXL_DIAG
 int g_knobs[SDXL_NKNOBS] = {0};
+#endif
 static thread_local char g_err[1024] = "";
 void sdxl_set_error(const char* fmt, ...) {
   va_list ap;
@@ -102,7 +104,7 @@ static int on_side(Plan& p, hipStream_t main, F&& fn) {
 template <class F>
 static int side_leaf(Plan& p, hipStream_t main, F&& fn) {
   Engine& e = *p.eng;
-  if (!e.use_side || !e.side || gemm_profiling() || g_knobs[2] == 16) return on_side(p, main, fn);     // (knob 2 = 16: own event each, A/B runs)
+  if (!e.use_side || !e.side || gemm_profiling() || KNOB(2) == 16) return on_side(p, main, fn);     // (knob 2 = 16: own event each, A/B runs)
   e.side_leaves.emplace_back(std::function<int(hipStream_t)>(fn));
   return 0;
 }
@@ -219,7 +221,7 @@ struct LinearOp : Op {
     if (!gu && x->need_grad) {
       dsplit = gemm_pick_splitk_small((int)x->rows, K, N, 2);
       // knob 3 (experiment): split the reduction of the long-K dgrads (N >= knob 4) s ways although their tiles fill half the chip
-      if (g_knobs[3] > 1 && N >= (g_knobs[4] > 0 ? g_knobs[4] : 8192) && N % (64 * g_knobs[3]) == 0 && dsplit == 1) dsplit = g_knobs[3];
+      if (KNOB(3) > 1 && N >= (KNOB(4) > 0 ? KNOB(4) : 8192) && N % (64 * KNOB(3)) == 0 && dsplit == 1) dsplit = KNOB(3);
       want_slab_main(p, (int)x->rows, K, dsplit);
     }
   }
@@ -268,8 +270,8 @@ struct LinearOp : Op {
       if (gu) { g.geglu = 2; g.geglu_group = ggroup; g.aux = p.P(gu); g.ldaux = gu->ld(); g.ldc = gu->ld(); }
       else if (dx.addend != NONE) { g.resid = p.GP(dx.addend); g.ldr = x->ld(); }
       if (dsplit > 1) { g.splitk = dsplit; g.slab = p.F(p.slab_main_off); }
-      g.prio = g_knobs[0];
-      if (g_knobs[6] > 0 && !gu && (g_knobs[8] <= 0 || N >= g_knobs[8])) g.cfg = g_knobs[6];     // experiment: configuration of the linear dgrads
+      g.prio = KNOB(0);
+      if (KNOB(6) > 0 && !gu && (KNOB(8) <= 0 || N >= KNOB(8))) g.cfg = KNOB(6);     // experiment: configuration of the linear dgrads
       CHK(launch_gemm(g, st));
     }
     return 0;
@@ -296,7 +298,7 @@ struct ConvOp : Op {
   size_t s2_planar_off = NONE;     // stride 2: the input gradient by output phase (GemmP::up2 == 2; knob 2 = 256: the general gather)
   int up_fs = 1, up_ds = 1, up_ws = 1;
   bool up_wg = false;       // the weight gradient too (needs whole 64-pixel reduction steps): the upsampled image is then not produced at all
-  bool up2() const { return x_low != nullptr && g_knobs[2] != 64; }
+  bool up2() const { return x_low != nullptr && KNOB(2) != 64; }
   void enable_up2(Plan& p, Act* xl, Plan::GradDst* udx) {
     if (stride != 1 || Cin % 64 || Cout % 64 || resid || rowvec) return;
     x_low = xl; up_dx = udx;
@@ -322,8 +324,10 @@ struct ConvOp : Op {
     Wo = (W - 1) / stride + 1;
   }
   int fwd(Plan& p, hipStream_t st) override {
-    if (s2x_off != NONE && g_knobs[2] == 512)      // (knob 2 = 512, experiment: measured neutral in the step -- 114.0-114.4 on, 113.8-114.3 off -- the general strided gather stays)
+#ifdef SDXL_DIAG
+    if (s2x_off != NONE && KNOB(2) == 512)      // (knob 2 = 512, experiment: measured neutral in the step -- 114.0-114.4 on, 113.8-114.3 off -- the general strided gather stays)
       return launch_conv3x3_s2_fwd(p.P(x), p.eng->Wp(w), p.eng->Wp(b), (bf16*)p.F(s2x_off), p.P(y), Bn, H, W, Cin, Cout, st);
+#endif
     if (up2())
       return launch_upconv3x3_fwd(p.P(x_low), p.eng->Wp(w), p.eng->Wp(b), (bf16*)p.F(weff_off), (bf16*)p.F(planar_off), p.P(y), Bn, H / 2,
                                   W / 2, Cin, Cout, up_fs, p.F(p.slab_main_off), st);
@@ -353,7 +357,7 @@ struct ConvOp : Op {
       rv32_ld = rowvec->ld();
     }
     if (x->need_grad) dx = p.grad_dst(x);
-    if (stride == 2 && H % 2 == 0 && W % 2 == 0 && Cin % 64 == 0 && Cout % 8 == 0 && !resid && !rowvec && (Bn * Ho * Wo) % 64 == 0)
+    if (SDXL_UP2_3 && stride == 2 && H % 2 == 0 && W % 2 == 0 && Cin % 64 == 0 && Cout % 8 == 0 && !resid && !rowvec && (Bn * Ho * Wo) % 64 == 0)
       s2x_off = p.alloc(sizeof(bf16) * (size_t)4 * upconv_plane_rows(Bn, Ho, Wo) * Cin);
     if (x->need_grad && stride == 2 && H % 2 == 0 && W % 2 == 0 && Cout % 64 == 0 && Cin % 8 == 0)
       s2_planar_off = p.alloc(sizeof(bf16) * (size_t)4 * upconv_plane_rows(Bn, Ho, Wo) * Cin);
@@ -370,14 +374,16 @@ struct ConvOp : Op {
     const bf16* dy = p.GP(dy_off);
     const long Mo = (long)Bn * Ho * Wo;
     if (resid && !resid_alias) CHK(launch_add(p.GP(dres.addend), dy, p.GP(dres.out), Mo * Cout, st));
-    const bool upw = up2() && up_wg && g_knobs[2] != 128;       // (knob 2 = 128: weight gradient on the upsampled image, A/B runs)
+    const bool upw = up2() && up_wg && KNOB(2) != 128;       // (knob 2 = 128: weight gradient on the upsampled image, A/B runs)
     if (up2()) CHK(launch_pixel_shuffle2(dy, (bf16*)p.F(planar_off), Bn, H / 2, W / 2, Cout, 0, st));      // dy in its four phases: dgrad and weight gradient read it
-    if (s2x_off != NONE && g_knobs[2] == 512) {
+#ifdef SDXL_DIAG
+    if (s2x_off != NONE && KNOB(2) == 512) {
       CHK(on_side(p, st, [&](hipStream_t s2) -> int {
         return launch_conv3x3_s2_wgrad(dy, (const bf16*)p.F(s2x_off), p.eng->Gp(w), p.eng->Gp(b), p.eng->emit_base ? p.eng->emit_base + w.off : nullptr,
                                        p.eng->emit_scale, first ? 0 : 1, Bn, H, W, Cin, Cout, splitk, p.F(p.slab_off), s2);
       }));
     } else
+#endif
     if (upw) {
       CHK(on_side(p, st, [&](hipStream_t s2) -> int {
         return launch_upconv3x3_wgrad((const bf16*)p.F(planar_off), p.P(x_low), p.F(dweff_off), p.eng->Gp(w), p.eng->Gp(b),
@@ -407,14 +413,14 @@ struct ConvOp : Op {
       if (drv.addend != NONE) { sdxl_set_error("conv: time-embedding row vector has another gradient writer"); return 3; }
       CHK(launch_colsum_f32_batched(dy, p.F(rv32_off), Bn, Ho * Wo, Cout, Cout, rv32_ld, st));
     }
-    if (x->need_grad && s2_planar_off != NONE && g_knobs[2] != 256) {
+    if (x->need_grad && s2_planar_off != NONE && KNOB(2) != 256) {
       CHK(launch_conv3x3_s2_dgrad(dy, p.eng->Wp(w), (bf16*)p.F(s2_planar_off), p.GP(dx.out), dx.addend != NONE ? p.GP(dx.addend) : nullptr, Bn, H, W,
-                                  Cin, Cout, g_knobs[0], st));
+                                  Cin, Cout, KNOB(0), st));
     } else
     if (x->need_grad && up2()) {      // straight into the low-resolution gradient (the UpsampleOp's backward is a no-op then)
       CHK(launch_upconv3x3_dgrad(nullptr, (const bf16*)p.F(weff_off), (bf16*)p.F(planar_off), p.GP(up_dx->out),
                                  up_dx->addend != NONE ? p.GP(up_dx->addend) : nullptr, Bn, H / 2, W / 2, Cin, Cout, up_ds,
-                                 p.F(p.slab_main_off), g_knobs[0], st));
+                                 p.F(p.slab_main_off), KNOB(0), st));
     } else
     if (x->need_grad) {
       GemmP g;
@@ -427,8 +433,8 @@ struct ConvOp : Op {
       g.flip = 1; g.b_tap_stride = Cin;
       if (dx.addend != NONE) { g.resid = p.GP(dx.addend); g.ldr = Cin; }
       if (dsplit > 1) { g.splitk = dsplit; g.slab = p.F(p.slab_main_off); }
-      g.prio = g_knobs[0];
-      if (g_knobs[7] > 0) g.cfg = g_knobs[7];     // experiment: configuration of the conv dgrads
+      g.prio = KNOB(0);
+      if (KNOB(7) > 0) g.cfg = KNOB(7);     // experiment: configuration of the conv dgrads
       CHK(launch_gemm(g, st));
     }
     return 0;
@@ -486,7 +492,7 @@ struct LayerNormOp : Op {
     // dbeta as a leaf pass of their own on the side stream (re-reads x, dy: 21 MB, from L2 / MALL) -- step -0.7 ms against the fused
     // form (dx + per-block parameter partial sums in one pass: 180 VGPRs + 40 KiB LDS, one block per CU when co-running;
     // knob 10 = 2 selects it, A/B runs).  Round 2 measured the two forms equal; since then the main stream became the critical one.
-    if (g_knobs[10] != 2) {
+    if (KNOB(10) != 2) {
       CHK(launch_layernorm_bwd(p.P(x), p.GP(dy_off), p.eng->Wp(gm), p.F(stats_off), p.GP(dx.out), p.GP(dx.addend), nullptr, nullptr, (int)x->rows, C, st));
       const bf16* xp = p.P(x); const bf16* dyp = p.GP(dy_off); const float* sp = p.F(stats_off);
       float* dg = p.eng->Gp(gm); float* db = p.eng->Gp(bt); const int Mr = (int)x->rows, Cc = C;
@@ -562,7 +568,7 @@ struct AttnOp : Op {
     if (bad) { sdxl_set_error("attention: operand gradient has another writer"); return 3; }
     AttnP a;
     fill(p, a, true);
-    a.prio = g_knobs[1];
+    a.prio = KNOB(1);
     if (self) return launch_attn_bwd(a, st);
     // cross attention: dK | dV (this block's slice of the grouped projection's gradient) is read by nothing before that
     // projection's weight gradient, a leaf on the side stream -- so the dK / dV kernel (+ its partial reduce) goes there too,
@@ -605,7 +611,7 @@ struct UpsampleOp : Op {
   ConvOp* fused = nullptr;     // the convolution that consumes y works on x directly (ConvOp::up2): y is its weight gradient's operand only
   UpsampleOp(Act* x_, Act* y_, int B_, int H_, int W_, int C_) : x(x_), y(y_), Bn(B_), H(H_), W(W_), C(C_) {}
   int fwd(Plan& p, hipStream_t st) override {
-    if (fused && fused->up2() && fused->up_wg && g_knobs[2] != 128) return 0;      // nothing reads y
+    if (fused && fused->up2() && fused->up_wg && KNOB(2) != 128) return 0;      // nothing reads y
     if (fused && fused->up2() && !p.eng->use_graphs) {   // off the critical stream: nothing reads y before the backward's side-stream weight gradient
                                                          // (not under graph capture: the forward's capture ends with nothing to join the side stream)
       const bf16* xp = p.P(x); bf16* yp = p.P(y);
@@ -722,7 +728,7 @@ struct Builder {
   // (256-byte interleave); 64 padding columns spread them (NN 4096 x 1280 x 10240: DMA-only loop 172 -> 133 us,
   // profiles/r04a_cr256_ld_sensitivity.txt).  The padded tensor is the parent of a column view, as the grouped K | V projection's slices are.
   Act* wide_act(long rows, int cols) {
-    if (g_knobs[18] == 1 || cols % 512) return pl->new_act(rows, cols);
+    if (KNOB(18) == 1 || cols % 512) return pl->new_act(rows, cols);
     return pl->view(pl->new_act(rows, cols + 64), 0, cols);
   }
   // fused projection of several [Ni, K] source matrices into one [sum Ni, K] native matrix (no bias)
@@ -814,7 +820,7 @@ struct Builder {
     // packing group 64: the forward projection then runs on the 256 x 256 kernel, whose register epilogue has value and gate of
     // a channel in one lane (131 vs 156 us at level 2: the 128-row kernel stages the fp32 tile through LDS, two barriers per 64
     // rows); the backward's dgrad epilogue takes any group.  (knob 5 = 80: round 2's packing for 160-column tiles, A/B runs)
-    const int group = (g_knobs[5] == 80 && (4 * C) % 80 == 0) ? 80 : 64;
+    const int group = (KNOB(5) == 80 && (4 * C) % 80 == 0) ? 80 : 64;
     LinearOp *ff1 = nullptr, *ff2 = nullptr;
     Act* u = linear(b + ".ff.net.0.proj", l3, C, 8 * C, true, nullptr, false, 2, &ff1, group);
     Act* g = pl ? wide_act(x->rows, 4 * C) : nullptr;

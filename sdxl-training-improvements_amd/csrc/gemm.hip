@@ -27,7 +27,9 @@
 
 static int g_mode256 = 1;     // 0: 128-row kernel only, 1: selection policy (gemm_use256), 2: 256 x 256 kernel wherever applicable
 static int g_force_cfg = 0;   // > 0: force that configuration of the 128-row kernel (microbenchmarks; sdxl_set_gemm_mode)
-static int g_sk_mode = 0;     // stream-K kernel (gemm_sk.hip): 0 never, 1 policy (gemm_use_sk), 2 wherever applicable
+#ifdef SDXL_DIAG
+static int g_sk_mode = 0;     // stream-K kernel (gemm_sk.hip, diagnostics build only): 0 never, 1 policy (gemm_use_sk), 2 wherever applicable
+#endif
 
 static constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
 static constexpr int gemm_smem_bytes(int BN, int S, int BK, int NW = 4) {
@@ -92,13 +94,13 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
   const int l16 = lane & 15, g = lane >> 4;
   int bx, by;
   xcd_tile_map(p.xcd_px, bx, by);   // XCD-aware tile order (gemm_tiles.h)
-  const int n0 = bx * BN;
-  const int m0 = by * BMT;
 #ifdef SDXL_GEMM_DIAG   // scratch diagnostics only (never defined in the product build): knock out one pipeline component
-  constexpr int dbg = SDXL_GEMM_DIAG;       // bit 0: no MFMA, bit 1: no DMA in the main loop, bit 2: no fragment reads
-#else
+  constexpr int dbg = SDXL_GEMM_DIAG;       // bit 0: no MFMA, bit 1: no DMA in the main loop, bit 2: no fragment reads,
+#else                                       // bit 3: every workgroup works on tile (0, 0) (all L2 hits after the first touch)
   constexpr int dbg = 0;
 #endif
+  const int n0 = (dbg & 8) ? 0 : bx * BN;
+  const int m0 = (dbg & 8) ? 0 : by * BMT;
 
   // reduction schedule
   int tap_fixed = 0, split = 0;
@@ -157,15 +159,15 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
   long ua = 0, ub = 0;       // CF: uniform element offsets of the step being staged
   int s_tap = 0, s_c = 0;    // CF, NT / NN: (tap, channel step) of the step being staged
   // CF, TN: this workgroup's tap.  (up2 == 3: stride-2 gather from the four phase planes of the input: kernel row 0 reads plane row i - 1)
-  const int tdy = p.up2 == 3 ? (tap_fixed / 3 == 0 ? -1 : 0) : p.up2 ? up2_dy(tap_fixed) : tap_fixed / 3 - 1;
-  const int tdx = p.up2 == 3 ? (tap_fixed % 3 == 0 ? -1 : 0) : p.up2 ? up2_dx(tap_fixed) : tap_fixed - (tap_fixed / 3) * 3 - 1;
-  const long s3_plane = p.up2 == 3 ? (long)(((tap_fixed / 3 != 1) ? 2 : 0) + ((tap_fixed % 3 != 1) ? 1 : 0)) * p.up_plane : 0;      // TN: phase plane of this tap's source pixels
+  const int tdy = (SDXL_UP2_3 && p.up2 == 3) ? (tap_fixed / 3 == 0 ? -1 : 0) : p.up2 ? up2_dy(tap_fixed) : tap_fixed / 3 - 1;
+  const int tdx = (SDXL_UP2_3 && p.up2 == 3) ? (tap_fixed % 3 == 0 ? -1 : 0) : p.up2 ? up2_dx(tap_fixed) : tap_fixed - (tap_fixed / 3) * 3 - 1;
+  const long s3_plane = (SDXL_UP2_3 && p.up2 == 3) ? (long)(((tap_fixed / 3 != 1) ? 2 : 0) + ((tap_fixed % 3 != 1) ? 1 : 0)) * p.up_plane : 0;      // TN: phase plane of this tap's source pixels
   const int up_phase = (CF && FORM == GEMM_NT && p.up2) ? m0 / p.up_plane : dn_phase;      // up2, NT (and NN of mode 2): this workgroup's output phase
   // CF, NT / NN: uniform element offsets of (tap s_tap, channel step s_c)
   auto tap_offsets = [&]() {
     int dy, dx, wtap;
     long plane = 0;
-    if (FORM == GEMM_NT && p.up2 == 3) {         // stride-2 forward on the four phase planes of the input: kernel row 0 / 1 / 2 = plane row i - 1 (a = 1) / i (0) / i (1)
+    if (FORM == GEMM_NT && (SDXL_UP2_3 && p.up2 == 3)) {         // stride-2 forward on the four phase planes of the input: kernel row 0 / 1 / 2 = plane row i - 1 (a = 1) / i (0) / i (1)
       const int ky = s_tap / 3, kx = s_tap - ky * 3;
       dy = ky == 0 ? -1 : 0; dx = kx == 0 ? -1 : 0;
       wtap = s_tap;
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
             for (int t = 0; t < 16; ++t) {
               if (t >= p.taps) break;
               int ys, xs;
-              if (FORM == GEMM_NT && p.up2 == 3) {
+              if (FORM == GEMM_NT && (SDXL_UP2_3 && p.up2 == 3)) {
                 ys = r.y + (t / 3 == 0 ? -1 : 0);
                 xs = r.x + (t % 3 == 0 ? -1 : 0);
               } else if (FORM == GEMM_NN && p.up2 == 2) {
@@ -1053,8 +1055,8 @@ int gemm_pick_splitk_small(int M, int N, int K, int kind) {     // K = the whole
   // sum -- 4 x 32 x 32, 1280 -> 1280: forward 170 (8-wave split-K groups) / 139 (8-wave 4 x 2) -> 117 us = 1 030 TFLOP/s, dgrad
   // 171 -> 120; step -0.8 ms.  Not for the linear layers (kinds 2, 3; knob 2 bits, experiment): the forward FF2 projection loses
   // 0.9 ms of the step to the slab round trip, the long dgrads are neutral beside the weight-gradient stream.
-  const bool conv_kind = (kind == 0 || kind == 1) && g_knobs[2] != 1;
-  const bool lin_kind = (kind == 2 || kind == 3) && g_knobs[2] > 1 && ((g_knobs[2] >> kind) & 1);
+  const bool conv_kind = (kind == 0 || kind == 1) && KNOB(2) != 1;
+  const bool lin_kind = (kind == 2 || kind == 3) && KNOB(2) > 1 && ((KNOB(2) >> kind) & 1);
   if ((conv_kind || lin_kind) && tiles > 128 && tiles <= 256 && K >= 5120) return 2;
   if (tiles >= 128) return 1;
   long s = 256 / tiles;
@@ -1074,6 +1076,8 @@ int gemm_pick_group(int M, int N, int taps, long red, int splitk) {
   return g < 2 ? 1 : (g > GEMM_MAX_GROUP ? GEMM_MAX_GROUP : g);
 }
 void gemm_set_mode(int mode) { g_mode256 = mode & 3; g_force_cfg = mode >> 2; }
+static int launch_gemm_impl(const GemmP& pin, hipStream_t st);
+#ifdef SDXL_DIAG
 void gemm_set_sk_mode(int mode) { g_sk_mode = mode; }
 int gemm_sk_mode() { return g_sk_mode; }
 // Policy of the stream-K kernel for a single problem (measured, profiles/r03*): where 256 x 256 tiles do not fill whole rounds
@@ -1084,7 +1088,6 @@ bool gemm_use_sk(const GemmP& p) {
   if (tiles * kt < 1024) return false;                 // less than 4 K-steps per CU
   return true;
 }
-static int launch_gemm_impl(const GemmP& pin, hipStream_t st);
 // several problems in ONE stream-K launch (a layer's dgrad + wgrad); every problem must satisfy gemm_sk_applicable
 int launch_gemm_multi(const GemmP* ps, int n, hipStream_t st) {
   if (!g_prof.on) return launch_gemm_sk(ps, n, st);
@@ -1103,6 +1106,7 @@ int launch_gemm_multi(const GemmP* ps, int n, hipStream_t st) {
   g_prof.recs.push_back({n > 1 ? 3 : ps[0].form, n, ps[0].M, ps[0].N, ps[0].K, 1});
   return rc;
 }
+#endif
 // SDXL_LAUNCH_LOG=<path>: one line per GEMM / attention launch in host launch order (= rocprofv3's Dispatch_Id order), so that a
 // kernel trace can be joined with the problems' shapes (profiles/tools/phase_rate.py)
 FILE* launch_log() {
@@ -1132,9 +1136,9 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
   ARG_CHECK(p.N % 8 == 0, "gemm: N=%d must be a multiple of 8", p.N);
   ARG_CHECK(p.lda % 8 == 0 && p.ldb % 8 == 0, "gemm: lda=%ld ldb=%ld must be multiples of 8", p.lda, p.ldb);
   if (p.up2) {
-    ARG_CHECK(p.taps == (p.up2 == 3 ? 9 : p.form == GEMM_NT || p.up2 == 2 ? 4 : 16) && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws &&
+    ARG_CHECK(p.taps == ((SDXL_UP2_3 && p.up2 == 3) ? 9 : p.form == GEMM_NT || p.up2 == 2 ? 4 : 16) && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws &&
               p.K % 64 == 0 && !p.geglu && p.group <= 1 && p.up_plane % 128 == 0 && p.up_rows <= p.up_plane && p.up_rows % (p.Hm * p.Wm) == 0 &&
-              (p.up2 == 3 ? (p.form == GEMM_NT ? p.M == p.up_rows : p.form == GEMM_TN && p.K == p.up_rows) :
+              ((SDXL_UP2_3 && p.up2 == 3) ? (p.form == GEMM_NT ? p.M == p.up_rows : p.form == GEMM_TN && p.K == p.up_rows) :
                p.up2 == 2 ? (p.form == GEMM_NN && p.M == 4 * p.up_plane && p.splitk <= 1)
                           : p.form == GEMM_NT ? p.M == 4 * p.up_plane : p.form == GEMM_NN ? p.M == p.up_rows : p.K == p.up_rows),
               "gemm: up2 needs the fast same-size gather (reduction %% 64 == 0), taps 4 (NT, M = 4 planes of a multiple of 128 rows) / 16 (NN, TN)");
@@ -1216,11 +1220,13 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
       return rc;
     }
   }
+#ifdef SDXL_DIAG
   if (g_sk_mode && !(p.form != GEMM_TN && p.splitk > 1) && (g_sk_mode == 2 ? gemm_sk_applicable(p) : gemm_use_sk(p))) {
     GemmP q = p;
     q.splitk = 1;
     return launch_gemm_sk(&q, 1, st);      // persistent stream-K kernel (gemm_sk.hip)
   }
+#endif
   {   // 256 x 256 kernel (gemm256.hip)
     if (g_mode256 && p.group <= 1 && !p.Cb && !(p.form != GEMM_TN && p.splitk > 1) && gemm256_applicable(p)) {
       // the forward GEGLU projection packed in groups of 64: the 256 x 256 kernel's register epilogue (value and gate of a channel
@@ -1365,6 +1371,7 @@ int launch_conv3x3_s2_dgrad(const bf16* dy, const bf16* w, bf16* planar, bf16* d
   return launch_pixel_shuffle2(planar, dx, B, Hl, Wl, Cin, 1, st, addend);
 }
 
+#ifdef SDXL_DIAG
 // Stride-2 3x3 convolution (pad 1, H and W even) through the fast same-size gather: x [B][H][W][Cin] is de-interleaved into its four
 // phase planes once (`xplanar` [4][plane][Cin], kept for the weight gradient), tap (ky, kx) then reads ONE plane at row offset -1 / 0
 int launch_conv3x3_s2_fwd(const bf16* x, const bf16* w, const bf16* bias, bf16* xplanar, bf16* y, int B, int H, int W, int Cin, int Cout,
@@ -1407,3 +1414,4 @@ int launch_conv3x3_s2_wgrad(const bf16* dy, const bf16* xplanar, float* dw, floa
   if (emit) { g.Cb = emit; g.cb_scale = emit_scale; }
   return launch_gemm(g, st);
 }
+#endif

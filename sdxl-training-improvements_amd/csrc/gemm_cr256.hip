@@ -370,11 +370,11 @@ bool cr256_applicable(const GemmP& p) {
 // per byte where the 128 x 160 kernel stages 71 -- the dgrad / weight-gradient pairs of a level-2 transformer block run 8-16 % faster
 // (profiles/r04a_pair_bench.txt).  A bias gradient forces 128-column tiles (its accumulators).
 int cr256_wgrad_cfg(int M, int N, long red, bool bias) {
-  if (g_knobs[16] == 1) return 0;
+  if (KNOB(16) == 1) return 0;
   if (red < 2048 || red > 8192 || red % CR_BK || M % 8 || N % 8) return 0;
   if ((long)M * N < 1280L * 1280L) return 0;
-  if (g_knobs[16] == 2) return 32;
-  if (g_knobs[16] == 3) return (bias || N % 160) ? 32 : 31;
+  if (KNOB(16) == 2) return 32;
+  if (KNOB(16) == 3) return (bias || N % 160) ? 32 : 31;
   if (bias || N % 160) return 32;
   // no bias: 160-column tiles for the small outputs that go out grouped (1280 x 1280 three at a time: 120 workgroups), 128-column
   // tiles where those give >= 150 workgroups (3840 x 1280: 150 against 120)

@@ -17,8 +17,19 @@
 //   15 = 1: no half-height tail workgroups in the 256 x 256 kernel
 //   16 co-resident 256-row kernel for the level-2 linear weight gradients: 0 policy, 1 off, 2 / 3 = 128 / 160-column tiles wherever allowed;
 //   17 its split-K workgroup target (0: none); 18 = 1: no padding columns on the feed-forward hidden tensors
+// The product library has NO knobs: KNOB(i) is the constant 0 (= the shipped policy) and every experiment branch below it folds away.
+// The diagnostics build (`build.py --diag`: -DSDXL_DIAG -> libsdxlstep_diag.so, include/sdxlstep_diag.h) keeps the table, sdxl_set_knob,
+// the stream-K kernel (gemm_sk.hip), the stride-2 forward / weight gradient on phase planes (GemmP::up2 == 3) and the W = 32 three-tap form:
+// measured, parity-tested experiments the step does not run (DESIGN.md sections 10, 11).
 #define SDXL_NKNOBS 24
+#ifdef SDXL_DIAG
 extern int g_knobs[SDXL_NKNOBS];
+#define KNOB(i) (g_knobs[(i)])
+constexpr bool SDXL_UP2_3 = true;
+#else
+#define KNOB(i) 0
+constexpr bool SDXL_UP2_3 = false;
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // bf16 MFMA GEMM family (gemm.hip).  C[M,N] = sum_k A(m,k) * B(k,n), fp32 accumulate.
@@ -118,6 +129,7 @@ int gemm_pick_splitk(int M, int N, int taps, long red);        // split-K factor
 int gemm_pick_splitk_small(int M, int N, int K, int kind = -1);               // split-K factor for NT / NN (bf16 output) launches of small problems
 int launch_gemm256(const GemmP& p, hipStream_t st);
 void gemm256_set_tail(bool on);     // half-height workgroups for the last partial round (default on; A/B runs)
+#ifdef SDXL_DIAG
 // persistent stream-K kernel (gemm_sk.hip): up to 4 problems (M, N multiples of 256, K of 64, no gather) in ONE launch, their
 // K-steps cut evenly over the CUs; partial tiles are handed to the tile's owner inside the launch (fixed order: reproducible)
 bool gemm_sk_applicable(const GemmP& p);
@@ -128,6 +140,7 @@ int gemm_sk_mode();
 bool gemm_use_sk(const GemmP& p);
 void gemm_sk_set_workers(int n);                      // > 0: force the worker count (microbenchmarks), 0: policy
 int gemm_sk_error(hipStream_t st, unsigned* out);     // != 0: an owner gave up waiting for a partial tile (results invalid)
+#endif
 // 3x3 weight gradient, three taps per workgroup (conv_wgrad3.hip): same-size stride-1 convolutions whose image width is a multiple of 64
 bool conv_wgrad3_applicable(const GemmP& p);
 bool conv_wgrad3_policy(int M, int N, long red, int Wm, int stride);   // the plan's choice (long reductions: the 128^2 / 64^2 levels)
@@ -226,10 +239,12 @@ int launch_pixel_shuffle2(const bf16* src, bf16* dst, int B, int H, int W, int C
 static inline long upconv_plane_rows(int B, int H, int W) { return ((long)B * H * W + 127) / 128 * 128; }
 int launch_upconv3x3_fwd(const bf16* x, const bf16* w, const bf16* bias, bf16* weff, bf16* planar, bf16* y, int B, int H, int W, int Cin,
                          int Cout, int splitk, float* slab, hipStream_t st);          // gemm.hip
+#ifdef SDXL_DIAG
 int launch_conv3x3_s2_fwd(const bf16* x, const bf16* w, const bf16* bias, bf16* xplanar, bf16* y, int B, int H, int W, int Cin, int Cout,
                           hipStream_t st);      // gemm.hip (GemmP::up2 == 3)
 int launch_conv3x3_s2_wgrad(const bf16* dy, const bf16* xplanar, float* dw, float* dbias, bf16* emit, float emit_scale, int accumulate, int B,
                             int H, int W, int Cin, int Cout, int splitk, float* slab, hipStream_t st);
+#endif
 int launch_conv3x3_s2_dgrad(const bf16* dy, const bf16* w, bf16* planar, bf16* dx, const bf16* addend, int B, int H, int W, int Cin,
                             int Cout, int prio, hipStream_t st);      // gemm.hip (GemmP::up2 == 2)
 int launch_upconv_unfold_grads(const float* dweff, float* dw, bf16* emit, float emit_scale, int accumulate, int Cout, int Cin, hipStream_t st);

@@ -655,7 +655,7 @@ int launch_layernorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const
   dim3 blk(256), grid(nblk);
 #define LN_LAUNCH(NV, LPR)                                                                                               \
   {                                                                                                                      \
-    if (!params && g_knobs[11] != 1) {                                                                                  \
+    if (!params && KNOB(11) != 1) {                                                                                  \
       if (accumulate) hipLaunchKernelGGL((ln_bwd_lean_kernel<NV, LPR, true>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, M);  \
       else hipLaunchKernelGGL((ln_bwd_lean_kernel<NV, LPR, false>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, M);            \
     } else if (params) {                                                                                                        \

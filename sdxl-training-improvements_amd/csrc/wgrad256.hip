@@ -191,7 +191,7 @@ bool wgrad256_applicable(const GemmP& p) {
 int wgrad256_pick_splitk(int M, int N, long red) {
   const long tiles = (long)cdiv(M, WL_BM) * cdiv(N, WL_BN);
   const long ktiles = red / WL_BK;
-  const long target = g_knobs[13] > 0 ? g_knobs[13] : 144;
+  const long target = KNOB(13) > 0 ? KNOB(13) : 144;
   long s = (target + tiles / 2) / tiles;
   if (s < 1) s = 1;
   while (s > 1 && ktiles / s < 16) --s;

@@ -1,12 +1,27 @@
 """ctypes binding of libsdxlstep.so (include/sdxlstep.h).  No fallback: if the HIP library is missing or a
-call fails this raises -- the product path never silently degrades to PyTorch ops or to the CPU oracle."""
+call fails this raises -- the product path never silently degrades to PyTorch ops or to the CPU oracle.
+
+SDXL_DIAG=1 in the environment (or use_diag() before the first load()) selects libsdxlstep_diag.so, the -DSDXL_DIAG build with the
+experiment ABI of include/sdxlstep_diag.h part 2 (knobs, stream-K, ...): A/B tooling and the tests marked `diag` only."""
 from __future__ import annotations
 
 import ctypes as C
 from pathlib import Path
 
+import os
+
 HERE = Path(__file__).resolve().parent
-LIB_PATH = HERE / "libsdxlstep.so"
+DIAG = os.environ.get("SDXL_DIAG", "") == "1"
+LIB_PATH = HERE / ("libsdxlstep_diag.so" if DIAG else "libsdxlstep.so")
+
+
+def use_diag() -> None:
+    """select the diagnostics build (before the first load())"""
+    global DIAG, LIB_PATH
+    if _lib is not None and not DIAG:
+        raise SdxlError("use_diag() after the product library has been loaded")
+    DIAG, LIB_PATH = True, HERE / "libsdxlstep_diag.so"
+
 
 
 class SdxlError(RuntimeError):
@@ -77,8 +92,6 @@ SIGNATURES = {
     "sdxl_op_conv3x3_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "sdxl_op_upconv3x3_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "sdxl_op_upconv3x3_dgrad": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "sdxl_op_conv3x3_s2_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "sdxl_op_conv3x3_s2_wgrad": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "sdxl_op_conv3x3_s2_dgrad": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "sdxl_op_upconv3x3_wgrad": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "sdxl_op_conv3x3_dgrad": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -101,15 +114,23 @@ SIGNATURES = {
     "sdxl_op_ff_geglu_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sdxl_op_ff_geglu_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sdxl_op_loss": [_P(LossConfig), _P(Batch), _vp, _vp, _vp, _f, _vp, _i, _vp],
-    "sdxl_probe_layout": [_vp, _vp],
     "sdxl_profile_gemm_begin": [],
-    "sdxl_set_gemm_mode": [_i],
     "sdxl_profile_gemm_end": [_P(C.c_double), _P(C.c_double), _P(_i)],
+}
+# include/sdxlstep_diag.h part 1: test hooks, exported by the product library too
+TEST_HOOK_SIGNATURES = {
+    "sdxl_probe_layout": [_vp, _vp],
+    "sdxl_set_gemm_mode": [_i],
     "sdxl_debug_act_checksums": [_vp, _P(C.c_ulonglong), _i, _P(_i), _i],
+}
+# include/sdxlstep_diag.h part 2: experiment ABI, exported by libsdxlstep_diag.so only
+DIAG_SIGNATURES = {
     "sdxl_set_knob": [_i, _i],
     "sdxl_set_sk_mode": [_i, _i],
     "sdxl_sk_error": [_vp, _P(C.c_uint)],
     "sdxl_op_gemm_sk": [_i, _P(_i), _P(_vp), _P(_vp), _P(_vp), _P(_i), _P(_i), _P(_i), _P(_vp), _P(_vp), _P(_i), _vp],
+    "sdxl_op_conv3x3_s2_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "sdxl_op_conv3x3_s2_wgrad": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
 }
 
 _lib = None
@@ -121,12 +142,16 @@ def load() -> C.CDLL:
     if _lib is not None:
         return _lib
     if not LIB_PATH.exists():
-        raise SdxlError(f"{LIB_PATH} is missing -- build it with `python {HERE / 'build.py'}` "
+        raise SdxlError(f"{LIB_PATH} is missing -- build it with `python {HERE / 'build.py'}{' --diag' if DIAG else ''}` "
                         "(there is no PyTorch/CPU fallback for the training step)")
     lib = C.CDLL(str(LIB_PATH))
     lib.sdxl_last_error.restype = C.c_char_p
     lib.sdxl_last_error.argtypes = []
-    for name, args in SIGNATURES.items():
+    sigs = dict(SIGNATURES)
+    sigs.update(TEST_HOOK_SIGNATURES)
+    if DIAG:
+        sigs.update(DIAG_SIGNATURES)
+    for name, args in sigs.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = args
         fn.restype = C.c_int

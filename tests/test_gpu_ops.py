@@ -42,6 +42,14 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def knob(L, kid, value):
+    """experiment knob of the DIAGNOSTICS build (sdxl_set_knob); False against the product library, which has none"""
+    if not lib.DIAG:
+        return False
+    lib.check(L.sdxl_set_knob(kid, value))
+    return True
+
+
 def relerr(got, ref):
     got, ref = got.float(), ref.float()
     return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-20))
@@ -153,6 +161,7 @@ def _sk_launch(L, probs, workers):
     assert e.value == 0, f"stream-K hand-off gave up waiting (error word {e.value})"
 
 
+@pytest.mark.diag
 @pytest.mark.parametrize("workers", [1, 7, 37, 100, 255, 256, 0])
 def test_gemm_stream_k_forms_and_partitions(L, workers):
     """Persistent stream-K kernel (gemm_sk.hip): every form, with partitions that cut tiles into two, three and many pieces
@@ -176,6 +185,7 @@ def test_gemm_stream_k_forms_and_partitions(L, workers):
     report("sk tn bias grad", db, dy.float().sum(0), 1e-4)
 
 
+@pytest.mark.diag
 def test_gemm_stream_k_fused_dgrad_wgrad_is_reproducible(L):
     """A layer's dgrad (NN) and wgrad (TN) in ONE launch, as the work list is meant to be used; the partition is a function of the
     shapes only, the partials are added in worker order: repeated launches give identical bits."""
@@ -211,13 +221,13 @@ def test_gemm_tn_long_reduction_wgrad256(L, M, N, K, splitk):
     report("wgrad256 bias grad", db, a.float().sum(0), 1e-4)
     lib.check(L.sdxl_op_gemm(2, ptr(a), ptr(b), ptr(out), M, N, K, None, None, 1, splitk, stream()))
     report("wgrad256 +=", out, 2 * ref, tol)
-    lib.check(L.sdxl_set_knob(9, 1))
-    try:
-        o1 = torch.zeros(M, N, dtype=torch.float32, device=dev())
-        lib.check(L.sdxl_op_gemm(2, ptr(a), ptr(b), ptr(o1), M, N, K, None, None, 0, 0, stream()))
-    finally:
-        lib.check(L.sdxl_set_knob(9, 0))
-    report("wgrad256 vs 128x160 kernel", out * 0.5, o1, tol)
+    if knob(L, 9, 1):                                  # (diagnostics build: the 128 x 160 kernel on the same problem)
+        try:
+            o1 = torch.zeros(M, N, dtype=torch.float32, device=dev())
+            lib.check(L.sdxl_op_gemm(2, ptr(a), ptr(b), ptr(o1), M, N, K, None, None, 0, 0, stream()))
+        finally:
+            knob(L, 9, 0)
+        report("wgrad256 vs 128x160 kernel", out * 0.5, o1, tol)
 
 
 @pytest.fixture(params=[31, 32])
@@ -441,9 +451,9 @@ def test_conv3x3_stride2_dgrad_by_output_phase(L, B, H, W, Cin, Cout):
         dx = torch.empty(B, H, W, Cin, dtype=torch.bfloat16, device=dev())
         lib.check(L.sdxl_op_conv3x3_s2_dgrad(ptr(dy), ptr(w), ptr(planar), ptr(dx), ptr(addend) if addend is not None else None, B, H, W, Cin, Cout, stream()))
         report(f"conv s2 dgrad by phase {B}x{H}x{W} {Cin}->{Cout} addend={addend is not None}", dx, xr.grad + (addend.float() if addend is not None else 0), 8e-3)
-    if Cin % 64 or (B * (H // 2) * (W // 2)) % 64:
+    if Cin % 64 or (B * (H // 2) * (W // 2)) % 64 or not lib.DIAG:
         return
-    # forward and weight gradient of the same convolution on the four phase planes of x (GemmP::up2 == 3)
+    # diagnostics build: forward and weight gradient of the same convolution on the four phase planes of x (GemmP::up2 == 3)
     bias = rnd(Cout, seed=34)
     xplanar = torch.empty(4 * ((B * (H // 2) * (W // 2) + 127) // 128 * 128), Cin, dtype=torch.bfloat16, device=dev())
     y = torch.empty(B, H // 2, W // 2, Cout, dtype=torch.bfloat16, device=dev())
@@ -510,11 +520,12 @@ def test_conv3x3_wgrad_three_taps_per_workgroup(L, B, H, W, Cin, Cout, splitk):
     tap (image borders, row ends at the K-step seams, batch seams, ragged channel tiles), bias gradient, overwrite and += , the
     plan's split-K and forced ones; and against the one-tap-per-workgroup kernel."""
     if W == 32:
-        lib.check(L.sdxl_set_knob(14, 2))          # the W = 32 form is not the plan's default (see conv_wgrad3_policy)
+        if not knob(L, 14, 2):                     # the W = 32 form exists in the diagnostics build only (see conv_wgrad3_policy)
+            pytest.skip("W = 32 three-tap form: diagnostics build only")
     try:
         _conv_wgrad3_case(L, B, H, W, Cin, Cout, splitk)
     finally:
-        lib.check(L.sdxl_set_knob(14, 0))
+        knob(L, 14, 0)
 
 
 def _conv_wgrad3_case(L, B, H, W, Cin, Cout, splitk):
@@ -532,15 +543,15 @@ def _conv_wgrad3_case(L, B, H, W, Cin, Cout, splitk):
     report("conv wgrad3 bias grad", db, dy.float().sum((0, 1, 2)), 1e-4)
     lib.check(L.sdxl_op_conv3x3_wgrad2(ptr(x), ptr(dy), ptr(dw), None, B, H, W, Cin, Cout, 1, splitk, 1, stream()))
     report("conv wgrad3 +=", dw, 2 * ref, tol)
-    lib.check(L.sdxl_set_knob(12, 1))                                         # the one-tap kernel on the same problem
-    try:
-        dw1 = torch.zeros(Cout, 9, Cin, dtype=torch.float32, device=dev())
-        lib.check(L.sdxl_op_conv3x3_wgrad2(ptr(x), ptr(dy), ptr(dw1), None, B, H, W, Cin, Cout, 1, 0, 0, stream()))
-    finally:
-        lib.check(L.sdxl_set_knob(12, 0))
-        if W == 32:
-            lib.check(L.sdxl_set_knob(14, 2))
-    report("conv wgrad3 vs one-tap kernel", dw * 0.5, dw1, tol)
+    if knob(L, 12, 1):                                                        # (diagnostics build: the one-tap kernel on the same problem)
+        try:
+            dw1 = torch.zeros(Cout, 9, Cin, dtype=torch.float32, device=dev())
+            lib.check(L.sdxl_op_conv3x3_wgrad2(ptr(x), ptr(dy), ptr(dw1), None, B, H, W, Cin, Cout, 1, 0, 0, stream()))
+        finally:
+            knob(L, 12, 0)
+            if W == 32:
+                knob(L, 14, 2)
+        report("conv wgrad3 vs one-tap kernel", dw * 0.5, dw1, tol)
 
 
 def _attn_ref(q, k, v, heads):
@@ -695,13 +706,14 @@ def test_layernorm_fwd_bwd(L, M, Cc):
     dx = torch.empty_like(x)
     dg = torch.zeros(Cc, dtype=torch.float32, device=dev())
     db = torch.zeros(Cc, dtype=torch.float32, device=dev())
-    for form in (0, 2):      # 0: the plan's default (lean dx kernel + parameter-gradient pass), 2: dx and parameter partial sums in one pass
-        lib.check(L.sdxl_set_knob(10, form))
+    # 0: the plan's form (lean dx kernel + parameter-gradient pass); 2 (diagnostics build): dx and parameter partial sums in one pass
+    for form in ((0, 2) if lib.DIAG else (0,)):
+        knob(L, 10, form)
         dx.zero_(); dg.zero_(); db.zero_()
         try:
             lib.check(L.sdxl_op_layernorm_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(stats), ptr(dx), ptr(dg), ptr(db), M, Cc, 0, stream()))
         finally:
-            lib.check(L.sdxl_set_knob(10, 0))
+            knob(L, 10, 0)
         report(f"layernorm dx (form {form})", dx, xr.grad, 1e-2)
         report("layernorm dgamma", dg, gr.grad, 2e-3)
         report("layernorm dbeta", db, br.grad, 2e-3)

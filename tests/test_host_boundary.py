@@ -15,13 +15,22 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 def test_header_symbols_all_exported_and_bound():
-    hdr = (ROOT / "include" / "sdxlstep.h").read_text()
-    declared = set(re.findall(r"\b(sdxl_[a-z0-9_]+)\s*\(", hdr))
+    """include/sdxlstep.h (the boundary) <-> lib.SIGNATURES <-> the product .so, symbol for symbol; the test hooks and the experiment
+    ABI live in include/sdxlstep_diag.h: part 1 is exported by the product library too, part 2 by the diagnostics build ONLY (the
+    product library must not carry the experiments)."""
+    names = lambda text: set(re.findall(r"\b(sdxl_[a-z0-9_]+)\s*\(", text))
+    declared = names((ROOT / "include" / "sdxlstep.h").read_text())
+    dh = (ROOT / "include" / "sdxlstep_diag.h").read_text()
+    part1, part2 = dh.split("part 2: experiment ABI", 1)
+    hooks, experiments = names(part1.split("part 1: test hooks", 1)[1]), names(part2)
+    assert len(declared) <= 58 and not (declared & (hooks | experiments))
     L = lib.load()
-    for name in sorted(declared):
-        assert hasattr(L, name), f"{name} declared in sdxlstep.h but not exported by libsdxlstep.so"
-    bound = set(lib.SIGNATURES) | {"sdxl_last_error"}
-    assert declared == bound, (declared - bound, bound - declared)
+    for name in sorted(declared | hooks):
+        assert hasattr(L, name), f"{name} declared but not exported by {lib.LIB_PATH.name}"
+    assert declared == set(lib.SIGNATURES) | {"sdxl_last_error"}, (declared ^ (set(lib.SIGNATURES) | {"sdxl_last_error"}))
+    assert hooks == set(lib.TEST_HOOK_SIGNATURES) and experiments == set(lib.DIAG_SIGNATURES)
+    for name in sorted(experiments):
+        assert hasattr(L, name) == lib.DIAG, f"{name}: experiment ABI {'missing from the diagnostics' if lib.DIAG else 'present in the PRODUCT'} library"
 
 
 def test_fails_loudly_without_gpu():
