@@ -32,7 +32,8 @@ FLOP_PER_IMAGE_1024 = 20.28e12      # fwd+bwd, BASELINE.md section 2 (2*M*N*K of
 FLOP_PER_IMAGE_1344x768 = 19.93e12          # 1344x768 (latent 96x168)
 FLOP_PER_IMAGE_512 = 4.77e12
 PEAK_BF16_TFLOPS = 2516.6           # 256 CU x 2.4 GHz x 4096 FLOP/clk/CU (MI355X dense bf16 MFMA)
-PMC_SUMMARY = "r03_pmc_step_summary.json"     # committed PMC passes (profiles/tools/measure_step.sh), stamped with the commit they were taken at
+ATTN_FLOP_PER_IMAGE_1024 = 2.351e12   # of those, attention QK^T / PV fwd + bwd (3.135 of 27.045 TFLOP per B = 4 forward)
+PMC_SUMMARY = "r04_pmc_step_summary.json"     # committed PMC passes (profiles/tools/measure_step.sh), stamped with the commit they were taken at
 
 
 def kernels_changed_since(commit):
@@ -332,13 +333,21 @@ def main():
         stale = kernels_changed_since(traffic_commit) if traffic_commit else None
         if stale:
             traffic = None
+        # two bases, both stated: `achieved` / `frac` = the flops the family EXECUTES (the up-sampler convolutions run on the low-resolution
+        # image: 16 instead of 36 tap-pixels per output quad) over the event-bracketed time; `frac_algorithmic` = the reference
+        # formulation's flops of the family (BASELINE.md section 2 minus attention) over the same time -- the basis of `step_mfma_frac`.
+        alg = None
+        if wl["flop_per_image"] == FLOP_PER_IMAGE_1024 and len(buckets) == 1 and ms.value > 0:
+            alg = (FLOP_PER_IMAGE_1024 - ATTN_FLOP_PER_IMAGE_1024) * wl["B"] * args.profile_steps / (ms.value * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "flops_basis": "executed (frac), algorithmic = reference formulation (frac_algorithmic)",
+                "achieved_algorithmic": None if alg is None else round(alg, 1),
+                "frac_algorithmic": None if alg is None else round(alg / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "traffic_note": ("the committed PMC summary was taken at commit %s and the kernel sources changed since: re-run "
                                  "profiles/tools/measure_step.sh" % traffic_commit) if stale else
                                 ("bytes per step over all launches of the family (fabric side, MALL hits included), PMC passes at commit %s; "
                                  "algorithmic operand + result bytes ~94e9" % traffic_commit),
-                "kernel": "gemm_kernel<NT|NN|TN, conv|linear> (128-row tiles) + gemm256_kernel (256x256 tiles) + conv_wgrad3_kernel (3x3 wgrad, three taps per workgroup) + wgrad256_kernel (long-reduction linear wgrad, 256x160 tiles): bf16 MFMA 16x16x32",
+                "kernel": "gemm_kernel<NT|NN|TN, conv|linear> (128-row tiles) + gemm256_kernel (256x256 tiles) + conv_wgrad3_kernel (3x3 wgrad, three taps per workgroup) + wgrad256_kernel (long-reduction linear wgrad, 256x160 tiles) + cr256_kernel (co-resident 256-row tiles: level-2 linear wgrads): bf16 MFMA 16x16x32",
                 "launches_per_step": n.value // args.profile_steps,
                 "gemm_ms_per_step": round(ms.value / args.profile_steps, 2),
                 "gemm_tflop_per_step": round(fl.value / args.profile_steps / 1e12, 2)}

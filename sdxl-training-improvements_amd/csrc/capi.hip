@@ -180,6 +180,7 @@ int sdxl_plan(sdxl_handle* h, int B, int H, int W, int ctx, size_t* ws_bytes) {
     e.build(p.get());
     it = e.plans.emplace(key, std::move(p)).first;
   }
+  if (e.cur != it->second.get()) e.drop_pending();
   e.cur = it->second.get();
   if (ws_bytes) *ws_bytes = e.cur->ws_bytes;
   return 0;
@@ -310,6 +311,7 @@ static unsigned loss_cfg_bits(const sdxl_loss_config& lc, bool tag) {
 
 static int run_forward_ops(Engine& e, hipStream_t st) {
   Plan& p = *e.cur;
+  e.drop_pending();      // (leftovers of a backward that failed half way)
   const bool side = e.use_side && e.side && !gemm_profiling();
   if (side) {   // hoisted ops (inputs-only dependencies) run on the side stream, concurrently with the first layers
     HIP_CHECK_RET(hipEventRecord(e.ev_hoist, st));
@@ -325,6 +327,11 @@ static int run_forward_ops(Engine& e, hipStream_t st) {
       waited = true;
     }
     CHK(op->fwd(p, st));
+  }
+  if (side && e.side_dirty) {      // forward work put on the side stream (an upsampled image only a weight gradient reads): the caller's
+    HIP_CHECK_RET(hipEventRecord(e.ev_join, e.side));      // stream owns everything the forward produced once this returns
+    HIP_CHECK_RET(hipStreamWaitEvent(st, e.ev_join, 0));
+    e.side_dirty = false;
   }
   return 0;
 }
@@ -389,7 +396,14 @@ int sdxl_segment_range(sdxl_handle* h, int k, size_t* off, size_t* n) {
   return 0;
 }
 
+static int run_backward_segment_body(Engine& e, int k, bool first, hipStream_t st);
 static int run_backward_segment(Engine& e, int k, bool first, hipStream_t st) {
+  if (k == 0) e.drop_pending();
+  const int rc = run_backward_segment_body(e, k, first, st);
+  if (rc) e.drop_pending();      // an op failed: its queued leaves / grouped weight gradients must not ride on a later step's fork event
+  return rc;
+}
+static int run_backward_segment_body(Engine& e, int k, bool first, hipStream_t st) {
   Plan& p = *e.cur;
   int s = e.nseg - 1 - k;
   e.ev_used = 0;   // per-op events are consumed in order; a segment's waits are all enqueued before the pool is reused

@@ -145,6 +145,10 @@ struct Engine {
   std::vector<std::function<int(hipStream_t)>> side_leaves;
   std::vector<LnRedEntry> ln_pending;     // LayerNorm backward launches whose dgamma | dbeta partials are not reduced yet
   int flush_ln_params(Plan& p, hipStream_t main);
+  // Everything queued for a later launch holds raw workspace pointers of the plan and step it was queued in: dropped at the start of a
+  // forward / of a backward, when a backward segment fails half way, and when the current plan changes (never launched against another
+  // step's or plan's buffers).
+  void drop_pending() { side_leaves.clear(); wg_pending.clear(); ln_pending.clear(); }
   bool side_dirty = false;       // the side stream has work the caller's stream has not joined yet
   // hipGraph replay of the step (sdxl_set_graph_mode, OFF by default): forward (+ loss) and backward are captured once per
   // (plan, configuration) -- both streams, every event edge -- and replayed with one hipGraphLaunch, on an engine-owned
