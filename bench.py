@@ -187,6 +187,11 @@ def main():
                     help="N > 1: all-reduce of the bf16 gradient buckets overlapped with the backward (default: what north_star "
                          "names), or zero1 = reduce-scatter of the buckets + the all-gather of the (updated) parameters, BOTH inside "
                          "the timed step (the same bytes on the wire as the all-reduce; the sharded update itself is reported apart)")
+    ap.add_argument("--exchange-shadow", default=None, metavar="CH[:LDS_KB[:GBPS]]",
+                    help="N = 1 only: price the co-residency of the exchange's device kernels without a node -- after every backward segment "
+                         "a stand-in kernel of CH workgroups x 256 threads (LDS_KB of LDS each, default 64) streams a bucket-sized buffer on "
+                         "a third stream for bucket_bytes x 2 x 7/8 / GBPS (default 300 GB/s: reduce-scatter + all-gather over 7 xGMI links)")
+    ap.add_argument("--max-nchannels", type=int, default=None, help="N > 1: NCCL_MAX_NCHANNELS for RCCL (its kernels take one workgroup per channel)")
     ap.add_argument("--no-emit", action="store_true", help="N > 1 A/B: cast the fp32 gradient arena per bucket instead of bf16 wgrad epilogues")
     ap.add_argument("--profile-steps", type=int, default=1, help="extra steps with per-launch GEMM event timing")
     ap.add_argument("--gemm-mode", type=int, default=None, help="A/B runs: sdxl_set_gemm_mode (0 = 128-row kernel only)")
@@ -208,6 +213,8 @@ def main():
     backend = os.environ.get("SDXL_BENCH_BACKEND", "nccl")
     if os.environ.get("SDXL_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
+    if args.max_nchannels:
+        os.environ["NCCL_MAX_NCHANNELS"] = str(args.max_nchannels)
     if world > 1 and backend == "nccl" and rank == 0 and "NCCL_DEBUG" not in os.environ:
         # rank 0 logs RCCL's topology / algorithm choices to a file; the lines end up in config.exchange.rccl
         os.environ["SDXL_RCCL_LOG"] = f"/tmp/sdxl_rccl_{os.getpid()}.log"
@@ -257,6 +264,20 @@ def main():
     sharded_exchange = isinstance(sync, D.ShardedGradSync)
     scale = 1.0 / world / accum
     micro = [0]
+    shadow = None
+    if args.exchange_shadow and world == 1:
+        f = args.exchange_shadow.split(":")
+        shadow = {"channels": int(f[0]), "lds_kb": int(f[1]) if len(f) > 1 else 64, "gbps": float(f[2]) if len(f) > 2 else 300.0}
+        shadow_buf = torch.zeros(max(n for _o, n in net.segment_ranges()), dtype=torch.bfloat16, device=dev)
+        comm_stream = torch.cuda.Stream(device=dev)
+
+        def shadow_on_segment(k, off, n):
+            # called with the engine's side stream current (behind the segment's weight gradients), as the real cast + collective are;
+            # RCCL's kernel then runs on the process group's own stream: a third stream here
+            comm_stream.wait_stream(torch.cuda.current_stream())
+            us = 2.0 * n * 2 * 7 / 8 / shadow["gbps"] / 1e3              # bytes / (GB/s) -> us
+            lib.check(L.sdxl_op_exchange_shadow(C.c_void_p(shadow_buf.data_ptr()), n * 2, shadow["channels"], shadow["lds_kb"] * 1024,
+                                                float(us), C.c_void_p(comm_stream.cuda_stream)))
 
     def step():
         """one micro-step: (cycle start: zero grads) + loss prep + UNet forward + loss + UNet backward (+ at N > 1, on the cycle's
@@ -271,7 +292,13 @@ def main():
         exch = world > 1 and last
         if exch and emit:
             net.set_grad_emit(sync.comm, 1.0)
-        net.backward(scale, first, on_segment=sync.on_segment if exch else None, segment_stream=True)
+        net.backward(scale, first, on_segment=sync.on_segment if exch else (shadow_on_segment if shadow else None), segment_stream=True)
+        if shadow:
+            if shadow.get("_ev") is None:
+                shadow["_ev"] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            shadow["_ev"][0].record()                       # the backward's own end on the caller's stream ...
+            shadow["_ev"][1].record(comm_stream)            # ... and the last stand-in kernel's: the un-overlapped tail of the exchange
+            torch.cuda.current_stream().wait_stream(comm_stream)
         if exch:
             if emit:
                 net.set_grad_emit(None)
@@ -306,6 +333,9 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
+    if shadow and shadow.get("_ev"):
+        ev = shadow.pop("_ev")
+        shadow["tail_ms_last_step"] = round(max(0.0, ev[0].elapsed_time(ev[1])), 3)
     loss = net.read_loss()[0]
     net_param_elems = int(net.param_elems)       # bf16 gradient bytes sent (and, reduced, received) per rank and exchange = 2 x this
     images = world * wl["B"] * args.steps
@@ -403,13 +433,17 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": wl["desc"], "global_batch": wl["B"] * world, "parallelism": f"dp{world}",
-                          "exchange": None if world == 1 else {
+                          "exchange": ({"shadow": shadow, "what": "single GPU: a stand-in kernel per backward segment on a third stream (no bytes "
+                                        "leave the GPU); the step time beside it prices the exchange kernels' co-residency"} if shadow else None)
+                          if world == 1 else {
                               "what": ("reduce-scatter of the bf16 gradient buckets overlapped with the backward + all-gather of the parameter slices, "
                                        "both inside the timed step (ZeRO-1 wire pattern; the sharded update is in `optimizer`)") if sharded_exchange
                                       else "all-reduce of the bf16 gradient buckets overlapped with the backward, complete inside the timed step",
                               "every_n_micro_steps": accum,
                               "exchange_bytes_timed": 2 * net_param_elems,     # bf16 gradient arena per rank and exchange (in: RS / AR; out: AG / AR)
-                              "backend": backend, "rccl": rccl_info()},
+                              "backend": backend, "rccl": rccl_info(),
+                              "rccl_env": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS",
+                                                                         "RCCL_MSCCL_ENABLE") if os.environ.get(k) is not None}},
                           "weights": "synthetic (counter-hash init of the 2,567,463,684-parameter SDXL-base UNet)"},
                "step_time": step_stats,
                "step_tflops_per_gpu": round(step_tflops, 1),

@@ -27,6 +27,10 @@ int sdxl_set_gemm_mode(int mode);
  * order; synchronises the device.  n_out receives the number of activations. */
 int sdxl_debug_act_checksums(sdxl_handle* h, unsigned long long* out_host, int cap, int* n_out, int grads);
 
+/* stand-in for a collective's device kernel on one GPU (bench.py --exchange-shadow): `workgroups` x 256 threads holding `lds_bytes` of
+ * LDS each stream `buf` for `busy_us` microseconds; run beside the backward it prices the co-residency of the gradient exchange. */
+int sdxl_op_exchange_shadow(void* buf, size_t bytes, int workgroups, int lds_bytes, float busy_us, void* stream);
+
 /* ---- part 2: experiment ABI (diagnostics build only) ---- */
 /* experiment knobs of the plan (A/B runs; 0 = the shipped policy): see csrc/kernels.h.  Process-global, read at plan-build, forward
  * and backward time: set them before sdxl_plan / the first step and do not change them while a handle is in use. */

@@ -907,6 +907,9 @@ int sdxl_adamw_decay(void* shift, const void* p, size_t n, float decay, void* st
 }
 
 int sdxl_probe_layout(void* out, void* st) { return probe_layout(out, (hipStream_t)st); }
+int sdxl_op_exchange_shadow(void* buf, size_t bytes, int workgroups, int lds_bytes, float busy_us, void* st) {
+  return launch_exchange_shadow(buf, bytes, workgroups, lds_bytes, busy_us, (hipStream_t)st);
+}
 int sdxl_profile_gemm_begin(void) { return gemm_profile_begin(); }
 int sdxl_set_gemm_mode(int mode) {
   const int cfg = mode >> 2;

@@ -396,3 +396,41 @@ int launch_scale_f32(float* x, long n, const float* scale_dev, hipStream_t st) {
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
+
+// ---- exchange shadow (measurement hook, include/sdxlstep_diag.h part 1) ----
+// Stand-in for a collective's device kernel on a single GPU: `workgroups` x 256 threads with `lds_bytes` of LDS each (RCCL runs one such
+// workgroup per channel) read `buf` once and write it back (16-byte loads and stores, values unchanged), paced evenly over `busy_us`
+// microseconds of the 100 MHz real-time counter.  What it costs the step that runs beside it = the co-residency price of the gradient exchange's kernels,
+// before any multi-GPU node is available (bench.py --exchange-shadow).
+__global__ __launch_bounds__(256) void exchange_shadow_kernel(i32x4* __restrict__ buf, size_t n16, unsigned busy_ticks) {
+  extern __shared__ char shadow_lds[];
+  if (threadIdx.x == 0) shadow_lds[0] = 0;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  const size_t per = (n16 + gridDim.x - 1) / gridDim.x;
+  const size_t lo = per * blockIdx.x, hi = lo + per < n16 ? lo + per : n16;
+  const size_t nchunks = hi > lo ? (hi - lo + 255) / 256 : 1;
+  // PACED: the slice is read and written back exactly once, spread evenly over busy_ticks (a collective's kernel moves its bucket at the
+  // links' rate, not at the HBM's): chunk c may start once c / nchunks of the time has passed
+  size_t c = 0;
+  for (size_t i = lo; i < hi; i += 256, ++c) {
+    const unsigned long long due = (unsigned long long)((double)busy_ticks * (double)c / (double)nchunks);
+    while (__builtin_amdgcn_s_memrealtime() - t0 < due) __builtin_amdgcn_s_sleep(8);
+    if (i + threadIdx.x < hi) {
+      i32x4 v = __builtin_nontemporal_load(buf + i + threadIdx.x);
+      __builtin_nontemporal_store(v, buf + i + threadIdx.x);
+    }
+  }
+  while (__builtin_amdgcn_s_memrealtime() - t0 < busy_ticks) __builtin_amdgcn_s_sleep(8);
+}
+int launch_exchange_shadow(void* buf, size_t bytes, int workgroups, int lds_bytes, float busy_us, hipStream_t st) {
+  ARG_CHECK(buf && bytes >= 4096 && workgroups >= 1 && workgroups <= 256 && lds_bytes >= 16 && lds_bytes <= 160 * 1024 && busy_us > 0.f,
+            "exchange shadow: bad arguments");
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)exchange_shadow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(exchange_shadow_kernel, dim3(workgroups), dim3(256), lds_bytes, st, (i32x4*)buf, bytes / 16, (unsigned)(busy_us * 100.f));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}

@@ -697,8 +697,9 @@ struct Builder {
   std::map<std::string, int> tp_col;        // resnet prefix -> first column in tp_all
   long tp_total = 0;
   PRef wtp, btp;
-  Act* kv_all = nullptr;                     // [B*ctx][sum 2C]: cross-attention K | V of every transformer block
-  std::map<std::string, int> kv_col;        // transformer block prefix -> first column in kv_all
+  std::map<int, Act*> kv_all;                // per channel width C: [B*ctx][sum 2C] cross-attention K | V of every transformer block of that width
+  std::map<std::string, int> kv_col;        // transformer block prefix -> first column in its group's tensor
+  std::map<int, bool> kv_done;
   explicit Builder(Engine& e_, Plan* p_) : e(e_), pl(p_) {
     if (pl) { B = pl->B; H = pl->H; W = pl->W; ctx = pl->ctx; } else { B = H = W = ctx = 0; }
   }
@@ -806,7 +807,7 @@ struct Builder {
     Act* l2 = layernorm(b + ".norm2", x1, C);
     Act* q = linear(b + ".attn2.to_q", l2, C, C, false, nullptr);
     // K | V of the prompt embeddings: this block's 2C columns of the grouped projection (one GEMM for all blocks, run())
-    Act* kv = pl ? pl->view(kv_all, kv_col.at(b), 2 * C) : nullptr;
+    Act* kv = pl ? pl->view(kv_all.at(C), kv_col.at(b), 2 * C) : nullptr;
     (void)cross;
     Act* a2 = nullptr;
     if (pl) {
@@ -856,16 +857,21 @@ struct Builder {
       pl->in_tag_off = pl->alloc(sizeof(float) * B);
       tagseg(pl->add<EmbedInOp>(), PRef());
     }
-    auto register_kv = [&]() {
-      // Cross-attention K / V projections of ALL transformer blocks as ONE GEMM: they share the A operand (the prompt
-      // embeddings, [B*77][2048]) and depend on nothing else, so the 70 per-block launches (M = 308 rows: 119 TFLOP/s each)
-      // become one [308] x [sum 2C = 166 400] x [2048] problem on the side stream at the start of the forward, and their 70
-      // weight-gradient launches one TN GEMM.  The weight is registered (and the op placed) right before the first transformer
-      // block: in the backward its gradient is then complete -- and, a segment of its own (Engine::build), exchanged -- as soon
-      // as the last cross-attention backward has run, under the remaining ~25 ms of the backward, not after its end.
-      // Every block's attention reads / writes its column slice of the result.
+    auto register_kv = [&](int Cgrp) {
+      // Cross-attention K / V projections of all transformer blocks of one width as ONE GEMM: they share the A operand (the prompt
+      // embeddings, [B*77][2048]) and depend on nothing else, so the 70 per-block launches (M = 308 rows: 119 TFLOP/s each) become
+      // two problems on the side stream at the start of the forward -- [308] x [60 x 2560 = 153 600] x [2048] for the 1280-channel
+      // blocks, [308] x [10 x 1280] x [2048] for the 640-channel ones -- and their 70 weight-gradient launches two TN GEMMs.
+      // A group's weight is registered (and its op placed) right before the FIRST transformer block of its width: in the backward its
+      // gradient is then complete as soon as the last cross-attention backward of that width has run.  One group per width, not one
+      // for all: the 1280-channel group is 92 % of the weight (314 M parameters, a segment of its own: Engine::build) and complete after
+      // down_blocks.2, with the whole 640-channel level's backward still to run under its exchange; as ONE weight its 681 MB bucket
+      // became ready ~3 ms before the end of the backward and its exchange was the step's un-overlapped tail (bench.py
+      // --exchange-shadow: 2.7 ms at 300 GB/s, profiles/r04c_exchange_shadow.txt).
+      // Every block's attention reads / writes its column slice of its group's result.
       std::vector<std::pair<std::string, int>> blocks;
       auto add_tf = [&](const std::string& p, int C, int depth) {
+        if (C != Cgrp) return;
         for (int k = 0; k < depth; ++k) blocks.emplace_back(p + ".transformer_blocks." + std::to_string(k), C);
       };
       for (int i = 0; i < 3; ++i)
@@ -886,9 +892,11 @@ struct Builder {
         kv_col[b.first] = (int)col;
         col += 2L * b.second;
       }
+      kv_done[Cgrp] = true;
       if (pl) {
-        kv_all = pl->new_act((long)B * ctx, (int)ntot, true, kv_pad_rows(B, ctx));
-        LinearOp* op = tagseg(pl->add<LinearOp>(ehs, kv_all, wkv, PRef(), cross, (int)ntot, nullptr), wkv);
+        Act* all = pl->new_act((long)B * ctx, (int)ntot, true, kv_pad_rows(B, ctx));
+        kv_all[Cgrp] = all;
+        LinearOp* op = tagseg(pl->add<LinearOp>(ehs, all, wkv, PRef(), cross, (int)ntot, nullptr), wkv);
         op->hoist_fwd = true;
       }
     };
@@ -941,7 +949,7 @@ struct Builder {
         x = resnet(p + ".resnets." + std::to_string(j), x, h, w, prev, ch[i]);
         prev = ch[i];
         if (c.transformer_layers[i] > 0) {
-          if (kv_col.empty()) register_kv();
+          if (!kv_done[ch[i]]) register_kv(ch[i]);
           x = transformer(p + ".attentions." + std::to_string(j), x, ehs, h, w, ch[i], c.transformer_layers[i]);
         }
         skips.push_back({x, prev});
@@ -954,7 +962,7 @@ struct Builder {
       }
     }
     x = resnet("mid_block.resnets.0", x, h, w, prev, prev);
-    if (kv_col.empty()) register_kv();
+    if (!kv_done[prev]) register_kv(prev);
     x = transformer("mid_block.attentions.0", x, ehs, h, w, prev, c.transformer_layers[2]);
     x = resnet("mid_block.resnets.1", x, h, w, prev, prev);
     for (int ui = 0; ui < 3; ++ui) {

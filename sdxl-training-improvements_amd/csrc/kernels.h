@@ -262,6 +262,7 @@ int launch_sumsq_f32(const float* x, long n, float* out /* += */, hipStream_t st
 int launch_sumsq_bf16(const bf16* x, long n, float* out /* += */, hipStream_t st);
 int launch_clip_coef(const float* sumsq, float max_norm, float* coef, hipStream_t st);
 int launch_scale_f32(float* x, long n, const float* scale_dev, hipStream_t st);
+int launch_exchange_shadow(void* buf, size_t bytes, int workgroups, int lds_bytes, float busy_us, hipStream_t st);   // measurement hook
 
 // ------------------------------------------------------------------------------------------------
 // loss side (loss.hip) -- restates reference compute_loss arithmetic on device
