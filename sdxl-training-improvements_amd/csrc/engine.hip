@@ -180,7 +180,7 @@ struct LinearOp : Op {
   PRef w, b;
   int K, N;
   int resid_alias = 0, splitk = 1, wgroup = 1;
-  int crcfg = 0;                // weight gradient on the co-resident 256-row kernel (gemm_cr256.hip): GemmP::cfg 31 / 32
+  int crcfg = 0, crsplit = 1;   // weight gradient on the co-resident 256-row kernel (gemm_cr256.hip): GemmP::cfg 31 / 32, its split-K factor
   int fsplit = 1, dsplit = 1;   // split-K of the forward / dgrad launch (small-M problems, gemm_pick_splitk_small)
   size_t dy32_off = NONE;   // the output gradient arrives as fp32 sums (grouped time-embedding projection): cast first
   size_t dy_off = NONE;
@@ -217,6 +217,7 @@ struct LinearOp : Op {
     wgroup = gemm_pick_group(N, K, 1, x->rows, splitk);
     want_slab(p, N, K, 1, splitk);
     crcfg = cr256_wgrad_cfg(N, K, x->rows, b.off != NONE);
+    if (crcfg) { crsplit = cr256_pick_splitk(N, K, x->rows, crcfg); want_slab(p, N, K, 1, crsplit); }
     if (!gact) { fsplit = gemm_pick_splitk_small((int)x->rows, N, K, 3); want_slab_main(p, (int)x->rows, N, fsplit); }
     if (!gu && x->need_grad) {
       dsplit = gemm_pick_splitk_small((int)x->rows, K, N, 2);
@@ -244,7 +245,7 @@ struct LinearOp : Op {
       g.accumulate = first ? 0 : 1;
       g.bias_grad = b.off != NONE ? p.eng->Gp(b) : nullptr;   // column sums of dY ride along on the matrix pipe
       if (p.eng->emit_base) { g.Cb = p.eng->emit_base + w.off; g.cb_scale = p.eng->emit_scale; }
-      if (crcfg) { g.cfg = crcfg; if (wgroup <= 1) g.splitk = 1; }     // (a grouped launch's stragglers keep the 128-row policy's split)
+      if (crcfg) { g.cfg = crcfg; if (wgroup <= 1) g.splitk = crsplit; }     // (a grouped launch's stragglers keep the 128-row policy's split)
       const int pad = x->pad_rows < y->pad_rows ? x->pad_rows : y->pad_rows;
       if (pad > 0 && (M + pad) % 64 == 0) {     // zero rows appended to both operands: every reduction step is a full one
         g.K = M + pad;

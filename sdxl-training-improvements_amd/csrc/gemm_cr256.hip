@@ -371,14 +371,26 @@ bool cr256_applicable(const GemmP& p) {
 // (profiles/r04a_pair_bench.txt).  A bias gradient forces 128-column tiles (its accumulators).
 int cr256_wgrad_cfg(int M, int N, long red, bool bias) {
   if (KNOB(16) == 1) return 0;
-  if (red < 2048 || red > 8192 || red % CR_BK || M % 8 || N % 8) return 0;
-  if ((long)M * N < 1280L * 1280L) return 0;
+  if (red < 2048 || red > (KNOB(19) == 1 ? 32768 : 8192) || red % CR_BK || M % 8 || N % 8) return 0;      // (knob 19 = 1, experiment: the 16 384-row level too)
+  if ((long)M * N < (red > 8192 ? 640L * 640L : 1280L * 1280L)) return 0;
   if (KNOB(16) == 2) return 32;
   if (KNOB(16) == 3) return (bias || N % 160) ? 32 : 31;
   if (bias || N % 160) return 32;
   // no bias: 160-column tiles for the small outputs that go out grouped (1280 x 1280 three at a time: 120 workgroups), 128-column
   // tiles where those give >= 150 workgroups (3840 x 1280: 150 against 120)
   return (long)cdiv(M, CR_BM) * (N / 160) >= 100 ? 32 : 31;
+}
+
+// split-K factor of a weight gradient on this kernel: whole reductions at the 4096-token level (its tiles fill half the chip beside the
+// dgrad); longer reductions with few tiles are cut to ~`target` workgroups of >= 64 K-steps
+int cr256_pick_splitk(int M, int N, long red, int cfg) {
+  if (red <= 8192) return 1;
+  const long tiles = (long)cdiv(M, CR_BM) * cdiv(N, cfg == 31 ? 160 : 128);
+  const long target = KNOB(17) > 0 ? KNOB(17) : 256;
+  long s = (target + tiles / 2) / tiles;
+  if (s < 1) s = 1;
+  while (s > 1 && red / CR_BK / s < 64) --s;
+  return (int)(s > 32 ? 32 : s);
 }
 
 // bn = 160 or 128 (0: 160 where N divides and no bias gradient is asked for, else 128)
