@@ -387,12 +387,15 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
 // Delta[bh][q] = sum_d dO[q][d] * O[q][d] is computed here from the dO fragments the kernel holds anyway (each lane
 // has 16 of the row's 64 d; two cross-lane steps finish the sum) and stored for the dK/dV kernel that follows.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
-  set_wave_prio(p.prio);
-  __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE_ELEMS];
+// (bx, bh): the workgroup's 128-query block and (batch, head); sm: 4 tiles of LDS.  The body of attn_bwd_dq_kernel and of the dQ part of
+// attn_bwd_fused_kernel.
+// WRITE_DELTA: store Delta for a dK / dV kernel launched behind this one; false in the fused grid, where attn_delta_kernel wrote it before the
+// launch and a second writer inside the launch would race with the dK / dV workgroups reading it (different summation order: different bits).
+template <bool WRITE_DELTA>
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnP& p, bf16* sm, const int bx, const int bh) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l16 = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int q0 = bx * 128 + wave * 32;
   const bf16* Qb = p.Q + (long)b * p.Nq * p.ldq + h * HD;
   const bf16* dOb = p.dO + (long)b * p.Nq * p.lddo + h * HD;
   const bf16* Ob = p.O + (long)b * p.Nq * p.ldo + h * HD;
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
     dl = sum_over_g(dl);
     lse2[qb] = ok ? p.LSE[(long)bh * p.Nq + q] * LOG2E : 0.f;
     delta[qb] = dl;
-    if (ok && g == 0) p.Delta[(long)bh * p.Nq + q] = dl;
+    if (WRITE_DELTA && ok && g == 0) p.Delta[(long)bh * p.Nq + q] = dl;
   }
   f32x4 dq[4][2];
 #pragma unroll
@@ -522,6 +525,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   }
 }
 
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
+  set_wave_prio(p.prio);
+  __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE_ELEMS];
+  attn_bwd_dq_body<true>(p, sm, blockIdx.x, blockIdx.y);
+}
+
 // ------------------------------------------------------------------------------------------------
 // dK, dV: block = 64 keys (4 waves x 16), loop over 64-query tiles.  Scores un-transposed here:
 // S[q][key] = Q . K^T so that each lane owns one key column; P / dS feed dV^T = dO^T . P and
@@ -529,15 +538,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 // ------------------------------------------------------------------------------------------------
 // KB = 16-key column blocks per wave: 2 for self attention (block = 128 keys; every Q / dO fragment read from LDS
 // feeds two key blocks, halving the LDS traffic per MFMA), 1 for the split-query cross-attention form.
+// (bx, bh, bz): the workgroup's key block, (batch, head) and query split; nbh = B * H; sm: 4 tiles + 512 bf16 of LDS.  The body of
+// attn_bwd_dkv_kernel and of the dK / dV part of attn_bwd_fused_kernel.
 template <int KB>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
-  set_wave_prio(p.prio);
-  // ONE LDS object (a second one makes hipcc drain the LDS-DMA before every ds_read): Q0 dO0 Q1 dO1 | stats
-  __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE_ELEMS + 512];
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnP& p, bf16* sm, const int bx, const int bh, const int bz, const int nbh) {
   float (*sstat)[2][64] = (float (*)[2][64])(sm + 4 * TILE_ELEMS);                                   // [buf][lse2|delta][q]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l16 = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
-  const int key0 = blockIdx.x * (64 * KB) + wave * (16 * KB) + l16;  // this lane's key column of block kb: key0 + 16 kb
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int key0 = bx * (64 * KB) + wave * (16 * KB) + l16;  // this lane's key column of block kb: key0 + 16 kb
   const bf16* Qb = p.Q + (long)b * p.Nq * p.ldq + h * HD;
   const bf16* dOb = p.dO + (long)b * p.Nq * p.lddo + h * HD;
   const bf16* Kb = p.K + (long)b * p.Nk * p.ldk + h * HD;
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
 
   const int ntiles_all = (p.Nq + 63) / 64;
   const int per = (ntiles_all + p.qsplit - 1) / p.qsplit;
-  const int t_begin = blockIdx.z * per;
+  const int t_begin = bz * per;
   const int ntiles = min(ntiles_all, t_begin + per);
   // LSE / Delta of a query tile go to LDS by DMA as well (waves 0 / 1, 4 bytes per lane): no VGPR-destination load is in
   // flight inside the tile loop, whose compiler-placed s_waitcnt vmcnt(0) would drain the tile DMAs
@@ -696,7 +704,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     const int key = key0 + kb * 16;
     if (p.qsplit > 1) {   // fp32 partials: part[z][bh][key][2][64]
       const int kvt = (p.Nk + 63) / 64;
-      float* base = p.part + ((((long)blockIdx.z * gridDim.y + bh) * kvt * 64 + key) * 2) * 64;
+      float* base = p.part + ((((long)bz * nbh + bh) * kvt * 64 + key) * 2) * 64;
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         *(f32x4*)(base + db * 16 + g * 4) = dk[kb][db] * SCALE;
@@ -715,6 +723,51 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
       }
     }
   }
+}
+
+template <int KB>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
+  set_wave_prio(p.prio);
+  // ONE LDS object (a second one makes hipcc drain the LDS-DMA before every ds_read): Q0 dO0 Q1 dO1 | stats
+  __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE_ELEMS + 512];
+  attn_bwd_dkv_body<KB>(p, sm, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y);
+}
+
+// Delta[bh][q] = sum_d dO[q][d] * O[q][d] as a pass of its own (8 lanes per (row, head), 16-byte loads): what the fused backward
+// launch needs before it starts, because there the dK / dV workgroups no longer run behind the dQ workgroups that used to produce it.
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p) {
+  const long i = (long)blockIdx.x * 32 + (threadIdx.x >> 3);           // (b, q, h) triple, h fastest
+  const int c = threadIdx.x & 7;
+  const long total = (long)p.B * p.Nq * p.H;
+  float s = 0.f;
+  long bh = 0; int q = 0;
+  if (i < total) {
+    const int h = (int)(i % p.H);
+    const long bq = i / p.H;
+    q = (int)(bq % p.Nq);
+    const int b = (int)(bq / p.Nq);
+    bh = (long)b * p.H + h;
+    const bf16x8 d = *(const bf16x8*)(p.dO + bq * p.lddo + h * HD + c * 8);
+    const bf16x8 o = *(const bf16x8*)(p.O + bq * p.ldo + h * HD + c * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += (float)d[e] * (float)o[e];
+  }
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  if (i < total && c == 0) p.Delta[bh * p.Nq + q] = s;
+}
+
+// Self-attention backward as ONE grid: the dK / dV workgroups (128 keys each, the longer ones: first) and the dQ workgroups (128 queries
+// each) of a launch fill the 512 slots together.  As two launches each left its last round partly empty -- 640 workgroups per kernel at
+// N = 1024 (1.25 rounds), 1 280 at N = 4096 (2.5) -- and the second waited for the first; Delta comes from attn_delta_kernel.
+template <int KB>
+__global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const AttnP p, const int ndkv, const int nkb, const int nqb) {
+  set_wave_prio(p.prio);
+  __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE_ELEMS + 512];
+  const int id = blockIdx.x;
+  if (id < ndkv) attn_bwd_dkv_body<KB>(p, sm, id % nkb, id / nkb, 0, p.B * p.H);
+  else attn_bwd_dq_body<false>(p, sm, (id - ndkv) % nqb, (id - ndkv) / nqb);
 }
 
 // dK/dV = sum over query splits of the fp32 partials (fixed order), cast to bf16
@@ -801,7 +854,25 @@ int launch_attn_bwd_dkv(const AttnP& p, hipStream_t st) {
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
+// self-attention: Delta pass + one grid of dK / dV and dQ workgroups (see attn_bwd_fused_kernel)
+int launch_attn_bwd_fused(const AttnP& p, hipStream_t st) {
+  if (int e = check_attn_bwd(p)) return e;
+  ARG_CHECK(p.lddo % 8 == 0 && p.ldo % 8 == 0, "attention bwd (fused): dO / O row strides must be multiples of 8 elements");
+  if (FILE* f = launch_log()) { fprintf(f, "A,1,%d,%d,%d,%d\nA,2,%d,%d,%d,%d\n", p.B, p.H, p.Nq, p.Nk, p.B, p.H, p.Nq, p.Nk); fflush(f); }
+  AttnP q = p;
+  q.qsplit = 1;
+  const long total = (long)p.B * p.Nq * p.H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, q);
+  const int nkb = cdiv(p.Nk, 128), nqb = cdiv(p.Nq, 128), nbh = p.B * p.H;
+  hipLaunchKernelGGL(attn_bwd_fused_kernel<2>, dim3(nkb * nbh + nqb * nbh), dim3(256), 0, st, q, nkb * nbh, nkb, nqb);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+// dQ, dK, dV.  Self-attention-shaped problems whose dK / dV kernel needs no query split go out as the fused grid (knob 20 = 1,
+// diagnostics build: the two-launch form, A/B runs); short key sequences (cross attention) keep dQ, then the split dK / dV kernel + reduce.
 int launch_attn_bwd(const AttnP& p, hipStream_t st) {
+  const bool fused = KNOB(20) != 1 && (p.qsplit <= 1 || !p.part) && p.Nk >= 256 && p.lddo % 8 == 0 && p.ldo % 8 == 0;
+  if (fused) return launch_attn_bwd_fused(p, st);
   if (int e = launch_attn_bwd_dq(p, st)) return e;
   return launch_attn_bwd_dkv(p, st);
 }
