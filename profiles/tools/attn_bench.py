@@ -7,6 +7,8 @@ from sdxl_amd import lib
 if '--lib' in sys.argv:      # knock-out builds (tools/build_diag_attn.sh)
     lib.LIB_PATH = Path(sys.argv[sys.argv.index('--lib') + 1]).resolve()
 L = lib.load(); dev = torch.device('cuda:0')
+import os
+if os.environ.get('SDXL_KNOB20') == '1': lib.check(L.sdxl_set_knob(20, 1))      # diagnostics build: the two-launch self-attention backward
 ptr = lambda t: C.c_void_p(t.data_ptr())
 r = lambda *s: torch.randn(*s, device=dev).to(torch.bfloat16)
 ITERS = int(sys.argv[sys.argv.index('--iters') + 1]) if '--iters' in sys.argv else 20
