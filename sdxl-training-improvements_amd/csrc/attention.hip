@@ -862,7 +862,7 @@ int launch_attn_bwd_fused(const AttnP& p, hipStream_t st) {
   AttnP q = p;
   q.qsplit = 1;
   const long total = (long)p.B * p.Nq * p.H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, q);
+  if (!p.delta_ready) hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, q);
   const int nkb = cdiv(p.Nk, 128), nqb = cdiv(p.Nq, 128), nbh = p.B * p.H;
   hipLaunchKernelGGL(attn_bwd_fused_kernel<2>, dim3(nkb * nbh + nqb * nbh), dim3(256), 0, st, q, nkb * nbh, nkb, nqb);
   HIP_CHECK_RET(hipGetLastError());
@@ -871,7 +871,7 @@ int launch_attn_bwd_fused(const AttnP& p, hipStream_t st) {
 // dQ, dK, dV.  Self-attention-shaped problems whose dK / dV kernel needs no query split go out as the fused grid (knob 20 = 1,
 // diagnostics build: the two-launch form, A/B runs); short key sequences (cross attention) keep dQ, then the split dK / dV kernel + reduce.
 int launch_attn_bwd(const AttnP& p, hipStream_t st) {
-  const bool fused = KNOB(20) != 1 && (p.qsplit <= 1 || !p.part) && p.Nk >= 256 && p.lddo % 8 == 0 && p.ldo % 8 == 0;
+  const bool fused = (KNOB(20) != 1 || p.delta_ready) && (p.qsplit <= 1 || !p.part) && p.Nk >= 256 && p.lddo % 8 == 0 && p.ldo % 8 == 0;
   if (fused) return launch_attn_bwd_fused(p, st);
   if (int e = launch_attn_bwd_dq(p, st)) return e;
   return launch_attn_bwd_dkv(p, st);

@@ -175,11 +175,15 @@ static void want_slab(Plan& p, int M, int N, int taps, int splitk) {
 
 static int kv_pad_rows(int B, int ctx) { return (int)((64 - ((long)B * ctx) % 64) % 64); }   // B * 77 prompt tokens -> multiple of 64
 
+struct AttnOp;
+static void attn_delta_target(AttnOp* a, Plan& p, GemmP& g);      // (defined behind AttnOp)
+static bool attn_delta_wanted(const AttnOp* a);
 struct LinearOp : Op {
   Act *x, *y, *resid;
   PRef w, b;
   int K, N;
   int resid_alias = 0, splitk = 1, wgroup = 1;
+  struct AttnOp* delta_attn = nullptr;      // x is the output of this self-attention layer: the dgrad's epilogue also writes its Delta (GemmP::delta_out)
   int crcfg = 0, crsplit = 1;   // weight gradient on the co-resident 256-row kernel (gemm_cr256.hip): GemmP::cfg 31 / 32, its split-K factor
   int fsplit = 1, dsplit = 1;   // split-K of the forward / dgrad launch (small-M problems, gemm_pick_splitk_small)
   size_t dy32_off = NONE;   // the output gradient arrives as fp32 sums (grouped time-embedding projection): cast first
@@ -273,6 +277,8 @@ struct LinearOp : Op {
       if (dsplit > 1) { g.splitk = dsplit; g.slab = p.F(p.slab_main_off); }
       g.prio = KNOB(0);
       if (KNOB(6) > 0 && !gu && (KNOB(8) <= 0 || N >= KNOB(8))) g.cfg = KNOB(6);     // experiment: configuration of the linear dgrads
+      // (last: the epilogue that writes Delta exists on the 128 x 128 tiles of the 4-wave kernel only)
+      if (delta_attn && attn_delta_wanted(delta_attn) && dsplit <= 1 && K % 128 == 0) { attn_delta_target(delta_attn, p, g); g.cfg = 1; }
       CHK(launch_gemm(g, st));
     }
     return 0;
@@ -565,11 +571,13 @@ struct AttnOp : Op {
     if (dq.addend != NONE) bad = true;
     if (!self) { dkv = p.grad_dst(kv); if (dkv.addend != NONE) bad = true; }
   }
+  bool delta_fused = false;     // the out-projection's dgrad writes Delta (LinearOp::delta_attn): no Delta pass in the backward
   int bwd(Plan& p, hipStream_t st, bool) override {
     if (bad) { sdxl_set_error("attention: operand gradient has another writer"); return 3; }
     AttnP a;
     fill(p, a, true);
     a.prio = KNOB(1);
+    a.delta_ready = delta_fused ? 1 : 0;
     if (self) return launch_attn_bwd(a, st);
     // cross attention: dK | dV (this block's slice of the grouped projection's gradient) is read by nothing before that
     // projection's weight gradient, a leaf on the side stream -- so the dK / dV kernel (+ its partial reduce) goes there too,
@@ -578,6 +586,15 @@ struct AttnOp : Op {
     return side_leaf(p, st, [=](hipStream_t s2) -> int { return launch_attn_bwd_dkv(a, s2); });
   }
 };
+
+// level-2 self-attention (1280 channels at M = 4096: the out-projection's dgrad runs on 128 x 128 tiles, whose 64 x 64 wave tiles are whole
+// heads): Delta from that GEMM's epilogue instead of a pass of its own (60 launches per step).  knob 21 = 1: off (A/B runs)
+static bool attn_delta_wanted(const AttnOp* a) { return a->self && a->qsplit <= 1 && a->Nk >= 256 && a->C % 128 == 0 && a->delta_fused; }
+static void attn_delta_target(AttnOp* a, Plan& p, GemmP& g) {
+  g.delta_o = p.P(a->o); g.delta_ldo = a->C;
+  g.delta_out = p.F(a->delta_off);
+  g.delta_nq = a->Nq; g.delta_heads = a->heads;
+}
 
 struct SiluOp : Op {
   Act *x, *y;
@@ -800,11 +817,16 @@ struct Builder {
     Act* l1 = layernorm(b + ".norm1", x, C);
     Act* qkv = linear_fused({b + ".attn1.to_q", b + ".attn1.to_k", b + ".attn1.to_v"}, l1, C, C);
     Act* a1 = nullptr;
+    AttnOp* sa = nullptr;
     if (pl) {
       a1 = pl->new_act(x->rows, C);
-      tagseg(pl->add<AttnOp>(*pl, qkv, qkv, a1, B, heads, N, N, C, true), PRef());
+      sa = tagseg(pl->add<AttnOp>(*pl, qkv, qkv, a1, B, heads, N, N, C, true), PRef());
     }
-    Act* x1 = linear(b + ".attn1.to_out.0", a1, C, C, true, x);
+    LinearOp* o1 = nullptr;
+    Act* x1 = linear(b + ".attn1.to_out.0", a1, C, C, true, x, false, 0, &o1);
+    // Delta of the self-attention backward from the out-projection's dgrad epilogue where that GEMM runs on 128 x 128 tiles (one-round
+    // problems: M x C = 4096 x 1280; at M = 16384 x 640 the dgrad takes 160-column tiles, which split heads: Delta pass there)
+    if (sa && o1 && KNOB(21) != 1 && C % 128 == 0 && (x->rows / 128) * (C / 160) <= 256 && sa->qsplit <= 1) { sa->delta_fused = true; o1->delta_attn = sa; }
     Act* l2 = layernorm(b + ".norm2", x1, C);
     Act* q = linear(b + ".attn2.to_q", l2, C, C, false, nullptr);
     // K | V of the prompt embeddings: this block's 2C columns of the grouped projection (one GEMM for all blocks, run())

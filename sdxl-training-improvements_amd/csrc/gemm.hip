@@ -719,6 +719,8 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
           }
         }
       } else {
+        constexpr bool DELTA_OK = FORM == GEMM_NN && BN == 128 && NW == 4 && !KSP;     // wave tile 64 x 64 = one attention head per wave
+        float dl = 0.f;
 #pragma unroll
         for (int j = 0; j + 1 < NJ; j += 2) {
           float x[8];
@@ -731,7 +733,25 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
             x[r] = lo;
             x[4 + r] = hi;
           }
-          store_bf16(m, n0 + wn * (BN / 2) + (j + (g & 1)) * 16 + (g >> 1) * 8, x, 8);
+          const int n = n0 + wn * (BN / 2) + (j + (g & 1)) * 16 + (g >> 1) * 8;
+          store_bf16(m, n, x, 8);
+          if (DELTA_OK && p.delta_out && m < p.M && n < p.N) {      // (x now holds the pre-rounding sums: the same bf16 as stored)
+            const bf16x8 ov = *(const bf16x8*)(p.delta_o + (long)m * p.delta_ldo + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += (float)(bf16)x[e] * (float)ov[e];
+          }
+        }
+        if (DELTA_OK && p.delta_out) {      // the row's 64 columns sit in the four lanes l16 + 16 g: two exchange steps finish the sum
+          float a = dl, b2 = dl;
+          asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b2));
+          dl = a + b2;
+          a = dl; b2 = dl;
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b2));
+          dl = a + b2;
+          if (g == 0 && m < p.M) {
+            const int bb = m / p.delta_nq, qq = m - bb * p.delta_nq, hh = (n0 + wn * (BN / 2)) >> 6;
+            if (hh < p.delta_heads) p.delta_out[((long)bb * p.delta_heads + hh) * p.delta_nq + qq] = dl;
+          }
         }
         if (NJ & 1) {   // odd fragment count (BN = 160): the last fragment goes out in 8-byte pieces
           float x[8];

@@ -16,7 +16,7 @@
 //   12 = 1: no three-tap conv weight gradient; 13 split-K workgroup target of conv_wgrad3 / wgrad256 (144); 14 = 2: its W = 32 form
 //   15 = 1: no half-height tail workgroups in the 256 x 256 kernel
 //   16 co-resident 256-row kernel for the level-2 linear weight gradients: 0 policy, 1 off, 2 / 3 = 128 / 160-column tiles wherever allowed;
-//   17 its split-K workgroup target for long reductions (0: 256); 19 = 1: also the 16 384-row level's linear weight gradients on it; 20 = 1: self-attention backward as two launches (dQ, then dK / dV); 18 = 1: no padding columns on the feed-forward hidden tensors
+//   17 its split-K workgroup target for long reductions (0: 256); 19 = 1: also the 16 384-row level's linear weight gradients on it; 20 = 1: self-attention backward as two launches (dQ, then dK / dV); 21 = 1: Delta always from its own pass; 18 = 1: no padding columns on the feed-forward hidden tensors
 // The product library has NO knobs: KNOB(i) is the constant 0 (= the shipped policy) and every experiment branch below it folds away.
 // The diagnostics build (`build.py --diag`: -DSDXL_DIAG -> libsdxlstep_diag.so, include/sdxlstep_diag.h) keeps the table, sdxl_set_knob,
 // the stream-K kernel (gemm_sk.hip), the stride-2 forward / weight gradient on phase planes (GemmP::up2 == 3) and the W = 32 three-tap form:
@@ -101,6 +101,13 @@ struct GemmP {
   float cb_scale;
   float* bias_grad;  // TN only, optional: bias_grad[m] += sum_k A(k, m)  (column sums of dY, computed on the matrix pipe
                      // by the n-tile-0 / tap-0 workgroups with an all-ones B fragment; fp32 atomics, 128 per workgroup)
+  // NN (bf16 output), 128-column tiles of the 4-wave kernel only (a wave then owns whole 64-column heads): the output is an attention
+  // layer's dO; also write Delta[b * delta_heads + head][q] = sum_d dO[m][64 head + d] * O[m][64 head + d] (m = b * delta_nq + q, O = delta_o,
+  // row stride delta_ldo) from the bf16-rounded output -- what attn_delta_kernel would compute in a pass of its own
+  const bf16* delta_o;
+  long delta_ldo;
+  float* delta_out;
+  int delta_nq, delta_heads;
   int xcd_px;      // set by the launcher: XCD grid width over n-tiles (0 = identity order)
   int tail_n0;     // 256 x 256 kernel, set by its launcher: > 0 = the tile columns from tail_n0 on are computed by HALF-HEIGHT workgroups
                    // (128 x 256: waves 4-7 only stage data) so that a launch of 2.5 rounds of tiles takes ~2.6 rounds, not 3
@@ -186,6 +193,7 @@ struct AttnP {
   int qsplit;
   float* part;         // qsplit * B*H * kvtiles*64 * 64 * 2 floats
   int prio;            // wave priority of the backward kernels (see GemmP::prio)
+  int delta_ready;     // fused backward: Delta is already in place (written by the epilogue of the GEMM that produced dO, GemmP::delta_out)
 };
 size_t attn_part_floats(int B, int H, int Nk, int qsplit);
 int attn_pick_qsplit(int B, int H, int Nq, int Nk);
