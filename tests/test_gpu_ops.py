@@ -837,3 +837,17 @@ def test_loss_guard_device(L):
     pred8[0, 0] = float("nan")
     lib.check(L.sdxl_op_loss(C.byref(lc), C.byref(b), None, ptr(pred8), None, 1.0, ptr(out), 1, stream()))
     assert float(out[0]) == 1000.0 and float(out[7]) == 0.0
+
+
+def test_exchange_shadow_hook_leaves_the_buffer_alone_and_takes_its_time(L):
+    """bench.py --exchange-shadow's stand-in kernel (sdxl_op_exchange_shadow): reads and writes back the buffer unchanged, paced over busy_us"""
+    buf = rnd(1 << 20, seed=77)
+    ref = buf.clone()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    lib.check(L.sdxl_op_exchange_shadow(ptr(buf), buf.numel() * 2, 8, 64 * 1024, 500.0, stream()))
+    e1.record()
+    torch.cuda.synchronize()
+    assert torch.equal(buf, ref)
+    assert 0.45 <= e0.elapsed_time(e1) <= 5.0
+    assert L.sdxl_op_exchange_shadow(None, 0, 8, 1024, 1.0, stream()) == 1
