@@ -6,8 +6,11 @@
 // converges at ~0.9 PFLOP/s because the L2 -> LDS stream of a CU delivers ~45-50 KB/us whatever the two co-resident workgroups
 // are; the exclusive 256-row kernels (gemm256.hip, wgrad256.hip: 128-157 KiB, 190-250 registers) stage half
 // the bytes per flop but evict the other stream of the two-stream backward from their CU.  This tile stages 98 (BN 160) / 85
-// (BN 128) flops per byte and keeps the co-residency: the level-2 (4096-token) linear layers' dgrad (NN) and weight gradient (TN)
-// -- 50 ms of serialized kernel time per step -- run on it side by side.
+// (BN 128) flops per byte and keeps the co-residency.  What the step uses it for (cr256_wgrad_cfg, measured in DESIGN.md section 12):
+// the weight gradients (TN) of the 4096-token level's linear layers on the side stream, one 8-wave workgroup of this kernel beside one
+// 4-wave dgrad workgroup of gemm.hip per CU -- the dgrad / weight-gradient pairs of a transformer block run 8-16 % faster.  The NT / NN
+// forms are complete and parity-tested (sdxl_set_gemm_mode(4 * 31 / 32)) but not selected: with two 8-wave workgroups per CU the pair
+// stages fewer bytes per microsecond than 4-wave + 8-wave, and N = 1280 outputs at M = 4096 are only 128-160 tiles of 256 rows.
 //
 // Structure (wgrad256.hip's, thinner and for all three forms):
 //   * operand tiles of a K-step go global -> LDS by buffer_load_dwordx4 ... lds through raw buffer descriptors: one constant
@@ -384,12 +387,12 @@ int cr256_wgrad_cfg(int M, int N, long red, bool bias) {
 // split-K factor of a weight gradient on this kernel: whole reductions at the 4096-token level (its tiles fill half the chip beside the
 // dgrad); longer reductions with few tiles are cut to ~`target` workgroups of >= 64 K-steps
 int cr256_pick_splitk(int M, int N, long red, int cfg) {
-  if (red <= 8192) return 1;
+  if (red <= 8192 && KNOB(17) <= 0) return 1;      // (knob 17 > 0, experiment: the 4096-row level split to ~that many workgroups too)
   const long tiles = (long)cdiv(M, CR_BM) * cdiv(N, cfg == 31 ? 160 : 128);
   const long target = KNOB(17) > 0 ? KNOB(17) : 256;
   long s = (target + tiles / 2) / tiles;
   if (s < 1) s = 1;
-  while (s > 1 && red / CR_BK / s < 64) --s;
+  while (s > 1 && red / CR_BK / s < (red <= 8192 ? 32 : 64)) --s;
   return (int)(s > 32 ? 32 : s);
 }
 
