@@ -966,6 +966,7 @@ static int launch_one(const GemmP& p, hipStream_t st) {
   if (FORM == GEMM_NT && n160 && t160 <= 256 && (long)p.K * p.taps >= 2560) cfg = 23;
   if (p.cfg > 0) cfg = p.cfg;
   if (g_force_cfg > 0) cfg = g_force_cfg;
+  if (p.delta_out) cfg = 1;      // the epilogue that also writes an attention layer's Delta exists on 128 x 128 tiles only (whatever is forced)
   if (FORM != GEMM_TN && p.splitk > 1) cfg = n160 ? 13 : 1;     // split-K of the bf16-output forms: the 4-wave FAST configurations
   if (p.geglu == 1 && !g80 && (cfg == 3 || cfg == 13 || cfg == 23)) cfg = 1;   // forward, group-64 packing: 128-column tiles
   if (g80 && cfg != 3 && cfg != 13 && cfg != 23) cfg = 13;                 // group-80 packing needs 160-column tiles
@@ -1227,7 +1228,7 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
   int rc;
   {   // co-resident 256-row kernel (gemm_cr256.hip): forced configurations 31 (160-column tiles) / 32 (128)
     const int fc = p.cfg > 0 ? p.cfg : g_force_cfg;
-    if ((fc == 31 || fc == 32) && cr256_applicable(p)) {
+    if ((fc == 31 || fc == 32) && !p.delta_out && cr256_applicable(p)) {
       rc = launch_cr256(p, fc == 31 ? 160 : 128, st);
       if (rc == 0 && p.form == GEMM_TN && p.splitk > 1) {
         const long nv = (long)p.M * (p.N / 4);
