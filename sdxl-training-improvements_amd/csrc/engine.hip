@@ -277,6 +277,7 @@ struct LinearOp : Op {
       if (dsplit > 1) { g.splitk = dsplit; g.slab = p.F(p.slab_main_off); }
       g.prio = KNOB(0);
       if (KNOB(6) > 0 && !gu && (KNOB(8) <= 0 || N >= KNOB(8))) g.cfg = KNOB(6);     // experiment: configuration of the linear dgrads
+      if (KNOB(22) > 0 && gu) g.cfg = KNOB(22);     // experiment: configuration of the GEGLU (FF2) dgrad
       // (last: the epilogue that writes Delta exists on the 128 x 128 tiles of the 4-wave kernel only)
       if (delta_attn && attn_delta_wanted(delta_attn) && dsplit <= 1 && K % 128 == 0) { attn_delta_target(delta_attn, p, g); g.cfg = 1; }
       CHK(launch_gemm(g, st));
