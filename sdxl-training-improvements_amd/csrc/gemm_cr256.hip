@@ -32,7 +32,7 @@
 
 namespace {
 
-constexpr int CR_BM = 256, CR_BK = 32, CR_S = 3;
+constexpr int CR_BM = 256, CR_BK = 32, CR_S = 3, CR_S_DEEP = 6;   // ring depth: 3 = the co-resident form (<= 78 KiB), 6 = an exclusive form (156 / 144 KiB, experiment)
 constexpr unsigned CR_OOB = 0x80000000u;   // per-lane offset beyond num_records: the load returns zeros
 
 #ifndef SDXL_CR_DIAG      // scratch diagnostics only (never defined in the product build): knock out one pipeline component
@@ -44,19 +44,19 @@ struct CrGeom {
   static constexpr int A_BYTES = CR_BM * CR_BK * 2;     // 16 KiB
   static constexpr int B_BYTES = BN * CR_BK * 2;        // 10 / 8 KiB
   static constexpr int STAGE = A_BYTES + B_BYTES;
-  static constexpr int SMEM = CR_S * STAGE;             // 79 872 / 73 728 bytes
+  static constexpr int smem(int S) { return S * STAGE; }  // S = 3: 79 872 / 73 728 bytes
   static constexpr int NCB = B_BYTES / 1024;            // 10 / 8 pieces of the B tile
   static constexpr int NJ = BN / 32;                    // B fragments per wave
 };
 
-template <int FORM, int BN, bool BIASG>
-__global__ __launch_bounds__(512, 4) void cr256_kernel(const GemmP pin) {
+template <int FORM, int BN, bool BIASG, int S>
+__global__ __launch_bounds__(512, S == CR_S ? 4 : 2) void cr256_kernel(const GemmP pin) {
   using G = CrGeom<BN>;
   constexpr bool A_KC = FORM != GEMM_TN;   // A tile K-contiguous (rows = output rows)
   constexpr bool B_KC = FORM == GEMM_NT;   // B tile K-contiguous (rows = output columns)
   constexpr int NJ = G::NJ;
   constexpr int dbg = SDXL_CR_DIAG;
-  static_assert(!BIASG || (FORM == GEMM_TN && BN == 128), "bias gradient: TN form, 128-column tiles");
+  static_assert(!BIASG || (FORM == GEMM_TN && (BN == 128 || S > CR_S)), "bias gradient: TN form; 128-column tiles in the co-resident form");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const bf16* Ap = pin.A;
   const bf16* Bp = pin.B;
@@ -178,16 +178,16 @@ __global__ __launch_bounds__(512, 4) void cr256_kernel(const GemmP pin) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
-  stage(0, 0 < T);
-  stage(1, 1 < T);
+#pragma unroll
+  for (int d = 0; d < S - 1; ++d) stage(d, d < T);
   if (dbg & 2) dma_on = false;
-  int rd = 0, wr = 2;
+  int rd = 0, wr = S - 1;
   for (int t = 0; t < T; ++t) {
     // this wave's pieces of step t have landed (those of step t + 1 may be outstanding) ...
-    if (HAS_B1 && b1) wait_vmcnt<4>();
-    else wait_vmcnt<3>();
+    if (HAS_B1 && b1) wait_vmcnt<4 * (S - 2)>();
+    else wait_vmcnt<3 * (S - 2)>();
     __builtin_amdgcn_s_barrier();           // ... everyone's; and every wave is done reading slot `wr` (step t - 1)
-    const bool live = t + 2 < T;
+    const bool live = t + S - 1 < T;
     const char* At = smem + rd * G::STAGE;
     const char* Bt = At + G::A_BYTES;
     // fragment reads: all of B and the first two A rows up front, A rows 2 and 3 behind the products of rows 0 and 1 (28 instead
@@ -219,8 +219,8 @@ __global__ __launch_bounds__(512, 4) void cr256_kernel(const GemmP pin) {
       if (i < 2) { read_a(i + 2); __builtin_amdgcn_sched_barrier(0); }
     }
     advance();
-    rd = rd + 1 == CR_S ? 0 : rd + 1;
-    wr = wr + 1 == CR_S ? 0 : wr + 1;
+    rd = rd + 1 == S ? 0 : rd + 1;
+    wr = wr + 1 == S ? 0 : wr + 1;
   }
   wait_vmcnt<0>();     // dummy tail pieces must not outlive the workgroup's LDS allocation
 
@@ -335,16 +335,16 @@ __global__ __launch_bounds__(512, 4) void cr256_kernel(const GemmP pin) {
   }
 }
 
-template <int FORM, int BN, bool BIASG>
+template <int FORM, int BN, bool BIASG, int S = CR_S>
 int launch_cr(const GemmP& p, hipStream_t st) {
   using G = CrGeom<BN>;
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)cr256_kernel<FORM, BN, BIASG>, hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)cr256_kernel<FORM, BN, BIASG, S>, hipFuncAttributeMaxDynamicSharedMemorySize, G::smem(S)));
     attr_set = true;
   }
   dim3 grid(cdiv(p.N, BN), cdiv(p.M, CR_BM), p.group > 1 ? p.group : p.splitk);
-  hipLaunchKernelGGL((cr256_kernel<FORM, BN, BIASG>), grid, dim3(512), G::SMEM, st, p);
+  hipLaunchKernelGGL((cr256_kernel<FORM, BN, BIASG, S>), grid, dim3(512), G::smem(S), st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -397,14 +397,14 @@ int cr256_pick_splitk(int M, int N, long red, int cfg) {
 }
 
 // bn = 160 or 128 (0: 160 where N divides and no bias gradient is asked for, else 128)
-int launch_cr256(const GemmP& pin, int bn, hipStream_t st) {
+int launch_cr256(const GemmP& pin, int bn, hipStream_t st, bool deep) {
   ARG_CHECK(cr256_applicable(pin), "cr256: problem %dx%dx%d (form %d) does not fit the co-resident 256-row kernel", pin.M, pin.N, pin.K, pin.form);
   GemmP p = pin;
   bool biasg = p.form == GEMM_TN && p.bias_grad != nullptr;
   if (p.form == GEMM_TN && p.group > 1)
     for (int i = 0; i < p.group; ++i) biasg = biasg || p.gbias_grad[i] != nullptr;
   if (bn == 0) bn = (p.N % 160 == 0 && !biasg) ? 160 : 128;
-  if (biasg) bn = 128;
+  if (biasg && !deep) bn = 128;
   {   // px x (8/px) XCD grid over the (n, m) tile grid minimising the per-XCD operand footprint ~ N/px + M/py
     const int gx = cdiv(p.N, bn), gy = cdiv(p.M, CR_BM);
     double best = 1e30;
@@ -417,6 +417,17 @@ int launch_cr256(const GemmP& pin, int bn, hipStream_t st) {
     }
   }
   if (p.splitk > 1) p.slab_ld = p.N;
+#ifdef SDXL_DIAG      // the exclusive 6-deep form (forced configurations 33 / 34): experiment, diagnostics build only
+  if (deep) {
+    switch (p.form) {
+      case GEMM_NT: return bn == 160 ? launch_cr<GEMM_NT, 160, false, CR_S_DEEP>(p, st) : launch_cr<GEMM_NT, 128, false, CR_S_DEEP>(p, st);
+      case GEMM_NN: return bn == 160 ? launch_cr<GEMM_NN, 160, false, CR_S_DEEP>(p, st) : launch_cr<GEMM_NN, 128, false, CR_S_DEEP>(p, st);
+      default:
+        if (biasg) return bn == 160 ? launch_cr<GEMM_TN, 160, true, CR_S_DEEP>(p, st) : launch_cr<GEMM_TN, 128, true, CR_S_DEEP>(p, st);
+        return bn == 160 ? launch_cr<GEMM_TN, 160, false, CR_S_DEEP>(p, st) : launch_cr<GEMM_TN, 128, false, CR_S_DEEP>(p, st);
+    }
+  }
+#endif
   switch (p.form) {
     case GEMM_NT: return bn == 160 ? launch_cr<GEMM_NT, 160, false>(p, st) : launch_cr<GEMM_NT, 128, false>(p, st);
     case GEMM_NN: return bn == 160 ? launch_cr<GEMM_NN, 160, false>(p, st) : launch_cr<GEMM_NN, 128, false>(p, st);

@@ -162,7 +162,7 @@ int launch_wgrad256(const GemmP& p, hipStream_t st);
 void wgrad256_set_enabled(bool on);
 // co-resident 256-row tile, 8 waves, <= 78 KiB LDS, <= 128 registers (gemm_cr256.hip): linear NT / NN / TN problems, K % 32 == 0
 bool cr256_applicable(const GemmP& p);
-int launch_cr256(const GemmP& p, int bn, hipStream_t st);      // bn = 160 / 128 / 0 (pick)
+int launch_cr256(const GemmP& p, int bn, hipStream_t st, bool deep = false);      // bn = 160 / 128 / 0 (pick); deep: exclusive 6-deep ring (diagnostics build)
 int cr256_wgrad_cfg(int M, int N, long red, bool bias);
 int cr256_pick_splitk(int M, int N, long red, int cfg);        // the plan's choice for a linear weight gradient [M][N] over `red` rows: 0 / 31 / 32 (GemmP::cfg)
 // per-launch HIP-event timing of every GEMM launch between begin and end (end synchronises the device)
