@@ -850,5 +850,5 @@ def test_exchange_shadow_hook_leaves_the_buffer_alone_and_takes_its_time(L):
     e1.record()
     torch.cuda.synchronize()
     assert torch.equal(buf, ref)
-    assert 0.45 <= e0.elapsed_time(e1) <= 5.0
+    assert e0.elapsed_time(e1) >= 0.45          # (no upper bound: a first launch may carry module load time)
     assert L.sdxl_op_exchange_shadow(None, 0, 8, 1024, 1.0, stream()) == 1
