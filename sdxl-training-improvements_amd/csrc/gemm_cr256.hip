@@ -49,8 +49,12 @@ struct CrGeom {
   static constexpr int NJ = BN / 32;                    // B fragments per wave
 };
 
-template <int FORM, int BN, bool BIASG, int S>
-__global__ __launch_bounds__(512, S == CR_S ? 4 : 2) void cr256_kernel(const GemmP pin) {
+// PH: the K-step in two phases -- L: issue the DMA pieces of step t + 2, read all fragments of step t; M: the products -- with waves
+//     4-7 running one barrier behind waves 0-3 (a SIMD holds one wave of each half): one wave of every SIMD multiplies while the other
+//     issues its DMA pieces and fragment reads, instead of all eight doing each at the same time.  128-column tiles only (all nine
+//     fragments of a step are live at once: 160 columns do not fit the 128 registers).
+template <int FORM, int BN, bool BIASG, int S, bool PH = false>
+__global__ __launch_bounds__(512, S != CR_S ? 2 : (PH && BIASG) ? 3 : 4) void cr256_kernel(const GemmP pin) {
   using G = CrGeom<BN>;
   constexpr bool A_KC = FORM != GEMM_TN;   // A tile K-contiguous (rows = output rows)
   constexpr bool B_KC = FORM == GEMM_NT;   // B tile K-contiguous (rows = output columns)
@@ -182,6 +186,63 @@ __global__ __launch_bounds__(512, S == CR_S ? 4 : 2) void cr256_kernel(const Gem
   for (int d = 0; d < S - 1; ++d) stage(d, d < T);
   if (dbg & 2) dma_on = false;
   int rd = 0, wr = S - 1;
+  if (PH) {
+    static_assert(!PH || (S == 3 && BN == 128), "phased loop: 3-deep ring, 128-column tiles");
+    // Barrier sequence X0, X1, ...: half 0 (waves 0-3) runs L(t) in [X_2t, X_2t+1] and M(t) in [X_2t+1, X_2t+2], half 1 one barrier later.
+    // RAW: a wave's pieces of step t + 1 are waited for (counted vmcnt: only those of t + 2, just issued, may be outstanding) at the end
+    //      of its L(t), i.e. before X_2t+2 at the latest -- the barrier in front of the earliest L(t + 1).
+    // WAR: the pieces of step t + 2 overwrite the slot of step t - 1, whose last reads (half 1's L(t - 1), completed by its lgkmcnt(0))
+    //      precede X_2t, the barrier in front of the earliest L(t).
+    const int half = wave >> 2;
+    if (HAS_B1 && b1) wait_vmcnt<4>();
+    else wait_vmcnt<3>();
+    __builtin_amdgcn_s_barrier();
+    if (half == 1) __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < T; ++t) {
+      const bool live = t + 2 < T;
+      const char* At = smem + rd * G::STAGE;
+      const char* Bt = At + G::A_BYTES;
+      // ---- L(t) ----
+#pragma unroll
+      for (int pc = 0; pc < 4; ++pc) issue_piece(pc, wr, live);
+      advance();
+      bf16x8 fa[4], fb[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if (dbg & 4) fb[j] = ones;
+        else if (B_KC) fb[j] = frag_kc<CR_BK>(Bt, wn * (BN / 2) + j * 16 + l16, g);
+        else fb[j] = frag_nc<BN>(Bt, g * 8, wn * (BN / 2) + j * 16, l16);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (dbg & 4) fa[i] = ones;
+        else if (A_KC) fa[i] = frag_kc<CR_BK>(At, wm * 64 + i * 16 + l16, g);
+        else fa[i] = frag_nc<128>(At + (wm >> 1) * (G::A_BYTES / 2), g * 8, (wm & 1) * 64 + i * 16, l16);
+      }
+      if (HAS_B1 && b1) wait_vmcnt<4>();
+      else wait_vmcnt<3>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      // ---- M(t) ----
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (BIASG && do_bias) accb[BIASG ? i : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[BIASG ? i : 0], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (dbg & 1) acc[i][j][0] += (float)fa[i][0] + (float)fb[j][0];
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      rd = rd + 1 == S ? 0 : rd + 1;
+      wr = wr + 1 == S ? 0 : wr + 1;
+    }
+    if (half == 0) __builtin_amdgcn_s_barrier();      // both halves execute the same number of barriers
+  } else
   for (int t = 0; t < T; ++t) {
     // this wave's pieces of step t have landed (those of step t + 1 may be outstanding) ...
     if (HAS_B1 && b1) wait_vmcnt<4 * (S - 2)>();
@@ -335,16 +396,16 @@ __global__ __launch_bounds__(512, S == CR_S ? 4 : 2) void cr256_kernel(const Gem
   }
 }
 
-template <int FORM, int BN, bool BIASG, int S = CR_S>
+template <int FORM, int BN, bool BIASG, int S = CR_S, bool PH = false>
 int launch_cr(const GemmP& p, hipStream_t st) {
   using G = CrGeom<BN>;
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)cr256_kernel<FORM, BN, BIASG, S>, hipFuncAttributeMaxDynamicSharedMemorySize, G::smem(S)));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)cr256_kernel<FORM, BN, BIASG, S, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, G::smem(S)));
     attr_set = true;
   }
   dim3 grid(cdiv(p.N, BN), cdiv(p.M, CR_BM), p.group > 1 ? p.group : p.splitk);
-  hipLaunchKernelGGL((cr256_kernel<FORM, BN, BIASG, S>), grid, dim3(512), G::smem(S), st, p);
+  hipLaunchKernelGGL((cr256_kernel<FORM, BN, BIASG, S, PH>), grid, dim3(512), G::smem(S), st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -372,7 +433,7 @@ bool cr256_applicable(const GemmP& p) {
 // wgrad256.hip): beside the 4-wave dgrad kernels of the caller's stream one 8-wave workgroup of this kernel per CU stages 85-98 flops
 // per byte where the 128 x 160 kernel stages 71 -- the dgrad / weight-gradient pairs of a level-2 transformer block run 8-16 % faster
 // (profiles/r04a_pair_bench.txt).  A bias gradient forces 128-column tiles (its accumulators).
-int cr256_wgrad_cfg(int M, int N, long red, bool bias) {
+static int cr256_wgrad_cfg_tiles(int M, int N, long red, bool bias) {
   if (KNOB(16) == 1) return 0;
   if (red < 2048 || red > (KNOB(19) == 1 ? 32768 : 8192) || red % CR_BK || M % 8 || N % 8) return 0;      // (knob 19 = 1, experiment: the 16 384-row level too)
   if ((long)M * N < (red > 8192 ? 640L * 640L : 1280L * 1280L)) return 0;
@@ -383,12 +444,18 @@ int cr256_wgrad_cfg(int M, int N, long red, bool bias) {
   // tiles where those give >= 150 workgroups (3840 x 1280: 150 against 120)
   return (long)cdiv(M, CR_BM) * (N / 160) >= 100 ? 32 : 31;
 }
+int cr256_wgrad_cfg(int M, int N, long red, bool bias) {
+  int cfg = cr256_wgrad_cfg_tiles(M, N, red, bias);
+  // 128-column tiles: the phased loop (configuration 35; knob 23 = 1: the lockstep loop everywhere, = 2: phased only for >= 256 tiles)
+  if (cfg == 32 && KNOB(23) != 1 && (KNOB(23) != 2 || (long)cdiv(M, CR_BM) * cdiv(N, 128) >= 256)) cfg = 35;
+  return cfg;
+}
 
 // split-K factor of a weight gradient on this kernel: whole reductions at the 4096-token level (its tiles fill half the chip beside the
 // dgrad); longer reductions with few tiles are cut to ~`target` workgroups of >= 64 K-steps
 int cr256_pick_splitk(int M, int N, long red, int cfg) {
   if (red <= 8192 && KNOB(17) <= 0) return 1;      // (knob 17 > 0, experiment: the 4096-row level split to ~that many workgroups too)
-  const long tiles = (long)cdiv(M, CR_BM) * cdiv(N, cfg == 31 ? 160 : 128);
+  const long tiles = (long)cdiv(M, CR_BM) * cdiv(N, (cfg == 31 || cfg == 33) ? 160 : 128);
   const long target = KNOB(17) > 0 ? KNOB(17) : 256;
   long s = (target + tiles / 2) / tiles;
   if (s < 1) s = 1;
@@ -397,7 +464,7 @@ int cr256_pick_splitk(int M, int N, long red, int cfg) {
 }
 
 // bn = 160 or 128 (0: 160 where N divides and no bias gradient is asked for, else 128)
-int launch_cr256(const GemmP& pin, int bn, hipStream_t st, bool deep) {
+int launch_cr256(const GemmP& pin, int bn, hipStream_t st, bool deep, bool phased) {
   ARG_CHECK(cr256_applicable(pin), "cr256: problem %dx%dx%d (form %d) does not fit the co-resident 256-row kernel", pin.M, pin.N, pin.K, pin.form);
   GemmP p = pin;
   bool biasg = p.form == GEMM_TN && p.bias_grad != nullptr;
@@ -428,6 +495,13 @@ int launch_cr256(const GemmP& pin, int bn, hipStream_t st, bool deep) {
     }
   }
 #endif
+  if (phased && bn == 128) {
+    switch (p.form) {
+      case GEMM_NT: return launch_cr<GEMM_NT, 128, false, CR_S, true>(p, st);
+      case GEMM_NN: return launch_cr<GEMM_NN, 128, false, CR_S, true>(p, st);
+      default: return biasg ? launch_cr<GEMM_TN, 128, true, CR_S, true>(p, st) : launch_cr<GEMM_TN, 128, false, CR_S, true>(p, st);
+    }
+  }
   switch (p.form) {
     case GEMM_NT: return bn == 160 ? launch_cr<GEMM_NT, 160, false>(p, st) : launch_cr<GEMM_NT, 128, false>(p, st);
     case GEMM_NN: return bn == 160 ? launch_cr<GEMM_NN, 160, false>(p, st) : launch_cr<GEMM_NN, 128, false>(p, st);

@@ -16,7 +16,7 @@
 //   12 = 1: no three-tap conv weight gradient; 13 split-K workgroup target of conv_wgrad3 / wgrad256 (144); 14 = 2: its W = 32 form
 //   15 = 1: no half-height tail workgroups in the 256 x 256 kernel
 //   16 co-resident 256-row kernel for the level-2 linear weight gradients: 0 policy, 1 off, 2 / 3 = 128 / 160-column tiles wherever allowed;
-//   17 its split-K workgroup target for long reductions (0: 256); 19 = 1: also the 16 384-row level's linear weight gradients on it; 20 = 1: self-attention backward as two launches (dQ, then dK / dV); 22 configuration of the GEGLU (FF2) dgrad; 21 = 1: Delta always from its own pass; 18 = 1: no padding columns on the feed-forward hidden tensors
+//   17 its split-K workgroup target for long reductions (0: 256); 19 = 1: also the 16 384-row level's linear weight gradients on it; 20 = 1: self-attention backward as two launches (dQ, then dK / dV); 23 = 1: lockstep loop of the co-resident 256-row kernel everywhere, = 2: its phased loop only for >= 256 tiles; 22 configuration of the GEGLU (FF2) dgrad; 21 = 1: Delta always from its own pass; 18 = 1: no padding columns on the feed-forward hidden tensors
 // The product library has NO knobs: KNOB(i) is the constant 0 (= the shipped policy) and every experiment branch below it folds away.
 // The diagnostics build (`build.py --diag`: -DSDXL_DIAG -> libsdxlstep_diag.so, include/sdxlstep_diag.h) keeps the table, sdxl_set_knob,
 // the stream-K kernel (gemm_sk.hip), the stride-2 forward / weight gradient on phase planes (GemmP::up2 == 3) and the W = 32 three-tap form:
@@ -162,7 +162,7 @@ int launch_wgrad256(const GemmP& p, hipStream_t st);
 void wgrad256_set_enabled(bool on);
 // co-resident 256-row tile, 8 waves, <= 78 KiB LDS, <= 128 registers (gemm_cr256.hip): linear NT / NN / TN problems, K % 32 == 0
 bool cr256_applicable(const GemmP& p);
-int launch_cr256(const GemmP& p, int bn, hipStream_t st, bool deep = false);      // bn = 160 / 128 / 0 (pick); deep: exclusive 6-deep ring (diagnostics build)
+int launch_cr256(const GemmP& p, int bn, hipStream_t st, bool deep = false, bool phased = false);      // bn = 160 / 128 / 0 (pick); deep: exclusive 6-deep ring (diagnostics build)
 int cr256_wgrad_cfg(int M, int N, long red, bool bias);
 int cr256_pick_splitk(int M, int N, long red, int cfg);        // the plan's choice for a linear weight gradient [M][N] over `red` rows: 0 / 31 / 32 (GemmP::cfg)
 // per-launch HIP-event timing of every GEMM launch between begin and end (end synchronises the device)
