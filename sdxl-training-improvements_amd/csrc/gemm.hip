@@ -1228,8 +1228,8 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
   int rc;
   {   // co-resident 256-row kernel (gemm_cr256.hip): forced configurations 31 (160-column tiles) / 32 (128)
     const int fc = p.cfg > 0 ? p.cfg : g_force_cfg;
-    if (fc >= 31 && fc <= 35 && !p.delta_out && cr256_applicable(p)) {      // (33 / 34: the exclusive 6-deep form, diagnostics build; 35: 128 columns, phased loop)
-      rc = launch_cr256(p, (fc == 31 || fc == 33) ? 160 : 128, st, fc == 33 || fc == 34, fc == 35);
+    if (fc >= 31 && fc <= 36 && !p.delta_out && cr256_applicable(p)) {      // (33 / 34: the exclusive 6-deep form, diagnostics build; 35 / 36: phased loop, 128 / 160 columns)
+      rc = launch_cr256(p, (fc == 31 || fc == 33 || fc == 36) ? 160 : 128, st, fc == 33 || fc == 34, fc == 35 || fc == 36);
       if (rc == 0 && p.form == GEMM_TN && p.splitk > 1) {
         const long nv = (long)p.M * (p.N / 4);
         int g = (int)((nv + 255) / 256);

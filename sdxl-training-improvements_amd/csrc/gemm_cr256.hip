@@ -54,13 +54,13 @@ struct CrGeom {
 //     issues its DMA pieces and fragment reads, instead of all eight doing each at the same time.  128-column tiles only (all nine
 //     fragments of a step are live at once: 160 columns do not fit the 128 registers).
 template <int FORM, int BN, bool BIASG, int S, bool PH = false>
-__global__ __launch_bounds__(512, S != CR_S ? 2 : (PH && BIASG) ? 3 : 4) void cr256_kernel(const GemmP pin) {
+__global__ __launch_bounds__(512, S != CR_S ? 2 : (PH && (BIASG || BN == 160)) ? 3 : 4) void cr256_kernel(const GemmP pin) {
   using G = CrGeom<BN>;
   constexpr bool A_KC = FORM != GEMM_TN;   // A tile K-contiguous (rows = output rows)
   constexpr bool B_KC = FORM == GEMM_NT;   // B tile K-contiguous (rows = output columns)
   constexpr int NJ = G::NJ;
   constexpr int dbg = SDXL_CR_DIAG;
-  static_assert(!BIASG || (FORM == GEMM_TN && (BN == 128 || S > CR_S)), "bias gradient: TN form; 128-column tiles in the co-resident form");
+  static_assert(!BIASG || (FORM == GEMM_TN && (BN == 128 || S > CR_S || PH)), "bias gradient: TN form; 128-column tiles in the lockstep co-resident form");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const bf16* Ap = pin.A;
   const bf16* Bp = pin.B;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512, S != CR_S ? 2 : (PH && BIASG) ? 3 : 4) void cr
   if (dbg & 2) dma_on = false;
   int rd = 0, wr = S - 1;
   if (PH) {
-    static_assert(!PH || (S == 3 && BN == 128), "phased loop: 3-deep ring, 128-column tiles");
+    static_assert(!PH || S == 3, "phased loop: 3-deep ring");
     // Barrier sequence X0, X1, ...: half 0 (waves 0-3) runs L(t) in [X_2t, X_2t+1] and M(t) in [X_2t+1, X_2t+2], half 1 one barrier later.
     // RAW: a wave's pieces of step t + 1 are waited for (counted vmcnt: only those of t + 2, just issued, may be outstanding) at the end
     //      of its L(t), i.e. before X_2t+2 at the latest -- the barrier in front of the earliest L(t + 1).
@@ -448,6 +448,8 @@ int cr256_wgrad_cfg(int M, int N, long red, bool bias) {
   int cfg = cr256_wgrad_cfg_tiles(M, N, red, bias);
   // 128-column tiles: the phased loop (configuration 35; knob 23 = 1: the lockstep loop everywhere, = 2: phased only for >= 256 tiles)
   if (cfg == 32 && KNOB(23) != 1 && (KNOB(23) != 2 || (long)cdiv(M, CR_BM) * cdiv(N, 128) >= 256)) cfg = 35;
+  // (knob 23 = 3 / 4, experiment: the phased loop on 160-column tiles for outputs of >= 8192 rows / wherever N % 160 == 0)
+  if (cfg == 35 && N % 160 == 0 && ((KNOB(23) == 3 && M >= 8192) || KNOB(23) == 4)) cfg = 36;
   return cfg;
 }
 
@@ -455,7 +457,7 @@ int cr256_wgrad_cfg(int M, int N, long red, bool bias) {
 // dgrad); longer reductions with few tiles are cut to ~`target` workgroups of >= 64 K-steps
 int cr256_pick_splitk(int M, int N, long red, int cfg) {
   if (red <= 8192 && KNOB(17) <= 0) return 1;      // (knob 17 > 0, experiment: the 4096-row level split to ~that many workgroups too)
-  const long tiles = (long)cdiv(M, CR_BM) * cdiv(N, (cfg == 31 || cfg == 33) ? 160 : 128);
+  const long tiles = (long)cdiv(M, CR_BM) * cdiv(N, (cfg == 31 || cfg == 33 || cfg == 36) ? 160 : 128);
   const long target = KNOB(17) > 0 ? KNOB(17) : 256;
   long s = (target + tiles / 2) / tiles;
   if (s < 1) s = 1;
@@ -471,7 +473,7 @@ int launch_cr256(const GemmP& pin, int bn, hipStream_t st, bool deep, bool phase
   if (p.form == GEMM_TN && p.group > 1)
     for (int i = 0; i < p.group; ++i) biasg = biasg || p.gbias_grad[i] != nullptr;
   if (bn == 0) bn = (p.N % 160 == 0 && !biasg) ? 160 : 128;
-  if (biasg && !deep) bn = 128;
+  if (biasg && !deep && !phased) bn = 128;
   {   // px x (8/px) XCD grid over the (n, m) tile grid minimising the per-XCD operand footprint ~ N/px + M/py
     const int gx = cdiv(p.N, bn), gy = cdiv(p.M, CR_BM);
     double best = 1e30;
@@ -502,6 +504,8 @@ int launch_cr256(const GemmP& pin, int bn, hipStream_t st, bool deep, bool phase
       default: return biasg ? launch_cr<GEMM_TN, 128, true, CR_S, true>(p, st) : launch_cr<GEMM_TN, 128, false, CR_S, true>(p, st);
     }
   }
+  if (phased && p.form == GEMM_TN)      // 160-column tiles, phased: the weight-gradient form only (up to 168 registers: three waves per SIMD)
+    return biasg ? launch_cr<GEMM_TN, 160, true, CR_S, true>(p, st) : launch_cr<GEMM_TN, 160, false, CR_S, true>(p, st);
   switch (p.form) {
     case GEMM_NT: return bn == 160 ? launch_cr<GEMM_NT, 160, false>(p, st) : launch_cr<GEMM_NT, 128, false>(p, st);
     case GEMM_NN: return bn == 160 ? launch_cr<GEMM_NN, 160, false>(p, st) : launch_cr<GEMM_NN, 128, false>(p, st);

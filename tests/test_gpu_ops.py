@@ -230,7 +230,7 @@ def test_gemm_tn_long_reduction_wgrad256(L, M, N, K, splitk):
         report("wgrad256 vs 128x160 kernel", out * 0.5, o1, tol)
 
 
-@pytest.fixture(params=[31, 32, 35] + ([33, 34] if lib.DIAG else []))
+@pytest.fixture(params=[31, 32, 35, 36] + ([33, 34] if lib.DIAG else []))
 def cr256(L, request):
     """force the co-resident 256-row kernel (gemm_cr256.hip; 31: 256 x 160 tiles, 32: 256 x 128) wherever it is applicable
     (diagnostics build: also 33 / 34, the exclusive 6-deep-ring form of the same tiles)"""
