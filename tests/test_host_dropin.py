@@ -210,3 +210,11 @@ def test_config_from_unet_shapes():
                                                      "projection_class_embeddings_input_dim": 2816, "attention_head_dim": [5, 10, 20]}), sd)
     assert tuple(c2.block_out_channels) == (320, 640, 1280) and tuple(c2.transformer_layers) == (0, 2, 10)
     assert c2.pooled_dim == 1280 and c2.head_dim == 64
+
+
+def test_checkpoint_dir_is_the_references_layout(tmp_path):
+    """sdxl_trainer.py:171-178: outputs/checkpoint-<epoch:04d> / outputs/final_checkpoint relative to the working directory; a path is taken as is"""
+    from pathlib import Path
+    assert T.checkpoint_dir(3) == Path("outputs") / "checkpoint-0003"
+    assert T.checkpoint_dir(12, is_final=True) == Path("outputs") / "final_checkpoint"
+    assert T.checkpoint_dir(tmp_path / "x", True) == tmp_path / "x" and T.checkpoint_dir(str(tmp_path / "y")) == tmp_path / "y"
