@@ -32,6 +32,13 @@ int sdxl_debug_act_checksums(sdxl_handle* h, unsigned long long* out_host, int c
 int sdxl_op_exchange_shadow(void* buf, size_t bytes, int workgroups, int lds_bytes, float busy_us, void* stream);
 
 /* ---- part 2: experiment ABI (diagnostics build only) ---- */
+/* the linear dgrad whose epilogue runs the backward of the LayerNorm that produced its input (csrc/kernels.h, GemmP::ln_x): dY [M][K] bf16,
+ * W [K][N] bf16 (N = the LayerNorm width), x [M][N] the LayerNorm's input, stats [M][2] its (mean, rstd), gamma [N]; dx [M][N] = the
+ * LayerNorm's input gradient (+ addend, or null); dy_out (or null) [M][N] = dY W; pcol (or null) [cdiv(M, 128)][2][N] fp32 partial sums of
+ * dgamma | dbeta per 128-row block.  N <= 1280, cdiv(M, 128) * cdiv(N, 128) <= 512.  Runs the launch three times (epochs 1, 2, 3) on one scratch buffer. */
+int sdxl_op_linear_dgrad_ln_bwd(const void* dy, const void* w, const void* x, const float* stats, const void* gamma, const void* addend,
+                                void* dx, void* dy_out, float* pcol, int M, int N, int K, void* stream);
+
 /* experiment knobs of the plan (A/B runs; 0 = the shipped policy): see csrc/kernels.h.  Process-global, read at plan-build, forward
  * and backward time: set them before sdxl_plan / the first step and do not change them while a handle is in use. */
 int sdxl_set_knob(int id, int value);

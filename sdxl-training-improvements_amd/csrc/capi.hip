@@ -408,6 +408,10 @@ static int run_backward_segment_body(Engine& e, int k, bool first, hipStream_t s
   int s = e.nseg - 1 - k;
   e.ev_used = 0;   // per-op events are consumed in order; a segment's waits are all enqueued before the pool is reused
   if (k == 0 && p.tp32_off != NONE) HIP_CHECK_RET(hipMemsetAsync(p.F(p.tp32_off), 0, p.tp32_bytes, st));
+  if (k == 0 && p.ln_part_floats) {      // the fused LayerNorm backward's tagged partial sums: epochs count from 1 in every backward
+    HIP_CHECK_RET(hipMemsetAsync(p.F(p.ln_part_off), 0, p.ln_part_floats * sizeof(float), st));
+    p.ln_epoch = 0;
+  }
   for (int i = p.seg_last_op[s]; i >= p.seg_first_op[s] && i >= 0; --i) CHK(p.ops[i]->bwd(p, st, first));
   // the segment's weight gradients are complete once `st` passes this point -- unless the caller declared (sdxl_set_join_mode)
   // that it only needs that of the whole backward (no per-segment gradient exchange): then the side stream runs free
@@ -919,6 +923,34 @@ int sdxl_set_gemm_mode(int mode) {
 }
 int sdxl_profile_gemm_end(double* flops, double* ms, int* launches) { return gemm_profile_end(flops, ms, launches); }
 #ifdef SDXL_DIAG     // ---- experiment ABI of the diagnostics build (include/sdxlstep_diag.h): not in the product library ----
+// dY [M][Kr] x W [Kr][N] (the NN dgrad form) with the LayerNorm backward of GemmP::ln_x in the epilogue: dx = LN_bwd(dY W | x, stats, gamma)
+// (+ addend), dy_out (or null) = dY W, pcol (or null) = [cdiv(M, 128)][2][N] dgamma | dbeta partial sums.  Scratch is allocated, zeroed and
+// freed per call (test hook; the plan shares its own); N <= 1280.
+int sdxl_op_linear_dgrad_ln_bwd(const void* dy, const void* w, const void* x, const float* stats, const void* gamma, const void* addend,
+                                void* dx, void* dy_out, float* pcol, int M, int N, int Kr, void* st) {
+  ARG_CHECK(gemm_ln_cfg(M, N, Kr) != 0, "linear_dgrad_ln_bwd: M=%d N=%d K=%d does not fit the fused epilogue", M, N, Kr);
+  float* part = nullptr;
+  const size_t pbytes = gemm_ln_part_floats(M, N) * sizeof(float);
+  HIP_CHECK_RET(hipMalloc((void**)&part, pbytes));
+  HIP_CHECK_RET(hipMemsetAsync(part, 0, pbytes, (hipStream_t)st));
+  GemmP g;
+  gemm_defaults(&g);
+  g.form = GEMM_NN;
+  g.A = (const bf16*)dy; g.B = (const bf16*)w; g.C = dy_out;
+  g.M = M; g.N = N; g.K = Kr;
+  g.lda = Kr; g.ldb = N; g.ldc = N;
+  g.ln_x = (const bf16*)x; g.ln_ldx = N; g.ln_stats = stats; g.ln_gamma = (const bf16*)gamma;
+  g.ln_dx = (bf16*)dx; g.ln_addend = (const bf16*)addend; g.ln_ldo = N;
+  g.ln_part = part; g.ln_pcol = pcol;
+  int rc = 0;
+  for (int epoch = 1; epoch <= 3 && rc == 0; ++epoch) {      // three launches on the same scratch: later ones find the earlier epochs' granules
+    g.ln_epoch = epoch;
+    rc = launch_gemm(g, (hipStream_t)st);
+  }
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)st));
+  (void)hipFree(part);
+  return rc;
+}
 // Knobs are process-global and read at plan-build, forward and backward time: set them BEFORE sdxl_plan / the first step of a handle and
 // leave them alone afterwards (A/B runs restart the process per setting, profiles/tools/ab.sh).
 int sdxl_set_knob(int id, int value) {

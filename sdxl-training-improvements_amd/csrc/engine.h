@@ -83,6 +83,10 @@ struct Plan {
   size_t slab_main_off = NONE, slab_main_floats = 0;   // the same for split forward / dgrad launches (caller's stream)
   size_t apart_off = NONE, apart_floats = 0;  // query-split partials of the self-attention dK / dV kernel (caller's stream)
   size_t apart_side_off = NONE, apart_side_floats = 0;   // ... of the cross-attention dK / dV kernel (side stream): never shared
+  // LayerNorm backward inside the dgrad epilogue of the linear layer its output feeds (GemmP::ln_x): the tagged per-row partial sums the
+  // column tiles of a row block exchange; shared, stream-ordered; zeroed at the start of a backward, whose fused launches count the epoch up
+  size_t ln_part_off = NONE, ln_part_floats = 0;
+  int ln_epoch = 0;
 
   Act* new_act(long rows, int cols, bool need_grad = true, int pad_rows = 0);
   Act* view(Act* parent, int col0, int cols);   // columns [col0, col0 + cols) of parent

@@ -178,12 +178,21 @@ static int kv_pad_rows(int B, int ctx) { return (int)((64 - ((long)B * ctx) % 64
 struct AttnOp;
 static void attn_delta_target(AttnOp* a, Plan& p, GemmP& g);      // (defined behind AttnOp)
 static bool attn_delta_wanted(const AttnOp* a);
+struct LayerNormOp;
+static bool ln_fuse_plan(LayerNormOp* ln, Plan& p, int mode);      // (defined behind LayerNormOp)
+static void ln_fuse_target(LayerNormOp* ln, Plan& p, GemmP& g, int mode);
 struct LinearOp : Op {
   Act *x, *y, *resid;
   PRef w, b;
   int K, N;
   int resid_alias = 0, splitk = 1, wgroup = 1;
   struct AttnOp* delta_attn = nullptr;      // x is the output of this self-attention layer: the dgrad's epilogue also writes its Delta (GemmP::delta_out)
+  // x is the output of this LayerNorm and feeds nothing else: the dgrad's epilogue runs the LayerNorm's backward (GemmP::ln_x) -- dx of the
+  // LayerNorm straight from the accumulators (the knock-out of the separate dx pass: -4.6 ms per step), its dgamma | dbeta partial sums too.
+  // ln_mode (plan_bwd): 0 not fused (the shipped plan; shape / split-K), 1 fused (knob 26 = 1, diagnostics build), 2 fused but dy is still
+  // stored and the parameter gradients take their own pass over it (knob 26 = 2).  Measured: -0.35 ms per step, not shipped.
+  struct LayerNormOp* ln_src = nullptr;
+  int ln_mode = 0;
   int crcfg = 0, crsplit = 1;   // weight gradient on the co-resident 256-row kernel (gemm_cr256.hip): GemmP::cfg 31 / 32, its split-K factor
   int fsplit = 1, dsplit = 1;   // split-K of the forward / dgrad launch (small-M problems, gemm_pick_splitk_small)
   size_t dy32_off = NONE;   // the output gradient arrives as fp32 sums (grouped time-embedding projection): cast first
@@ -228,6 +237,9 @@ struct LinearOp : Op {
       // knob 3 (experiment): split the reduction of the long-K dgrads (N >= knob 4) s ways although their tiles fill half the chip
       if (KNOB(3) > 1 && N >= (KNOB(4) > 0 ? KNOB(4) : 8192) && N % (64 * KNOB(3)) == 0 && dsplit == 1) dsplit = KNOB(3);
       want_slab_main(p, (int)x->rows, K, dsplit);
+      if (SDXL_LN_EPILOGUE && ln_src && KNOB(26) != 0 && dsplit == 1 && dx.addend == NONE && !x->parent && gemm_ln_cfg((int)x->rows, K, N) &&
+          ln_fuse_plan(ln_src, p, KNOB(26) == 2 ? 2 : 1))
+        ln_mode = KNOB(26) == 2 ? 2 : 1;
     }
   }
   int bwd(Plan& p, hipStream_t st, bool first) override {
@@ -280,6 +292,7 @@ struct LinearOp : Op {
       if (KNOB(22) > 0 && gu) g.cfg = KNOB(22);     // experiment: configuration of the GEGLU (FF2) dgrad
       // (last: the epilogue that writes Delta exists on the 128 x 128 tiles of the 4-wave kernel only)
       if (delta_attn && attn_delta_wanted(delta_attn) && dsplit <= 1 && K % 128 == 0) { attn_delta_target(delta_attn, p, g); g.cfg = 1; }
+      if (ln_mode) { ln_fuse_target(ln_src, p, g, ln_mode); g.cfg = 0; g.resid = nullptr; }
       CHK(launch_gemm(g, st));
     }
     return 0;
@@ -482,6 +495,7 @@ struct LayerNormOp : Op {
   size_t stats_off, part_off = NONE;
   size_t dy_off = NONE;
   Plan::GradDst dx;
+  int fused = 0;      // the consumer's dgrad epilogue produces dx (LinearOp::ln_mode); set by its plan_bwd, which runs first
   LayerNormOp(Plan& p, Act* x_, Act* y_, PRef g_, PRef b_, int C_, float eps_) : x(x_), y(y_), gm(g_), bt(b_), C(C_), eps(eps_) {
     stats_off = p.alloc(sizeof(float) * x->rows * 2);
   }
@@ -500,10 +514,25 @@ struct LayerNormOp : Op {
     // dbeta as a leaf pass of their own on the side stream (re-reads x, dy: 21 MB, from L2 / MALL) -- step -0.7 ms against the fused
     // form (dx + per-block parameter partial sums in one pass: 180 VGPRs + 40 KiB LDS, one block per CU when co-running;
     // knob 10 = 2 selects it, A/B runs).  Round 2 measured the two forms equal; since then the main stream became the critical one.
+    if (fused) {      // dx is in place (or will be: this op runs after the consumer in the backward order); the parameter gradients:
+      if (fused == 2) {
+        const bf16* xp = p.P(x); const bf16* dyp = p.GP(dy_off); const float* sp = p.F(stats_off);
+        float* dg = p.eng->Gp(gm); float* db = p.eng->Gp(bt); const int Mr = (int)x->rows, Cc = C;
+        return side_leaf(p, st, [=](hipStream_t s2) -> int { return launch_layernorm_param_grads(xp, dyp, sp, dg, db, Mr, Cc, s2); });
+      }
+      LnRedEntry r;      // the epilogue's per-row-block column sums, folded at the segment's end
+      r.part = p.F(part_off); r.dgamma = p.eng->Gp(gm); r.dbeta = p.eng->Gp(bt); r.C = C; r.nblk = gemm_ln_rowblocks((int)x->rows);
+      p.eng->ln_pending.push_back(r);
+      return 0;
+    }
+    // knob 25 (timing knock-outs, wrong gradients): 1 = no parameter-gradient pass, 2 = no dx pass either, 3 = dx pass only skipped
+    if (KNOB(25) == 2) return 0;
     if (KNOB(10) != 2) {
+      if (KNOB(25) != 3)
       CHK(launch_layernorm_bwd(p.P(x), p.GP(dy_off), p.eng->Wp(gm), p.F(stats_off), p.GP(dx.out), p.GP(dx.addend), nullptr, nullptr, (int)x->rows, C, st));
       const bf16* xp = p.P(x); const bf16* dyp = p.GP(dy_off); const float* sp = p.F(stats_off);
       float* dg = p.eng->Gp(gm); float* db = p.eng->Gp(bt); const int Mr = (int)x->rows, Cc = C;
+      if (KNOB(25) == 1) return 0;
       return side_leaf(p, st, [=](hipStream_t s2) -> int { return launch_layernorm_param_grads(xp, dyp, sp, dg, db, Mr, Cc, s2); });
     }
     LnRedEntry r;
@@ -514,6 +543,25 @@ struct LayerNormOp : Op {
     return 0;
   }
 };
+
+static bool ln_fuse_plan(LayerNormOp* ln, Plan& p, int mode) {
+  const int M = (int)ln->x->rows, C = ln->C;
+  if (ln->x->ld() != C || ln->y->ld() != C) return false;
+  if (gemm_ln_pcol_floats(M, C) > layernorm_bwd_part_floats(M, C)) return false;      // (the column partials live in the LayerNorm's own part buffer)
+  ln->fused = mode;
+  const size_t pf = gemm_ln_part_floats(M, C);
+  if (pf > p.ln_part_floats) p.ln_part_floats = pf;
+  return true;
+}
+static void ln_fuse_target(LayerNormOp* ln, Plan& p, GemmP& g, int mode) {
+  g.ln_x = p.P(ln->x); g.ln_ldx = ln->x->ld();
+  g.ln_stats = p.F(ln->stats_off);
+  g.ln_gamma = p.eng->Wp(ln->gm);
+  g.ln_dx = p.GP(ln->dx.out); g.ln_addend = p.GP(ln->dx.addend); g.ln_ldo = ln->x->ld();
+  g.ln_part = p.F(p.ln_part_off);
+  g.ln_epoch = ++p.ln_epoch;
+  if (mode == 1) { g.ln_pcol = p.F(ln->part_off); g.C = nullptr; }      // dy itself is not stored
+}
 
 // self attention: qkv [B*N][3C]; cross attention: q [B*N][C], kv [B*ctx][2C]
 struct AttnOp : Op {
@@ -741,7 +789,20 @@ struct Builder {
     Act* y = kind == 2 ? wide_act(x->rows, N) : pl->new_act(x->rows, N);
     LinearOp* op = tagseg(pl->add<LinearOp>(x, y, w, b, K, N, resid), w);
     if (op_out) *op_out = op;
+    ln_consumer(op);
     return y;
+  }
+  // LayerNorm outputs and the linear layers that read them: a LayerNorm whose output feeds exactly one linear layer has its backward run
+  // in that layer's dgrad epilogue (LinearOp::ln_src)
+  std::map<Act*, LayerNormOp*> ln_of;
+  std::map<Act*, LinearOp*> ln_reader;
+  void ln_consumer(LinearOp* op) {
+    auto it = ln_of.find(op->x);
+    if (it == ln_of.end()) return;
+    auto rd = ln_reader.find(op->x);
+    if (rd != ln_reader.end()) { rd->second->ln_src = nullptr; return; }      // a second reader: nobody fuses
+    ln_reader[op->x] = op;
+    op->ln_src = it->second;
   }
   // The feed-forward hidden tensors ([rows][8C] pre-activation, [rows][4C] activation): a row stride that is a multiple of 1 KiB puts the
   // 16 rows of a K-contiguous LDS-DMA piece (and the 32 k-rows of an N-contiguous one) on 1, 2 or 4 of the 16 L2 channels of an XCD
@@ -758,7 +819,7 @@ struct Builder {
     for (int i = 0; i < n; ++i) e.map_src(names[i] + ".weight", {Neach, K}, w, 0, (size_t)i * Neach * K, 0);
     if (!pl) return nullptr;
     Act* y = pl->new_act(x->rows, n * Neach);
-    tagseg(pl->add<LinearOp>(x, y, w, PRef(), K, n * Neach, nullptr), w);
+    ln_consumer(tagseg(pl->add<LinearOp>(x, y, w, PRef(), K, n * Neach, nullptr), w));
     return y;
   }
   Act* conv(const std::string& name, Act* x, int h, int w_, int cin, int cout, int stride, Act* resid, Act* rowvec,
@@ -792,7 +853,7 @@ struct Builder {
     e.map_src(name + ".bias", {C}, b, 0, 0, 0);
     if (!pl) return nullptr;
     Act* y = pl->new_act(x->rows, C);
-    tagseg(pl->add<LayerNormOp>(*pl, x, y, g, b, C, e.cfg.ln_eps), g);
+    ln_of[y] = tagseg(pl->add<LayerNormOp>(*pl, x, y, g, b, C, e.cfg.ln_eps), g);
     return y;
   }
   Act* silu(Act* x) {
@@ -1064,6 +1125,7 @@ void Engine::build(Plan* plan) {
     plan->slab_main_off = plan->alloc(sizeof(float) * (plan->slab_main_floats ? plan->slab_main_floats : 4));
     plan->apart_off = plan->alloc(sizeof(float) * (plan->apart_floats ? plan->apart_floats : 4));
     plan->apart_side_off = plan->alloc(sizeof(float) * (plan->apart_side_floats ? plan->apart_side_floats : 4));
+    plan->ln_part_off = plan->alloc(sizeof(float) * (plan->ln_part_floats ? plan->ln_part_floats : 4));
     plan->seg_first_op.assign(nseg, -1);
     plan->seg_last_op.assign(nseg, -2);
     for (int i = 0; i < (int)plan->ops.size(); ++i) {

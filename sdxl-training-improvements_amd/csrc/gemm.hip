@@ -32,6 +32,20 @@ static int g_sk_mode = 0;     // stream-K kernel (gemm_sk.hip, diagnostics build
 #endif
 
 static constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
+// sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), valid in the row's lane 15: four row_shr steps on the VALU, zeros shifted in
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+  return v;
+}
+__device__ __forceinline__ bf16x8 z8() {
+  bf16x8 z;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
+  return z;
+}
 static constexpr int gemm_smem_bytes(int BN, int S, int BK, int NW = 4) {
   // + 1 KiB that absorbs the padding DMA pieces, where the tiles' 1 KiB chunks do not divide evenly among the waves
   const bool pad = ((BM * BK * 2 / 1024) % NW) != 0 || ((BN * BK * 2 / 1024) % NW) != 0;
@@ -685,6 +699,200 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
     }
     return;
   }
+  // ---- LayerNorm backward in the epilogue of the dgrad that produces its dy (GemmP::ln_x; kernels.h) ----
+  constexpr bool LN_OK = SDXL_LN_EPILOGUE && FORM == GEMM_NN && !CONV && BN == 128 && NW == 4 && !KSP && FAST && BK == 64 && S == 2;      // (160-column tiles: 80 accumulators + this epilogue spill)
+  if constexpr (LN_OK) if (p.ln_x) {
+    constexpr int NP = NJ / 2;            // fragment pairs = 8-column chunks per lane and fragment row
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+    __syncthreads();                      // every wave is done with the ring: it becomes the exchange area
+    float* rowpart = (float*)smem;                 // [2 wave columns][128 rows][2]
+    float* rowtot = rowpart + 2 * 128 * 2;         // [2 gather halves][128][2]  S1, S2 of the whole rows
+    float* colpart = rowtot + 2 * 128 * 2;         // [2 wave rows][2][BN]
+    const int wcol = n0 + wn * (BN / 2);
+    const int mrow = m0 + wm * (MI * 16) + l16;    // fragment row i: + 16 i
+    float s1[MI], s2[MI], mean[MI], rstd[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const bool mok = mrow + i * 16 < p.M;
+      mean[i] = mok ? p.ln_stats[(long)(mrow + i * 16) * 2] : 0.f;
+      rstd[i] = mok ? p.ln_stats[(long)(mrow + i * 16) * 2 + 1] : 0.f;
+      s1[i] = 0.f; s2[i] = 0.f;
+    }
+    // pass 1, column chunk by column chunk: dy (bf16-rounded, as a stored dy would be read back; the accumulators keep the exchanged,
+    // rounded values for pass 2), the row sums of this wave's columns, the column sums of its rows.  (Predicated loads, chunk by chunk
+    // behind scheduling fences: 233 VGPRs; the straight-line form with clamped addresses takes 253, and above 240 a workgroup of this
+    // kernel no longer shares a CU with the bias-gradient instance of the co-resident weight-gradient kernel.)
+#pragma unroll
+    for (int jp = 0; jp < NP; ++jp) {
+      const int j = 2 * jp;
+      const int nc = wcol + (j + (g & 1)) * 16 + (g >> 1) * 8;
+      const bool nok = nc < p.N;
+      bf16x8 gv = z8();
+      if (nok) gv = *(const bf16x8*)(p.ln_gamma + nc);
+      float pg[8], pb[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { pg[e] = 0.f; pb[e] = 0.f; }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = mrow + i * 16;
+        const bool ok = nok && m < p.M;
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float lo = acc[i][j][r], hi = acc[i][j + 1][r];
+          asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));      // (2 wait states: VALU write -> permlane read)
+          lo = (float)(bf16)lo; hi = (float)(bf16)hi;
+          acc[i][j][r] = lo; acc[i][j + 1][r] = hi;
+          v[r] = lo; v[4 + r] = hi;
+        }
+        if (p.C && ok) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+          *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + nc) = o;
+        }
+        bf16x8 xv = z8();
+        if (ok) xv = *(const bf16x8*)(p.ln_x + (long)m * p.ln_ldx + nc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = ((float)xv[e] - mean[i]) * rstd[i];
+          const float t = v[e] * (float)gv[e];
+          s1[i] += t; s2[i] += t * xh;
+          pg[e] += v[e] * xh; pb[e] += v[e];
+        }
+        __builtin_amdgcn_sched_barrier(0);      // (keeps hipcc from hoisting every chunk's loads to the top: registers)
+      }
+      if (p.ln_pcol) {      // column sums over this wave's 64 rows: over the fragment rows in the lane (done), then over the 16 lanes of a row group
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float sg = row16_sum(pg[e]), sb = row16_sum(pb[e]);
+          if (l16 == 15) {
+            colpart[(wm * 2 + 0) * BN + (nc - n0) + e] = sg;
+            colpart[(wm * 2 + 1) * BN + (nc - n0) + e] = sb;
+          }
+        }
+      }
+    }
+    static_assert(!LN_OK || (NJ & 1) == 0, "LayerNorm-backward epilogue: whole fragment pairs");
+    // a row's columns of this wave sit in the four lanes l16 + 16 g: two exchange steps finish its sums (all four lanes get them)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      float a = s1[i], b2 = s1[i];
+      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b2));
+      float t = a + b2; a = t; b2 = t;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b2));
+      const float r1 = a + b2;
+      a = s2[i]; b2 = s2[i];
+      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b2));
+      t = a + b2; a = t; b2 = t;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b2));
+      const float r2 = a + b2;
+      if (g == 0) {
+        float* rp = rowpart + ((wn * 128) + wm * (MI * 16) + i * 16 + l16) * 2;
+        rp[0] = r1; rp[1] = r2;
+      }
+    }
+    __syncthreads();
+    const int ncolt = gridDim.x;
+    const long Mpad = (long)gridDim.y * BMT;
+    typedef unsigned long long u64;
+    u64* const slots = (u64*)p.ln_part;      // [column tile][row]{(S1, tag), (S2, tag)}: 8-byte granules, tag = this launch's epoch
+    const u64 tag = (u64)(unsigned)p.ln_epoch << 32;
+    if (tid < BMT) {     // this workgroup's partial sums of row tid: write-through (agent-scope) 8-byte stores, each carrying the tag
+      u64* dst = slots + ((long)bx * Mpad + m0 + tid) * 2;
+      const float q1 = rowpart[tid * 2] + rowpart[(128 + tid) * 2], q2 = rowpart[tid * 2 + 1] + rowpart[(128 + tid) * 2 + 1];
+      __hip_atomic_store(dst, tag | (u64)__float_as_uint(q1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dst + 1, tag | (u64)__float_as_uint(q2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (p.ln_pcol && tid < BN && n0 + tid < p.N) {
+      float* dst = p.ln_pcol + (long)by * 2 * p.N + n0 + tid;
+      dst[0] = colpart[tid] + colpart[2 * BN + tid];
+      dst[p.N] = colpart[BN + tid] + colpart[3 * BN + tid];
+    }
+    // meet the other column tiles of the row block.  ONE lane per column tile polls that tile's ready flag (set behind its granules: stores
+    // drained, workgroup barrier, then the flag) -- 320 workgroups x 256 threads polling the granules themselves is a 50 TB/s request storm
+    // on the fabric whenever the workgroups of a row block do not finish together, which is exactly when the others need the fabric
+    // (fused step 110.1 -> measured again below) -- then every thread gathers once.
+    unsigned* const flags = (unsigned*)(slots + (long)ncolt * Mpad * 2);      // [column tile][row block]
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flags + (long)bx * gridDim.y + by, (unsigned)p.ln_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64) {
+      int spins = 0;
+      bool ok;
+      do {
+        unsigned f = (unsigned)p.ln_epoch;
+        if (tid < ncolt) f = __hip_atomic_load(flags + (long)tid * gridDim.y + by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = __all(f == (unsigned)p.ln_epoch);
+        if (!ok) __builtin_amdgcn_s_sleep(4);
+      } while (!ok && ++spins < (1 << 22));
+    }
+    __syncthreads();
+    {   // thread (row, h) gathers the tiles c = 2 k + h (the tags are still checked: a granule that is not there yet is polled for)
+      constexpr int KC = 5;      // <= 10 column tiles (launcher-checked)
+      const int row = tid & (BMT - 1), h = tid >> 7;
+      u64 a[KC], b[KC];
+      int spins = 0;
+      bool ok;
+      do {
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+          const int c = 2 * k + h;
+          a[k] = tag; b[k] = tag;
+          if (c < ncolt) {
+            const u64* src = slots + ((long)c * Mpad + m0 + row) * 2;
+            a[k] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b[k] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        ok = true;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) ok = ok && (a[k] >> 32) == (tag >> 32) && (b[k] >> 32) == (tag >> 32);
+        if (!ok) __builtin_amdgcn_s_sleep(8);
+      } while (!ok && ++spins < (1 << 20));
+      float S1 = 0.f, S2 = 0.f;      // fixed order: the same sums in every workgroup of the row block, run to run
+#pragma unroll
+      for (int k = 0; k < KC; ++k)
+        if (2 * k + h < ncolt) { S1 += __uint_as_float((unsigned)a[k]); S2 += __uint_as_float((unsigned)b[k]); }
+      rowtot[(h * BMT + row) * 2] = S1;
+      rowtot[(h * BMT + row) * 2 + 1] = S2;
+    }
+    __syncthreads();
+    // pass 2: dx = rstd (dy g - S1 / N - xhat S2 / N) (+ addend); x is read again (L2)
+    float S1[MI], S2[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int row = wm * (MI * 16) + i * 16 + l16;
+      const float invn = 1.f / (float)p.N;
+      S1[i] = (rowtot[row * 2] + rowtot[(BMT + row) * 2]) * invn; S2[i] = (rowtot[row * 2 + 1] + rowtot[(BMT + row) * 2 + 1]) * invn;
+    }
+#pragma unroll
+    for (int jp = 0; jp < NP; ++jp) {
+      const int j = 2 * jp;
+      const int nc = wcol + (j + (g & 1)) * 16 + (g >> 1) * 8;
+      if (nc >= p.N) continue;
+      const bf16x8 gv = *(const bf16x8*)(p.ln_gamma + nc);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = mrow + i * 16;
+        if (m >= p.M) continue;
+        const bf16x8 xv = *(const bf16x8*)(p.ln_x + (long)m * p.ln_ldx + nc);
+        bf16x8 o;
+        if (p.ln_addend) o = *(const bf16x8*)(p.ln_addend + (long)m * p.ln_ldo + nc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = e < 4 ? acc[i][j][e & 3] : acc[i][j + 1][e & 3];
+          const float xh = ((float)xv[e] - mean[i]) * rstd[i];
+          float d = rstd[i] * (v * (float)gv[e] - S1[i] - xh * S2[i]);
+          if (p.ln_addend) d += (float)o[e];
+          o[e] = (bf16)d;
+        }
+        *(bf16x8*)(p.ln_dx + (long)m * p.ln_ldo + nc) = o;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    return;
+  }
   if (FORM == GEMM_TN || !p.geglu) {
     if (FORM != GEMM_TN) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // 24 wait states: MFMA results -> inline-asm VALU reads below (XDL write -> VALU read needs up to 18)
 #pragma unroll
@@ -729,7 +937,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
             // (inline asm: hipcc 7.2 folds four __builtin_amdgcn_permlane16_swap calls on the elements of a vector
             //  into one and reuses its result for all of them)
             float lo = acc[i][j][r], hi = acc[i][j + 1][r];
-            asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));      // (2 wait states: VALU write -> permlane read)
             x[r] = lo;
             x[4 + r] = hi;
           }
@@ -892,6 +1100,20 @@ __global__ void splitk_epilogue_kernel(const float* __restrict__ slab, bf16* __r
   }
 }
 
+// Configuration (1: 128 x 128 tiles) of an NN launch whose epilogue runs a LayerNorm backward (GemmP::ln_x), 0: it cannot -- all workgroups
+// of the launch must fit the chip at once (2 per CU: the column tiles of a row block wait for each other), and the epilogue exists on
+// 128-column tiles only (with the 80 accumulators of a 160-column tile it spills).
+int gemm_ln_cfg(int M, int N, int K) {
+  if (K % 64 || N % 8 || M <= 0) return 0;
+  const long t128 = (long)cdiv(M, BM) * cdiv(N, 128);
+  return t128 <= 512 && cdiv(N, 128) <= 10 ? 1 : 0;
+}
+size_t gemm_ln_part_floats(int M, int N) {      // GemmP::ln_part: two 8-byte granules per (column tile, row) + a ready flag per (column tile, row block)
+  return (size_t)cdiv(N, 128) * cdiv(M, BM) * BM * 4 + (size_t)cdiv(N, 128) * cdiv(M, BM) + 4;
+}
+size_t gemm_ln_pcol_floats(int M, int N) { return (size_t)cdiv(M, BM) * 2 * N; }                      // GemmP::ln_pcol
+int gemm_ln_rowblocks(int M) { return cdiv(M, BM); }
+
 size_t gemm_slab_floats(int M, int N, int taps, int splitk) { return splitk > 1 ? (size_t)splitk * M * N * taps : 0; }
 
 void gemm_defaults(GemmP* p) {
@@ -967,6 +1189,7 @@ static int launch_one(const GemmP& p, hipStream_t st) {
   if (p.cfg > 0) cfg = p.cfg;
   if (g_force_cfg > 0) cfg = g_force_cfg;
   if (p.delta_out) cfg = 1;      // the epilogue that also writes an attention layer's Delta exists on 128 x 128 tiles only (whatever is forced)
+  if (p.ln_x) cfg = 1;      // the LayerNorm-backward epilogue exists on 128 x 128 tiles only (gemm_ln_cfg, launcher-checked)
   if (FORM != GEMM_TN && p.splitk > 1) cfg = n160 ? 13 : 1;     // split-K of the bf16-output forms: the 4-wave FAST configurations
   if (p.geglu == 1 && !g80 && (cfg == 3 || cfg == 13 || cfg == 23)) cfg = 1;   // forward, group-64 packing: 128-column tiles
   if (g80 && cfg != 3 && cfg != 13 && cfg != 23) cfg = 13;                 // group-80 packing needs 160-column tiles
@@ -1226,6 +1449,18 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
   }
   const bool conv = p.taps != 1;
   int rc;
+  if (p.ln_x) {      // LayerNorm backward in the dgrad's epilogue (GemmP::ln_x)
+    ARG_CHECK(SDXL_LN_EPILOGUE, "gemm: the LayerNorm-backward epilogue exists in the diagnostics build only");
+    ARG_CHECK(p.form == GEMM_NN && !conv && p.splitk == 1 && !p.geglu && !p.resid && !p.bias && !p.rowvec && !p.delta_out && !p.up2,
+              "gemm: the LayerNorm-backward epilogue takes a plain NN problem");
+    const int lc = gemm_ln_cfg(p.M, p.N, p.K);
+    ARG_CHECK(lc != 0 && (p.cfg == lc || p.cfg == 0), "gemm: LayerNorm-backward epilogue: M=%d N=%d K=%d cfg=%d does not fit (gemm_ln_cfg)", p.M, p.N, p.K, p.cfg);
+    p.cfg = lc;
+    ARG_CHECK(p.ln_stats && p.ln_gamma && p.ln_dx && p.ln_part && p.ln_epoch > 0 && p.ln_ldx % 8 == 0 && p.ln_ldo % 8 == 0 && ((uintptr_t)p.ln_part & 15) == 0 &&
+              (((uintptr_t)p.ln_x | (uintptr_t)p.ln_dx | (uintptr_t)p.ln_addend | (uintptr_t)p.ln_gamma) & 15) == 0,
+              "gemm: LayerNorm-backward epilogue: missing or misaligned buffers");
+    return launch_one<GEMM_NN, false>(p, st);
+  }
   {   // co-resident 256-row kernel (gemm_cr256.hip): forced configurations 31 (160-column tiles) / 32 (128)
     const int fc = p.cfg > 0 ? p.cfg : g_force_cfg;
     if (fc >= 31 && fc <= 36 && !p.delta_out && cr256_applicable(p)) {      // (33 / 34: the exclusive 6-deep form, diagnostics build; 35 / 36: phased loop, 128 / 160 columns)

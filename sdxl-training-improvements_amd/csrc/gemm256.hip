@@ -333,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float lo = acc[i][2 * b][r], hi = acc[i][2 * b + 1][r];
-        asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));      // (2 wait states: VALU write -> permlane read)
         xq[b][r] = lo;
         xq[b][4 + r] = hi;
       }

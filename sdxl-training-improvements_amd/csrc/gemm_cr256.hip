@@ -381,7 +381,7 @@ __global__ __launch_bounds__(512, S != CR_S ? 2 : (PH && (BIASG || BN == 160)) ?
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float lo = acc[i][j][r], hi = acc[i][j + 1][r];
-        asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));      // (2 wait states: VALU write -> permlane read)
         x[r] = lo;
         x[4 + r] = hi;
       }

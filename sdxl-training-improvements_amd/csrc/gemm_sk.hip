@@ -347,7 +347,7 @@ __device__ __forceinline__ void sk_segment(CSkP* kp, CSkProb* pp, char* smem, in
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float lo = acc[i][2 * b][r], hi = acc[i][2 * b + 1][r];
-        asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));      // (2 wait states: VALU write -> permlane read)
         xq[b][r] = lo;
         xq[b][4 + r] = hi;
       }

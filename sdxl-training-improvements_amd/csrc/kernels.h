@@ -17,18 +17,23 @@
 //   15 = 1: no half-height tail workgroups in the 256 x 256 kernel
 //   16 co-resident 256-row kernel for the level-2 linear weight gradients: 0 policy, 1 off, 2 / 3 = 128 / 160-column tiles wherever allowed;
 //   17 its split-K workgroup target for long reductions (0: 256); 19 = 1: also the 16 384-row level's linear weight gradients on it; 20 = 1: self-attention backward as two launches (dQ, then dK / dV); 23 = 1: lockstep loop of the co-resident 256-row kernel everywhere, = 2: its phased loop only for >= 256 tiles; 22 configuration of the GEGLU (FF2) dgrad; 21 = 1: Delta always from its own pass; 18 = 1: no padding columns on the feed-forward hidden tensors
+//   24 = 1: GroupNorm backward partial sums by the LDS-free row-lane kernel (neutral in the step: r04i_ab_gn_nolds.txt)
+//   25 LayerNorm backward knock-outs (timing only, wrong gradients): 1 no dgamma / dbeta pass, 2 no dx pass either, 3 no dx pass
+//   26 LayerNorm backward in the consumer's dgrad epilogue (GemmP::ln_x): 0 separate passes (shipped), 1 fused (dx + dgamma | dbeta partials), 2 fused dx, dy stored and the parameter pass kept
 // The product library has NO knobs: KNOB(i) is the constant 0 (= the shipped policy) and every experiment branch below it folds away.
 // The diagnostics build (`build.py --diag`: -DSDXL_DIAG -> libsdxlstep_diag.so, include/sdxlstep_diag.h) keeps the table, sdxl_set_knob,
 // the stream-K kernel (gemm_sk.hip), the stride-2 forward / weight gradient on phase planes (GemmP::up2 == 3) and the W = 32 three-tap form:
 // measured, parity-tested experiments the step does not run (DESIGN.md sections 10, 11).
-#define SDXL_NKNOBS 24
+#define SDXL_NKNOBS 27
 #ifdef SDXL_DIAG
 extern int g_knobs[SDXL_NKNOBS];
 #define KNOB(i) (g_knobs[(i)])
 constexpr bool SDXL_UP2_3 = true;
+constexpr bool SDXL_LN_EPILOGUE = true;
 #else
 #define KNOB(i) 0
 constexpr bool SDXL_UP2_3 = false;
+constexpr bool SDXL_LN_EPILOGUE = false;      // GemmP::ln_x (LayerNorm backward in the dgrad epilogue): measured, not shipped
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -108,6 +113,23 @@ struct GemmP {
   long delta_ldo;
   float* delta_out;
   int delta_nq, delta_heads;
+  // (Diagnostics build only -- SDXL_LN_EPILOGUE; the product kernel has no such path.)  NN, plain bf16 epilogue, configuration 1 (128 x 128 tiles): this dgrad's output IS the output gradient dy of a LayerNorm (y = LN(x) feeds only
+  // this linear layer).  With ln_x set the epilogue also runs that LayerNorm's backward: per-row partial sums (sum dy g, sum dy g xhat) of
+  // the workgroup's columns -> ln_part[column tile][row] as 8-byte (value, tag) granules, write-through -> every workgroup of the row block
+  // gathers the granules of all its column tiles, polling until they carry this launch's tag (ln_epoch: unique among the launches that
+  // share ln_part since it was last zeroed) -> dx = rstd (dy g - S1 / N - xhat S2 / N) + addend, bf16, to ln_dx; and -- ln_pcol set -- the
+  // block's dgamma | dbeta column partial sums to ln_pcol[row block][2][N] (folded later by ln_param_reduce_kernel).  C == nullptr: dy itself
+  // is not stored.  N = the LayerNorm width <= 1280; launches of <= 512 workgroups only (all resident at once: the meeting cannot starve).
+  const bf16* ln_x;        // the LayerNorm's input [M][N], row stride ln_ldx
+  long ln_ldx;
+  const float* ln_stats;   // [M][2] mean, rstd (forward)
+  const bf16* ln_gamma;    // [N]
+  bf16* ln_dx;             // [M][N], row stride ln_ldo
+  const bf16* ln_addend;   // or nullptr
+  long ln_ldo;
+  float* ln_part;          // gemm_ln_part_floats(M, N) floats of scratch, 16-byte aligned, zeroed before epoch 1
+  int ln_epoch;            // > 0
+  float* ln_pcol;          // or nullptr: [gridDim.y][2][N]
   int xcd_px;      // set by the launcher: XCD grid width over n-tiles (0 = identity order)
   int tail_n0;     // 256 x 256 kernel, set by its launcher: > 0 = the tile columns from tail_n0 on are computed by HALF-HEIGHT workgroups
                    // (128 x 256: waves 4-7 only stage data) so that a launch of 2.5 rounds of tiles takes ~2.6 rounds, not 3
@@ -164,6 +186,10 @@ void wgrad256_set_enabled(bool on);
 bool cr256_applicable(const GemmP& p);
 int launch_cr256(const GemmP& p, int bn, hipStream_t st, bool deep = false, bool phased = false);      // bn = 160 / 128 / 0 (pick); deep: exclusive 6-deep ring (diagnostics build)
 int cr256_wgrad_cfg(int M, int N, long red, bool bias);
+int gemm_ln_cfg(int M, int N, int K);                  // GemmP::ln_x: the configuration such a launch takes (GemmP::cfg), 0 = not possible for this shape
+size_t gemm_ln_part_floats(int M, int N);
+size_t gemm_ln_pcol_floats(int M, int N);
+int gemm_ln_rowblocks(int M);
 int cr256_pick_splitk(int M, int N, long red, int cfg);        // the plan's choice for a linear weight gradient [M][N] over `red` rows: 0 / 31 / 32 (GemmP::cfg)
 // per-launch HIP-event timing of every GEMM launch between begin and end (end synchronises the device)
 int gemm_profile_begin();

@@ -208,6 +208,62 @@ __global__ void gn_bwd_reduce_kernel(const bf16* __restrict__ x, const bf16* __r
   }
 }
 
+// The same partial sums WITHOUT LDS: the backward runs this kernel beside the side stream's weight-gradient workgroups, whose
+// exclusive forms (wgrad256, conv_wgrad3: 157 KiB) leave no room for the 15 KiB reduction buffer of the kernel above -- it waited
+// for CUs the GEMMs did not hold (57 us per launch in the step against 23 alone).  Thread = (8-channel vector, row lane) with the
+// RPI row lanes of a vector ADJACENT in the wave (RPI a power of two <= 8): a wave's load covers RPI rows x 64 / RPI vectors (whole
+// 128-byte lines at RPI = 8), the row lanes are folded by a fixed-order xor tree, lane 0 of each vector stores the chunk's partial.
+template <bool SILU, int RPI>
+__global__ void gn_bwd_reduce_nolds_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                           const bf16* __restrict__ gamma, const bf16* __restrict__ beta,
+                                           const float* __restrict__ stats, float* __restrict__ part, int HW, int C, int G,
+                                           int rows_per_chunk) {
+  const int b = blockIdx.y, B = gridDim.y;
+  const int vec = threadIdx.x / RPI, rsub = threadIdx.x % RPI;
+  const int cpg = C / G;
+  float mean[8], rstd[8], ga[8], be[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    int c = vec * 8 + e, g = c / cpg;
+    mean[e] = stats[((long)b * G + g) * 2];
+    rstd[e] = stats[((long)b * G + g) * 2 + 1];
+    ga[e] = (float)gamma[c];
+    be[e] = (float)beta[c];
+  }
+  float sa[8], sb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sa[e] = 0.f; sb[e] = 0.f; }
+  const bf16* xb = x + (long)b * HW * C + vec * 8;
+  const bf16* db = dy + (long)b * HW * C + vec * 8;
+  const int r0 = blockIdx.x * rows_per_chunk;
+  const int r1 = min(HW, r0 + rows_per_chunk);
+#pragma unroll 2
+  for (int r = r0 + rsub; r < r1; r += RPI) {
+    bf16x8 v = *(const bf16x8*)(xb + (long)r * C);
+    bf16x8 d = *(const bf16x8*)(db + (long)r * C);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float xh = ((float)v[e] - mean[e]) * rstd[e];
+      float dn = (float)d[e];
+      if (SILU) dn *= silu_grad_f(xh * ga[e] + be[e]);
+      sa[e] += dn;
+      sb[e] += dn * xh;
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < RPI; off <<= 1)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sa[e] += __shfl_xor(sa[e], off, 64);
+      sb[e] += __shfl_xor(sb[e], off, 64);
+    }
+  if (rsub == 0) {
+    float* o = part + (((long)blockIdx.x * B + b) * C + vec * 8) * 2;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) *(f32x4*)(o + 2 * e) = (f32x4){sa[e], sb[e], sa[e + 1], sb[e + 1]};
+  }
+}
+
 // One block per (group, sample): fixed-order sum of the group's channels over the chunk partials, then -- all of a group's
 // channels being here -- dgamma / dbeta, the two group sums and the per-(b, c) coefficients of dx = c1*dn + c3*x + c2.
 // (Was two launches: a chunk sum over 64-channel blocks and a per-sample finalize; 46 of each per step.)
@@ -307,14 +363,30 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const
   GnGeom g = gn_geom(HW, C);
   float* part = ws;                                      // [chunks][B][C][2]
   float* coef = ws + (size_t)GN_MAX_CHUNKS * B * C * 2;  // [B][C][3]
-  size_t sh = sizeof(float) * 2 * g.rpi * C;
-  if (silu)
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel<true>, dim3(g.chunks, B), dim3(g.threads), sh, st, x, dy, gamma, beta,
-                       stats, part, HW, C, G, g.vpr, g.rpi, g.rows_per_chunk);
-  else
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel<false>, dim3(g.chunks, B), dim3(g.threads), sh, st, x, dy, gamma, beta,
-                       stats, part, HW, C, G, g.vpr, g.rpi, g.rows_per_chunk);
-  hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(G, B), dim3(1024), 0, st, part, g.chunks, gamma, stats, coef, dgamma, dbeta, HW, C, G);
+  int red_chunks = g.chunks;
+  if (KNOB(24) == 1) {
+    // LDS-free reduce: RPI row lanes per vector (<= 512 threads), ~8 rows per thread but >= 512 blocks where the sample allows
+    const int rpi = g.vpr * 8 <= 512 ? 8 : g.vpr * 4 <= 512 ? 4 : g.vpr * 2 <= 512 ? 2 : 1;
+    int rows = 8 * rpi;
+    while (rows > rpi && (long)cdiv(HW, rows) * B < 512) rows >>= 1;
+    if (cdiv(HW, rows) > GN_MAX_CHUNKS) rows = cdiv(HW, GN_MAX_CHUNKS);
+    red_chunks = cdiv(HW, rows);
+#define GN_RED(S, R) hipLaunchKernelGGL((gn_bwd_reduce_nolds_kernel<S, R>), dim3(red_chunks, B), dim3(g.vpr * R), 0, st, x, dy, \
+                                        gamma, beta, stats, part, HW, C, G, rows)
+#define GN_RED_R(S) { if (rpi == 8) GN_RED(S, 8); else if (rpi == 4) GN_RED(S, 4); else if (rpi == 2) GN_RED(S, 2); else GN_RED(S, 1); }
+    if (silu) GN_RED_R(true) else GN_RED_R(false)
+#undef GN_RED_R
+#undef GN_RED
+  } else {
+    size_t sh = sizeof(float) * 2 * g.rpi * C;
+    if (silu)
+      hipLaunchKernelGGL(gn_bwd_reduce_kernel<true>, dim3(g.chunks, B), dim3(g.threads), sh, st, x, dy, gamma, beta,
+                         stats, part, HW, C, G, g.vpr, g.rpi, g.rows_per_chunk);
+    else
+      hipLaunchKernelGGL(gn_bwd_reduce_kernel<false>, dim3(g.chunks, B), dim3(g.threads), sh, st, x, dy, gamma, beta,
+                         stats, part, HW, C, G, g.vpr, g.rpi, g.rows_per_chunk);
+  }
+  hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(G, B), dim3(1024), 0, st, part, red_chunks, gamma, stats, coef, dgamma, dbeta, HW, C, G);
 #define GN_BWD_APPLY(S, A)                                                                                          \
   hipLaunchKernelGGL((gn_bwd_apply_kernel<S, A>), dim3(g.chunks, B), dim3(g.threads), 0, st, x, dy, gamma, beta, stats, \
                      coef, dx, addend, HW, C, G, g.vpr, g.rpi, g.rows_per_chunk)

@@ -126,6 +126,7 @@ TEST_HOOK_SIGNATURES = {
 }
 # include/sdxlstep_diag.h part 2: experiment ABI, exported by libsdxlstep_diag.so only
 DIAG_SIGNATURES = {
+    "sdxl_op_linear_dgrad_ln_bwd": [_vp, _vp, _vp, _P(_f), _vp, _vp, _vp, _vp, _P(_f), _i, _i, _i, _vp],
     "sdxl_set_knob": [_i, _i],
     "sdxl_set_sk_mode": [_i, _i],
     "sdxl_sk_error": [_vp, _P(C.c_uint)],

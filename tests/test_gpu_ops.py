@@ -651,7 +651,8 @@ def test_attention_fixed_reference_overflow_fallback(L, F, Nk):
 
 
 @pytest.mark.parametrize("B,HW,Cc,silu", [(2, 64, 64, 1), (2, 256, 320, 1), (1, 1024, 960, 1), (2, 144, 1280, 0),
-                                          (2, 64, 192, 1), (1, 64, 2560, 1)])
+                                          (2, 64, 192, 1), (1, 64, 2560, 1), (2, 4096, 640, 1), (1, 100, 320, 1),
+                                          (2, 1000, 1920, 0)])
 def test_groupnorm_fwd_bwd(L, B, HW, Cc, silu):
     G = 32
     x = (rnd(B, HW, Cc, seed=40) * 3.0 + 1.5).to(torch.bfloat16)
@@ -722,6 +723,48 @@ def test_layernorm_fwd_bwd(L, M, Cc):
     dx2 = base.clone()
     lib.check(L.sdxl_op_layernorm_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(stats), ptr(dx2), ptr(dg), ptr(db), M, Cc, 1, stream()))
     report("layernorm dx += ", dx2, xr.grad + base.float(), 1e-2)
+
+
+@pytest.mark.diag
+@pytest.mark.parametrize("M,Cc,Kr,acc,keep_dy", [(4096, 1280, 1280, 1, 0), (4096, 1280, 3840, 0, 1), (1000, 640, 256, 1, 1),
+                                                 (4032, 1280, 10240, 1, 0), (128, 128, 64, 0, 0), (300, 320, 192, 1, 1),
+                                                 (16384, 512, 128, 0, 0)])
+def test_linear_dgrad_with_layernorm_backward_epilogue(L, M, Cc, Kr, acc, keep_dy):
+    """GemmP::ln_x (diagnostics build: measured, not shipped): the dgrad dY W of the linear layer behind a LayerNorm, with that LayerNorm's backward in its epilogue (row sums met across
+    the column tiles of a row block through memory), against the two separate ops (the library's own dgrad + LayerNorm backward) and torch."""
+    x = (rnd(M, Cc, seed=60) * 2.0 + 0.5).to(torch.bfloat16)
+    gamma, beta = (rnd(Cc, seed=61) * 0.1 + 1.0).to(torch.bfloat16), rnd(Cc, seed=62)
+    xf = x.float()
+    stats = torch.stack([xf.mean(1), (xf.var(1, unbiased=False) + 1e-5).rsqrt()], 1).contiguous()      # [M][2] mean, rstd (as the forward leaves them)
+    dyl = rnd(M, Kr, seed=63)                                   # output gradient of the linear layer [M][Kr]
+    w = rnd(Kr, Cc, seed=64, scale=Kr ** -0.5)                  # its weight [out = Kr][in = Cc]
+    addend = rnd(M, Cc, seed=65) if acc else None
+    dx = torch.full((M, Cc), float("nan"), dtype=torch.bfloat16, device=dev())
+    dy_out = torch.full((M, Cc), float("nan"), dtype=torch.bfloat16, device=dev()) if keep_dy else None
+    nrb = (M + 127) // 128
+    pcol = torch.full((nrb, 2, Cc), float("nan"), dtype=torch.float32, device=dev())
+    lib.check(L.sdxl_op_linear_dgrad_ln_bwd(ptr(dyl), ptr(w), ptr(x), C.cast(stats.data_ptr(), C.POINTER(C.c_float)), ptr(gamma), ptr(addend),
+                                            ptr(dx), ptr(dy_out), C.cast(pcol.data_ptr(), C.POINTER(C.c_float)), M, Cc, Kr, stream()))
+    torch.cuda.synchronize()
+    # reference: dy = bf16(dY W), then the LayerNorm backward of it in fp32
+    dy_ref = (dyl.float() @ w.float()).to(torch.bfloat16)
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.float().requires_grad_(True), beta.float().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (Cc,), gr, br, 1e-5).backward(dy_ref.float())
+    ref_dx = xr.grad + (addend.float() if acc else 0.0)
+    if keep_dy:
+        report(f"ln-epilogue dy {M}x{Cc}x{Kr}", dy_out, dy_ref, 8e-3)
+    report(f"ln-epilogue dx {M}x{Cc}x{Kr} acc{acc}", dx, ref_dx, 1e-2)
+    report("ln-epilogue dgamma", pcol[:, 0].sum(0), gr.grad, 3e-3)
+    report("ln-epilogue dbeta", pcol[:, 1].sum(0), br.grad, 3e-3)
+    if Cc % 128:
+        return
+    # against the library's own two-kernel path on the same bf16 dy: same formula, other summation order
+    dx2 = addend.clone() if acc else torch.empty_like(x)
+    dg = torch.zeros(Cc, dtype=torch.float32, device=dev())
+    db = torch.zeros(Cc, dtype=torch.float32, device=dev())
+    lib.check(L.sdxl_op_layernorm_bwd(ptr(x), ptr(dy_ref), ptr(gamma), ptr(stats), ptr(dx2), ptr(dg), ptr(db), M, Cc, acc, stream()))
+    report("ln-epilogue dx vs the separate pass", dx, dx2, 1e-2)
 
 
 def geglu_pack_rows(t, C4, G=64):
