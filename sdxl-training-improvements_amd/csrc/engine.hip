@@ -477,11 +477,13 @@ struct GroupNormOp : Op {
     if (need > p.gn_ws_floats) p.gn_ws_floats = need;  // one scratch, sized for the widest norm, allocated in build()
   }
   int fwd(Plan& p, hipStream_t st) override {
+    if (KNOB(27) & 2) return 0;      // (knob 27: timing knock-outs, wrong results -- kernels.h)
     return launch_groupnorm_fwd(p.P(x), p.P(y), p.eng->Wp(gm), p.eng->Wp(bt), p.F(stats_off), p.F(p.gn_ws_off), Bn, HW, C, G,
                                 eps, silu, st);
   }
   void plan_bwd(Plan& p) override { dy_off = y->goff; dx = p.grad_dst(x); }
   int bwd(Plan& p, hipStream_t st, bool) override {
+    if (KNOB(27) & 1) return 0;
     return launch_groupnorm_bwd(p.P(x), p.GP(dy_off), p.eng->Wp(gm), p.eng->Wp(bt), p.F(stats_off), p.GP(dx.out),
                                 p.GP(dx.addend), p.eng->Gp(gm), p.eng->Gp(bt), p.F(p.gn_ws_off), Bn, HW, C, G, silu, st);
   }
@@ -500,6 +502,7 @@ struct LayerNormOp : Op {
     stats_off = p.alloc(sizeof(float) * x->rows * 2);
   }
   int fwd(Plan& p, hipStream_t st) override {
+    if (KNOB(27) & 4) return 0;
     return launch_layernorm_fwd(p.P(x), p.P(y), p.eng->Wp(gm), p.eng->Wp(bt), p.F(stats_off), (int)x->rows, C, eps, st);
   }
   void plan_bwd(Plan& p) override {
@@ -607,6 +610,7 @@ struct AttnOp : Op {
     }
   }
   int fwd(Plan& p, hipStream_t st) override {
+    if (KNOB(27) & (self ? 32 : 64)) return 0;
     AttnP a;
     fill(p, a, false);
     return launch_attn_fwd(a, st);
@@ -623,6 +627,7 @@ struct AttnOp : Op {
   bool delta_fused = false;     // the out-projection's dgrad writes Delta (LinearOp::delta_attn): no Delta pass in the backward
   int bwd(Plan& p, hipStream_t st, bool) override {
     if (bad) { sdxl_set_error("attention: operand gradient has another writer"); return 3; }
+    if (KNOB(27) & (self ? 16 : 8)) return 0;
     AttnP a;
     fill(p, a, true);
     a.prio = KNOB(1);
