@@ -174,6 +174,55 @@ def rccl_info(max_lines: int = 6):
     return out or None
 
 
+def clock_probe(step, steps: int = 10):
+    """Shader clock / package power while `steps` more (untimed) steps run: one rocm-smi call per ~0.3 s from a thread of this process.
+    The step runs at the package power cap on this chip (profiles/r04j_clock_under_load.txt); the sustained clock scales every peak."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                txt = subprocess.run([exe, "-d", "0", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+            except Exception:
+                return
+            m = re.search(r"sclk clock level:[^(]*\((\d+)Mhz\)", txt)
+            w = re.search(r"Power \(W\):\s*([0-9.]+)", txt)
+            if m and w:
+                samples.append((int(m.group(1)), float(w.group(1))))
+
+    th = threading.Thread(target=sampler, daemon=True)
+    try:
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        th.start()
+        t_end = time.perf_counter() + 1.5
+        n = 0
+        while n < steps or time.perf_counter() < t_end:
+            step()
+            n += 1
+            if n % 4 == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+    finally:
+        stop.set()
+        th.join(timeout=15)
+    busy = [x for x in samples if x[1] > 600.0]      # samples taken while the chip was under load
+    if not busy:
+        return None
+    sclk = sorted(x[0] for x in busy)[len(busy) // 2]
+    watts = sorted(x[1] for x in busy)[len(busy) // 2]
+    return {"sclk_mhz_under_load": sclk, "package_w_under_load": watts, "samples": len(busy), "nominal_sclk_mhz": 2400,
+            "how": "rocm-smi beside untimed steps after the timed region (median of the samples above 600 W)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,6 +243,7 @@ def main():
     ap.add_argument("--max-nchannels", type=int, default=None, help="N > 1: NCCL_MAX_NCHANNELS for RCCL (its kernels take one workgroup per channel)")
     ap.add_argument("--no-emit", action="store_true", help="N > 1 A/B: cast the fp32 gradient arena per bucket instead of bf16 wgrad epilogues")
     ap.add_argument("--profile-steps", type=int, default=1, help="extra steps with per-launch GEMM event timing")
+    ap.add_argument("--no-clock-probe", action="store_true", help="skip the rocm-smi clock / power samples after the timed region")
     ap.add_argument("--gemm-mode", type=int, default=None, help="A/B runs: sdxl_set_gemm_mode (0 = 128-row kernel only)")
     ap.add_argument("--knob", action="append", default=[], help="A/B runs: id=value for sdxl_set_knob (repeatable)")
     ap.add_argument("--lib", default=None, help="A/B runs: another build of libsdxlstep.so (e.g. last round's) on the same box")
@@ -342,6 +392,11 @@ def main():
     value = images / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
+    # what the package lets the chip clock under this workload (untimed, after the timed region): rocm-smi sampled beside a few more steps
+    clock = None
+    if world == 1 and not args.no_clock_probe:
+        clock = clock_probe(step)
+
     # dominant-kernel roofline: per-launch HIP events around every GEMM-family launch (same stream), profiled steps
     roof = None
     if args.profile_steps > 0:
@@ -449,6 +504,10 @@ def main():
                "step_tflops_per_gpu": round(step_tflops, 1),
                "step_mfma_frac": round(step_tflops / PEAK_BF16_TFLOPS, 4),
                "loss": loss, "roofline": roof, "optimizer": opt_extra}
+        if clock:
+            clock["peak_at_sclk_tflops"] = round(PEAK_BF16_TFLOPS * clock["sclk_mhz_under_load"] / clock["nominal_sclk_mhz"], 1)
+            clock["step_mfma_frac_at_sclk"] = round(step_tflops / clock["peak_at_sclk_tflops"], 4)
+            out["clock"] = clock
         if world == 1 and not args.no_cpu_baseline:
             del net, sync
             torch.cuda.empty_cache()

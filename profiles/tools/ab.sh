@@ -2,7 +2,7 @@
 # same-box A/B of knob settings: bash profiles/tools/ab.sh <rounds> "<knobs A>" "<knobs B>" ...   (each a space-separated list of id=value, "-" = none)
 R=$1; shift
 export SDXL_DIAG=1
-B="python bench.py --no-cpu-baseline --no-optimizer --profile-steps 0 --steps 15 --warmup 4"
+B="python bench.py --no-cpu-baseline --no-optimizer --no-clock-probe --profile-steps 0 --steps 15 --warmup 4"
 for i in $(seq 1 $R); do
   for k in "$@"; do
     a=""; if [ "$k" != "-" ]; then for kv in $k; do a="$a --knob $kv"; done; fi

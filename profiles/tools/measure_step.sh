@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 rm -rf $O && mkdir -p $O
-B="python $R/bench.py --no-cpu-baseline --no-optimizer --profile-steps 0"
+B="python $R/bench.py --no-cpu-baseline --no-optimizer --no-clock-probe --profile-steps 0"
 # 1. overlapped (default) and serialized kernel summaries, 4 steps each
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/k -o k -- $B --steps 3 --warmup 1 2>&1 | tail -1 | cut -c1-200
 cp $(find $O/k -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
@@ -18,7 +18,7 @@ SDXL_NO_SIDE_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O
 cp $(find $O/l -name "*kernel_stats.csv" | head -1) $O/kernel_stats_serialized.csv
 rm -rf $O/k $O/l
 # 2. per-shape GEMM table from the per-launch HIP events of bench.py's profiled step
-(cd $R && SDXL_GEMM_PROF_DUMP=$O/gemm_dump.csv python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-optimizer --profile-steps 1 > /dev/null 2>&1)
+(cd $R && SDXL_GEMM_PROF_DUMP=$O/gemm_dump.csv python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-optimizer --no-clock-probe --profile-steps 1 > /dev/null 2>&1)
 python $R/profiles/tools/agg.py $O/gemm_dump.csv 0.4 > $O/gemm_shapes.txt; rm -f $O/gemm_dump.csv
 # 3. PMC over the whole step: three separate passes
 for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do

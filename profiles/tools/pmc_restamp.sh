@@ -2,7 +2,7 @@
 export SDXL_MEASURE_COMMIT=${1:-unknown}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_restamp; rm -rf $O && mkdir -p $O
-B="python $R/bench.py --no-cpu-baseline --no-optimizer --profile-steps 0"
+B="python $R/bench.py --no-cpu-baseline --no-optimizer --no-clock-probe --profile-steps 0"
 for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   d=$(echo $c | cut -d' ' -f1)
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc/$d -o p -- $B --steps 1 --warmup 1 2>&1 | tail -1 | cut -c1-100
