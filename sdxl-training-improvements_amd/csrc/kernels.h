@@ -22,11 +22,12 @@
 //   26 LayerNorm backward in the consumer's dgrad epilogue (GemmP::ln_x): 0 separate passes (shipped), 1 fused (dx + dgamma | dbeta partials), 2 fused dx, dy stored and the parameter pass kept
 //   27 timing knock-outs by op type (bit mask, wrong results): 1 GroupNorm backward, 2 GroupNorm forward, 4 LayerNorm forward, 8 cross-attention
 //      backward, 16 self-attention backward, 32 self-attention forward, 64 cross-attention forward
+//   28 wave priority (s_setprio 0..3) of the LayerNorm backward dx kernel
 // The product library has NO knobs: KNOB(i) is the constant 0 (= the shipped policy) and every experiment branch below it folds away.
 // The diagnostics build (`build.py --diag`: -DSDXL_DIAG -> libsdxlstep_diag.so, include/sdxlstep_diag.h) keeps the table, sdxl_set_knob,
 // the stream-K kernel (gemm_sk.hip), the stride-2 forward / weight gradient on phase planes (GemmP::up2 == 3) and the W = 32 three-tap form:
 // measured, parity-tested experiments the step does not run (DESIGN.md sections 10, 11).
-#define SDXL_NKNOBS 28
+#define SDXL_NKNOBS 29
 #ifdef SDXL_DIAG
 extern int g_knobs[SDXL_NKNOBS];
 #define KNOB(i) (g_knobs[(i)])

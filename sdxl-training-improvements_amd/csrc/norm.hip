@@ -579,8 +579,9 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16* __restrict__
 template <int NV, int LPR, bool ACC>
 __global__ __launch_bounds__(256) void ln_bwd_lean_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                    const bf16* __restrict__ gamma, const float* __restrict__ stats,
-                                   bf16* dx, const bf16* addend, int M) {
+                                   bf16* dx, const bf16* addend, int M, int prio) {
   constexpr int C = NV * LPR * 8;
+  set_wave_prio(prio);
   const int sub = threadIdx.x & (LPR - 1);
   const int row = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
   const bool ok = row < M;                      // (rows beyond M: zeros; the wave stays converged for the shuffles)
@@ -728,8 +729,8 @@ int launch_layernorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const
 #define LN_LAUNCH(NV, LPR)                                                                                               \
   {                                                                                                                      \
     if (!params && KNOB(11) != 1) {                                                                                  \
-      if (accumulate) hipLaunchKernelGGL((ln_bwd_lean_kernel<NV, LPR, true>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, M);  \
-      else hipLaunchKernelGGL((ln_bwd_lean_kernel<NV, LPR, false>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, M);            \
+      if (accumulate) hipLaunchKernelGGL((ln_bwd_lean_kernel<NV, LPR, true>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, M, KNOB(28));  \
+      else hipLaunchKernelGGL((ln_bwd_lean_kernel<NV, LPR, false>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, M, KNOB(28));            \
     } else if (params) {                                                                                                        \
       if (accumulate) hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, LPR, true, true>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, part, M, iters); \
       else hipLaunchKernelGGL((ln_bwd_dx_kernel<NV, LPR, false, true>), grid, blk, 0, st, x, dy, gamma, stats, dx, addend, part, M, iters);          \
