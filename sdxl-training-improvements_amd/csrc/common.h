@@ -2,6 +2,7 @@
 // Everything here is written for wave64 / gfx950 only -- no portability layer.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>

@@ -291,7 +291,7 @@ int launch_conv_wgrad3(const GemmP& p, hipStream_t st) {
   if (p.Wm == 32) hipLaunchKernelGGL(conv_wgrad3_kernel<2>, grid, dim3(512), w3_smem(2), st, p);
   else
 #endif
-  hipLaunchKernelGGL(conv_wgrad3_kernel<1>, grid, dim3(512), w3_smem(1), st, p);
+  GEMM_LAUNCH(conv_wgrad3_kernel<1>, grid, dim3(512), w3_smem(1), st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -121,6 +121,7 @@ static int launch_wgrad_bucket(Plan& p, hipStream_t main, std::vector<GemmP>& v)
     }
   }
   v.clear();
+  if (g.splitk > 1) g.anyorder = 0;      // (a straggler that keeps its split: the shared slab orders it)
   return on_side(p, main, [&g](hipStream_t s2) -> int { return launch_gemm(g, s2); });
 }
 int Engine::defer_wgrad(Plan& p, hipStream_t main, const GemmP& g, int grp) {
@@ -262,9 +263,13 @@ struct LinearOp : Op {
       g.bias_grad = b.off != NONE ? p.eng->Gp(b) : nullptr;   // column sums of dY ride along on the matrix pipe
       if (p.eng->emit_base) { g.Cb = p.eng->emit_base + w.off; g.cb_scale = p.eng->emit_scale; }
       if (crcfg) { g.cfg = crcfg; if (wgroup <= 1) g.splitk = crsplit; }     // (a grouped launch's stragglers keep the 128-row policy's split)
+      // knob 29 (experiment): no in-stream barrier for weight gradients whose operands were written on the caller's stream (everything but the
+      // prompt-side K | V projection, whose dY the side stream's own dK / dV kernels produce) and that use no shared split-K slab
+      if (KNOB(29) == 1 && M >= 1024 && dy32_off == NONE && (g.splitk <= 1 || wgroup > 1)) g.anyorder = 1;
       const int pad = x->pad_rows < y->pad_rows ? x->pad_rows : y->pad_rows;
       if (pad > 0 && (M + pad) % 64 == 0) {     // zero rows appended to both operands: every reduction step is a full one
         g.K = M + pad;
+        g.anyorder = 0;      // (behind its memsets)
         bf16* dyp = p.GP(dy_off) + (size_t)M * N;
         bf16* xp = p.P(x) + (size_t)M * K;
         const size_t nb_dy = (size_t)pad * N * sizeof(bf16), nb_x = (size_t)pad * K * sizeof(bf16);

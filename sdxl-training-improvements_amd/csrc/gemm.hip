@@ -1135,7 +1135,7 @@ static int launch_k(const GemmP& p, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), FORM == GEMM_TN ? (p.group > 1 ? p.group : p.taps * p.splitk) : p.splitk);
-  hipLaunchKernelGGL((gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW, KSP>), grid, dim3(NW * 64), smem, st, p);
+  GEMM_LAUNCH((gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW, KSP>), grid, dim3(NW * 64), smem, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -405,7 +405,7 @@ int launch_cr(const GemmP& p, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(cdiv(p.N, BN), cdiv(p.M, CR_BM), p.group > 1 ? p.group : p.splitk);
-  hipLaunchKernelGGL((cr256_kernel<FORM, BN, BIASG, S, PH>), grid, dim3(512), G::smem(S), st, p);
+  GEMM_LAUNCH((cr256_kernel<FORM, BN, BIASG, S, PH>), grid, dim3(512), G::smem(S), st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -23,11 +23,12 @@
 //   27 timing knock-outs by op type (bit mask, wrong results): 1 GroupNorm backward, 2 GroupNorm forward, 4 LayerNorm forward, 8 cross-attention
 //      backward, 16 self-attention backward, 32 self-attention forward, 64 cross-attention forward
 //   28 wave priority (s_setprio 0..3) of the LayerNorm backward dx kernel
+//   29 = 1: weight-gradient GEMMs that use no split-K slab and whose operands come from the caller's stream are launched any-order on the side stream
 // The product library has NO knobs: KNOB(i) is the constant 0 (= the shipped policy) and every experiment branch below it folds away.
 // The diagnostics build (`build.py --diag`: -DSDXL_DIAG -> libsdxlstep_diag.so, include/sdxlstep_diag.h) keeps the table, sdxl_set_knob,
 // the stream-K kernel (gemm_sk.hip), the stride-2 forward / weight gradient on phase planes (GemmP::up2 == 3) and the W = 32 three-tap form:
 // measured, parity-tested experiments the step does not run (DESIGN.md sections 10, 11).
-#define SDXL_NKNOBS 29
+#define SDXL_NKNOBS 30
 #ifdef SDXL_DIAG
 extern int g_knobs[SDXL_NKNOBS];
 #define KNOB(i) (g_knobs[(i)])
@@ -47,6 +48,12 @@ constexpr bool SDXL_LN_EPILOGUE = false;      // GemmP::ln_x (LayerNorm backward
 //   TN: A [K][M] M-contiguous, B [K][N] N-contiguous (optionally rows gathered) -> wgrad
 // ------------------------------------------------------------------------------------------------
 enum { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
+// kernel launch of a GemmP problem: in stream order, or (GemmP::anyorder) without the barrier against the stream's earlier launches
+#define GEMM_LAUNCH(kernel, grid, block, smem, st, p)                                                          \
+  do {                                                                                                         \
+    if ((p).anyorder) hipExtLaunchKernelGGL(kernel, grid, block, smem, st, nullptr, nullptr, hipExtAnyOrderLaunch, p); \
+    else hipLaunchKernelGGL(kernel, grid, block, smem, st, p);                                                 \
+  } while (0)
 
 #define GEMM_MAX_GROUP 4
 struct GemmP {
@@ -136,6 +143,7 @@ struct GemmP {
   int xcd_px;      // set by the launcher: XCD grid width over n-tiles (0 = identity order)
   int tail_n0;     // 256 x 256 kernel, set by its launcher: > 0 = the tile columns from tail_n0 on are computed by HALF-HEIGHT workgroups
                    // (128 x 256: waves 4-7 only stage data) so that a launch of 2.5 rounds of tiles takes ~2.6 rounds, not 3
+  int anyorder;    // host side, experiment (knob 29): launch without the in-stream barrier (hipExtAnyOrderLaunch): the kernel depends on nothing the stream ran before it
   int cfg;         // > 0: this launch's configuration of the 128-row kernel (1, 2, 3, 13, 23), overriding the selection policy
   int prio;        // wave priority (s_setprio 0..3) of the whole kernel: the backward's critical-path launches (dgrad chain, caller's
                    // stream) outrank the co-resident weight-gradient workgroups of the side stream on every SIMD they share

@@ -207,7 +207,7 @@ int launch_wgrad256(const GemmP& p, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(cdiv(p.N, WL_BN), cdiv(p.M, WL_BM), p.splitk);
-  hipLaunchKernelGGL(wgrad256_kernel, grid, dim3(512), WL_SMEM, st, p);
+  GEMM_LAUNCH(wgrad256_kernel, grid, dim3(512), WL_SMEM, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
