@@ -13,12 +13,31 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
+def run_dist(args, port, env, timeout=300, tries=3):
+    """torch.distributed.run of `args` on two ranks; a rendezvous that does not come up (seen once: the run sat in its 900 s timeout while
+    the same command takes 16 s) is killed -- launcher and ranks, by process group -- and retried on another port instead of failing the suite."""
+    import signal
+    last = None
+    for k in range(tries):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port + 17 * k)] + args
+        proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out, err = proc.communicate(timeout=timeout)
+            return subprocess.CompletedProcess(cmd, proc.returncode, out, err)
+        except subprocess.TimeoutExpired as e:
+            last = e
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)      # the session this Popen started: nothing else is in it
+            except ProcessLookupError:
+                pass
+            proc.communicate()
+    raise last
+
+
 def test_two_ranks_one_device_gloo():
     env = dict(os.environ, SDXL_BENCH_BACKEND="gloo", SDXL_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-optimizer",
-           "--profile-steps", "0"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    r = run_dist([str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-optimizer", "--profile-steps", "0"], 29541, env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints exactly one JSON line
@@ -36,10 +55,8 @@ def test_two_ranks_mixed_buckets_accum4_zero1_gloo():
     """configs[4] as a bench workload: the two bucket plans alternate per micro-step, gradients are exchanged on every 4th
     micro-step only; with --exchange zero1 the timed region holds reduce-scatter AND the parameter all-gather."""
     env = dict(os.environ, SDXL_BENCH_BACKEND="gloo", SDXL_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29545", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "0", "--no-optimizer",
-           "--profile-steps", "0", "--workload", "flow_mixed_accum4", "--exchange", "zero1"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    r = run_dist([str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "0", "--no-optimizer", "--profile-steps", "0",
+                  "--workload", "flow_mixed_accum4", "--exchange", "zero1"], 29545, env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     ex = out["config"]["exchange"]
@@ -51,8 +68,6 @@ def test_zero1_update_bit_equal_to_unsharded():
     """Row f3 (ZeRO-1): reduce-scatter -> norm on the slices + 1 float -> sharded fused AdamW -> all-gather gives the SAME BITS as
     all-reduce + the full update, two ranks on one GPU over gloo (tests/_zero1_worker.py)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29543", str(ROOT / "tests" / "_zero1_worker.py")]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    r = run_dist([str(ROOT / "tests" / "_zero1_worker.py")], 29543, env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "ZERO1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
