@@ -1191,9 +1191,9 @@ static int launch_one(const GemmP& p, hipStream_t st) {
   if (p.delta_out) cfg = 1;      // the epilogue that also writes an attention layer's Delta exists on 128 x 128 tiles only (whatever is forced)
   if (p.ln_x) cfg = 1;      // the LayerNorm-backward epilogue exists on 128 x 128 tiles only (gemm_ln_cfg, launcher-checked)
   if (FORM != GEMM_TN && p.splitk > 1) cfg = n160 ? 13 : 1;     // split-K of the bf16-output forms: the 4-wave FAST configurations
-  if (p.geglu == 1 && !g80 && (cfg == 3 || cfg == 13 || cfg == 23)) cfg = 1;   // forward, group-64 packing: 128-column tiles
-  if (g80 && cfg != 3 && cfg != 13 && cfg != 23) cfg = 13;                 // group-80 packing needs 160-column tiles
-  if ((cfg == 3 || cfg == 13 || cfg == 23) && p.N % 160 != 0) cfg = 1;
+  if (p.geglu == 1 && !g80 && (cfg == 3 || cfg == 13 || cfg == 23 || cfg == 43)) cfg = 1;   // forward, group-64 packing: 128-column tiles
+  if (g80 && cfg != 3 && cfg != 13 && cfg != 23 && cfg != 43) cfg = 13;                 // group-80 packing needs 160-column tiles
+  if ((cfg == 3 || cfg == 13 || cfg == 23 || cfg == 43) && p.N % 160 != 0) cfg = 1;
   if (cfg == 23 && FORM == GEMM_TN) cfg = 13;
   if (p.geglu == 1 && cfg == 2) cfg = 1;                      // the BK = 32 configuration has no room for the GEGLU staging tile
   switch (cfg) {
@@ -1201,6 +1201,9 @@ static int launch_one(const GemmP& p, hipStream_t st) {
     case 3: return launch_cfg<FORM, CONV, 160, 4, 64, 8>(p, st);
     case 23: return launch_cfg<FORM, CONV, 160, 4, 64, 8, true>(p, st);   // split-K wave groups
     case 13: return launch_cfg<FORM, CONV, 160, 2, 64, 4>(p, st);
+#ifdef SDXL_DIAG
+    case 43: return launch_cfg<FORM, CONV, 160, 4, 64, 4>(p, st);      // the 4-deep ring with FOUR waves (64 x 80 wave tiles: 74 KB of fragment reads per K-step against 115 with eight): 73.9 vs 67.3 us on NT 4096 x 1280 x 5120, not selected
+#endif
     default: return launch_cfg<FORM, CONV, 128, 2, 64, 4>(p, st);
   }
 }
