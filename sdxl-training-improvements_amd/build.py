@@ -24,7 +24,9 @@ LIB_DIAG = HERE / "libsdxlstep_diag.so"
 DIAG_SOURCES = ["gemm_sk.hip"]
 SOURCES = ["gemm.hip", "gemm256.hip", "conv_wgrad3.hip", "wgrad256.hip", "gemm_cr256.hip", "attention.hip", "norm.hip", "elementwise.hip", "loss.hip", "optimizer.hip", "engine.hip", "capi.hip"]
 HEADERS = ["common.h", "kernels.h", "gemm_tiles.h", "engine.h", "../../include/sdxlstep.h", "../../include/sdxlstep_diag.h"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
+# -fvisibility=hidden: the dynamic symbol table holds the SDXL_API entry points of include/sdxlstep.h / sdxlstep_diag.h and nothing else
+# (no C++ internals, no __device_stub__s); tests/test_host_boundary.py checks `nm -D`
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fvisibility-inlines-hidden", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
 
 
 def _hipcc() -> str:
@@ -68,8 +70,9 @@ def build(force: bool = False, verbose: bool = True, diag: bool = False) -> Path
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(cc, jobs))
     objs = [objdir / (s + ".o") for s in sources]
-    if force or jobs or _stale(libpath, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(libpath)] + [str(o) for o in objs]
+    if force or jobs or _stale(libpath, objs + [CSRC / "exports.map"]):
+        # the version script keeps everything but sdxl_* local (kernel handle objects, libstdc++ instantiations, device-stub functions)
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", f"-Wl,--version-script={CSRC / 'exports.map'}", "-o", str(libpath)] + [str(o) for o in objs]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

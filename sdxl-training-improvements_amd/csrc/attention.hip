@@ -126,14 +126,14 @@ __device__ __forceinline__ float sum_over_g(float x) {
 // ------------------------------------------------------------------------------------------------
 #if defined(ATTN_DIAG) && (ATTN_DIAG & 256)
 __device__ unsigned long long g_attn_wg[4096 * 3];
-extern "C" int sdxl_debug_attn_wg(unsigned long long* out) {
+extern "C" __attribute__((visibility("default"))) int sdxl_debug_attn_wg(unsigned long long* out) {
   if (hipDeviceSynchronize() != hipSuccess) return 2;
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_wg), sizeof(unsigned long long) * 4096 * 3) == hipSuccess ? 0 : 2;
 }
 #endif
 #if defined(ATTN_DIAG) && (ATTN_DIAG & 128)
 __device__ unsigned long long g_attn_stamps[4 * 4 * 6];
-extern "C" int sdxl_debug_attn_stamps(unsigned long long* out) {
+extern "C" __attribute__((visibility("default"))) int sdxl_debug_attn_stamps(unsigned long long* out) {
   if (hipDeviceSynchronize() != hipSuccess) return 2;
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_stamps), sizeof(unsigned long long) * 96) == hipSuccess ? 0 : 2;
 }

@@ -914,6 +914,24 @@ int sdxl_probe_layout(void* out, void* st) { return probe_layout(out, (hipStream
 int sdxl_op_exchange_shadow(void* buf, size_t bytes, int workgroups, int lds_bytes, float busy_us, void* st) {
   return launch_exchange_shadow(buf, bytes, workgroups, lds_bytes, busy_us, (hipStream_t)st);
 }
+// test hook (include/sdxlstep_diag.h part 1): the NN dgrad with the Delta epilogue, as LinearOp::bwd launches it for a self-attention
+// layer's out-projection
+int sdxl_op_linear_dgrad_delta(const void* dy, const void* w, const void* o, const void* addend, void* d_o, float* delta, int B, int Nq,
+                               int N, int K, void* st) {
+  ARG_CHECK(dy && w && o && d_o && delta && B > 0 && Nq > 0 && N % 128 == 0 && K % 64 == 0, "linear_dgrad_delta: B=%d Nq=%d N=%d K=%d", B, Nq, N, K);
+  GemmP g;
+  gemm_defaults(&g);
+  g.form = GEMM_NN;
+  g.A = (const bf16*)dy; g.B = (const bf16*)w; g.C = d_o;
+  g.M = B * Nq; g.N = N; g.K = K;
+  g.lda = K; g.ldb = N; g.ldc = N;
+  if (addend) { g.resid = (const bf16*)addend; g.ldr = N; }
+  g.delta_o = (const bf16*)o; g.delta_ldo = N;
+  g.delta_out = delta;
+  g.delta_nq = Nq; g.delta_heads = N / 64;
+  g.cfg = 1;
+  return launch_gemm(g, (hipStream_t)st);
+}
 int sdxl_profile_gemm_begin(void) { return gemm_profile_begin(); }
 int sdxl_set_gemm_mode(int mode) {
   const int cfg = mode >> 2;
@@ -932,7 +950,11 @@ int sdxl_op_linear_dgrad_ln_bwd(const void* dy, const void* w, const void* x, co
   float* part = nullptr;
   const size_t pbytes = gemm_ln_part_floats(M, N) * sizeof(float);
   HIP_CHECK_RET(hipMalloc((void**)&part, pbytes));
-  HIP_CHECK_RET(hipMemsetAsync(part, 0, pbytes, (hipStream_t)st));
+  if (hipError_t e = hipMemsetAsync(part, 0, pbytes, (hipStream_t)st)) {      // (every exit path frees the scratch)
+    (void)hipFree(part);
+    sdxl_set_error("linear_dgrad_ln_bwd: hipMemsetAsync -> %s", hipGetErrorString(e));
+    return 2;
+  }
   GemmP g;
   gemm_defaults(&g);
   g.form = GEMM_NN;
@@ -947,8 +969,9 @@ int sdxl_op_linear_dgrad_ln_bwd(const void* dy, const void* w, const void* x, co
     g.ln_epoch = epoch;
     rc = launch_gemm(g, (hipStream_t)st);
   }
-  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)st));
+  const hipError_t se = hipStreamSynchronize((hipStream_t)st);
   (void)hipFree(part);
+  if (se != hipSuccess) { sdxl_set_error("linear_dgrad_ln_bwd: hipStreamSynchronize -> %s", hipGetErrorString(se)); return 2; }
   return rc;
 }
 // Knobs are process-global and read at plan-build, forward and backward time: set them BEFORE sdxl_plan / the first step of a handle and

@@ -179,6 +179,7 @@ static int kv_pad_rows(int B, int ctx) { return (int)((64 - ((long)B * ctx) % 64
 struct AttnOp;
 static void attn_delta_target(AttnOp* a, Plan& p, GemmP& g);      // (defined behind AttnOp)
 static bool attn_delta_wanted(const AttnOp* a);
+static void attn_set_delta_fused(AttnOp* a, bool on);
 struct LayerNormOp;
 static bool ln_fuse_plan(LayerNormOp* ln, Plan& p, int mode);      // (defined behind LayerNormOp)
 static void ln_fuse_target(LayerNormOp* ln, Plan& p, GemmP& g, int mode);
@@ -188,6 +189,7 @@ struct LinearOp : Op {
   int K, N;
   int resid_alias = 0, splitk = 1, wgroup = 1;
   struct AttnOp* delta_attn = nullptr;      // x is the output of this self-attention layer: the dgrad's epilogue also writes its Delta (GemmP::delta_out)
+  bool delta_on = false;                    // ... decided in plan_bwd (the same predicate tells the attention backward that Delta is ready)
   // x is the output of this LayerNorm and feeds nothing else: the dgrad's epilogue runs the LayerNorm's backward (GemmP::ln_x) -- dx of the
   // LayerNorm straight from the accumulators (the knock-out of the separate dx pass: -4.6 ms per step), its dgamma | dbeta partial sums too.
   // ln_mode (plan_bwd): 0 not fused (the shipped plan; shape / split-K), 1 fused (knob 26 = 1, diagnostics build), 2 fused but dy is still
@@ -233,11 +235,19 @@ struct LinearOp : Op {
     crcfg = cr256_wgrad_cfg(N, K, x->rows, b.off != NONE);
     if (crcfg) { crsplit = cr256_pick_splitk(N, K, x->rows, crcfg); want_slab(p, N, K, 1, crsplit); }
     if (!gact) { fsplit = gemm_pick_splitk_small((int)x->rows, N, K, 3); want_slab_main(p, (int)x->rows, N, fsplit); }
+    if (delta_attn && !(!gu && x->need_grad)) attn_set_delta_fused(delta_attn, false);      // no dgrad launch: nobody would write Delta
     if (!gu && x->need_grad) {
       dsplit = gemm_pick_splitk_small((int)x->rows, K, N, 2);
       // knob 3 (experiment): split the reduction of the long-K dgrads (N >= knob 4) s ways although their tiles fill half the chip
       if (KNOB(3) > 1 && N >= (KNOB(4) > 0 ? KNOB(4) : 8192) && N % (64 * KNOB(3)) == 0 && dsplit == 1) dsplit = KNOB(3);
       want_slab_main(p, (int)x->rows, K, dsplit);
+      // the Delta epilogue is decided HERE, once, for both sides: this dgrad attaches it iff the attention backward (planned after this
+      // op: the plan walks the ops in reverse) is told that Delta is ready.  A split reduction (small batches: dsplit > 1) goes through the
+      // slab epilogue, which has no Delta path -- the attention backward then runs its own Delta pass.
+      if (delta_attn) {
+        delta_on = attn_delta_wanted(delta_attn) && dsplit <= 1 && K % 128 == 0;
+        attn_set_delta_fused(delta_attn, delta_on);
+      }
       if (SDXL_LN_EPILOGUE && ln_src && KNOB(26) != 0 && dsplit == 1 && dx.addend == NONE && !x->parent && gemm_ln_cfg((int)x->rows, K, N) &&
           ln_fuse_plan(ln_src, p, KNOB(26) == 2 ? 2 : 1))
         ln_mode = KNOB(26) == 2 ? 2 : 1;
@@ -296,7 +306,7 @@ struct LinearOp : Op {
       if (KNOB(6) > 0 && !gu && (KNOB(8) <= 0 || N >= KNOB(8))) g.cfg = KNOB(6);     // experiment: configuration of the linear dgrads
       if (KNOB(22) > 0 && gu) g.cfg = KNOB(22);     // experiment: configuration of the GEGLU (FF2) dgrad
       // (last: the epilogue that writes Delta exists on the 128 x 128 tiles of the 4-wave kernel only)
-      if (delta_attn && attn_delta_wanted(delta_attn) && dsplit <= 1 && K % 128 == 0) { attn_delta_target(delta_attn, p, g); g.cfg = 1; }
+      if (delta_on) { attn_delta_target(delta_attn, p, g); g.cfg = 1; }
       if (ln_mode) { ln_fuse_target(ln_src, p, g, ln_mode); g.cfg = 0; g.resid = nullptr; }
       CHK(launch_gemm(g, st));
     }
@@ -649,6 +659,7 @@ struct AttnOp : Op {
 // level-2 self-attention (1280 channels at M = 4096: the out-projection's dgrad runs on 128 x 128 tiles, whose 64 x 64 wave tiles are whole
 // heads): Delta from that GEMM's epilogue instead of a pass of its own (60 launches per step).  knob 21 = 1: off (A/B runs)
 static bool attn_delta_wanted(const AttnOp* a) { return a->self && a->qsplit <= 1 && a->Nk >= 256 && a->C % 128 == 0 && a->delta_fused; }
+static void attn_set_delta_fused(AttnOp* a, bool on) { a->delta_fused = on; }
 static void attn_delta_target(AttnOp* a, Plan& p, GemmP& g) {
   g.delta_o = p.P(a->o); g.delta_ldo = a->C;
   g.delta_out = p.F(a->delta_off);

@@ -1422,6 +1422,9 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
     ARG_CHECK(!p.Cb, "gemm: the bf16 gradient destination is a TN (wgrad) option");
   }
   if (p.splitk < 1) p.splitk = 1;
+  if (p.delta_out)      // a launch that is to write Delta must reach the 128 x 128 4-wave NN kernel's register epilogue: no slab path, no GEGLU
+    ARG_CHECK(p.form == GEMM_NN && p.splitk == 1 && p.taps == 1 && !p.geglu && p.delta_o && p.delta_nq > 0 && p.delta_heads > 0 && p.delta_ldo % 8 == 0,
+              "gemm: the Delta epilogue takes a plain, unsplit NN problem (form %d, splitk %d)", p.form, p.splitk);
   if (p.group > 1) {
     ARG_CHECK(p.form == GEMM_TN && p.taps == 1 && p.splitk == 1 && p.group <= GEMM_MAX_GROUP,
               "gemm: grouped launches are TN, one tap, no split-K, at most %d problems", GEMM_MAX_GROUP);
@@ -1480,14 +1483,14 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
     }
   }
 #ifdef SDXL_DIAG
-  if (g_sk_mode && !(p.form != GEMM_TN && p.splitk > 1) && (g_sk_mode == 2 ? gemm_sk_applicable(p) : gemm_use_sk(p))) {
+  if (g_sk_mode && !p.delta_out && !(p.form != GEMM_TN && p.splitk > 1) && (g_sk_mode == 2 ? gemm_sk_applicable(p) : gemm_use_sk(p))) {
     GemmP q = p;
     q.splitk = 1;
     return launch_gemm_sk(&q, 1, st);      // persistent stream-K kernel (gemm_sk.hip)
   }
 #endif
   {   // 256 x 256 kernel (gemm256.hip)
-    if (g_mode256 && p.group <= 1 && !p.Cb && !(p.form != GEMM_TN && p.splitk > 1) && gemm256_applicable(p)) {
+    if (g_mode256 && p.group <= 1 && !p.Cb && !p.delta_out && !(p.form != GEMM_TN && p.splitk > 1) && gemm256_applicable(p)) {      // (the Delta epilogue exists in the 128 x 128 4-wave kernel only)
       // the forward GEGLU projection packed in groups of 64: the 256 x 256 kernel's register epilogue (value and gate of a channel
       // in one lane) against the 128-row kernel's LDS-staged one -- 131 vs 156 us at 4096 x 10240 x 1280 although its 640 tiles
       // fill only 2.5 rounds (profiles/r03_notes)

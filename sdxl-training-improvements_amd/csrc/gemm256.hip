@@ -436,7 +436,7 @@ bool gemm256_applicable(const GemmP& p) {
 }
 
 #if G256_DIAG & 16
-extern "C" int sdxl_debug_g256_stamps(unsigned long long* out) {   // diagnostics build only
+extern "C" __attribute__((visibility("default"))) int sdxl_debug_g256_stamps(unsigned long long* out) {   // diagnostics build only
   HIP_CHECK_RET(hipDeviceSynchronize());
   HIP_CHECK_RET(hipMemcpyFromSymbol(out, HIP_SYMBOL(g256_stamps), sizeof(unsigned long long) * 2 * 4 * 4 * 8));
   return 0;

@@ -319,16 +319,22 @@ class NativeSDXLTrainer:
                             print({k: (round(v, 6) if isinstance(v, float) else v) for k, v in eff.items()}, flush=True)
                     acc_loss, acc_metrics = 0.0, defaultdict(float)
                 global_step += 1
-            if save_checkpoints and ep_n:
-                # the decision must be the same on every rank (each sees its own data): the epoch's mean loss averaged over ranks.
+            if save_checkpoints:
+                # the decision must be the same on every rank (each sees its own data): the epoch's loss sum and step count, both summed
+                # over ranks -- EVERY rank enters the reduction, also one whose shard produced no step this epoch (an uneven loader
+                # shard; a guard on the local count would leave the others waiting in the collective).
                 # prepare_checkpoint() is the collective part (every rank), save_checkpoint() itself has none (rank 0 writes).
-                mean = D.reduce_dict({"loss": ep_loss / ep_n})["loss"]
+                tot = D.reduce_dict({"loss_sum": ep_loss, "n": float(ep_n)}, average=False)
+                mean = tot["loss_sum"] / tot["n"] if tot["n"] > 0 else float("inf")
                 if mean < best:
                     best = mean
                     self.prepare_checkpoint()
                     self.save_checkpoint(epoch + 1, is_final=False)
+        # Every rank leaves train() with the COMPLETE optimizer state in place: the reference's main.py:110-111 calls
+        # save_checkpoint(path) on rank 0 only right after train() returns -- under ZeRO-1 that save would otherwise write rank 0's
+        # slices of the moments (`zero1_partial`, which load_optimizer_state refuses).  One all-gather of three arenas per train() call.
+        self.prepare_checkpoint()
         if save_checkpoints:
-            self.prepare_checkpoint()
             self.save_checkpoint(num_epochs, is_final=True)
 
     # -------------------------------------------------------------------------------- weights out (row f4)
@@ -407,6 +413,15 @@ class NativeSDXLTrainer:
         """resume: optimizer.pt written by save_checkpoint (the UNet weights come back through the model object).  The state
         holds tensors, numbers and dicts only, so the safe loader is enough."""
         sd = torch.load(str(Path(checkpoint_dir) / "optimizer.pt"), map_location="cpu", weights_only=True)
+        part = sd.pop("zero1_partial", None) if isinstance(sd, dict) else None
+        if part is not None:
+            # written under ZeRO-1 without prepare_checkpoint() on every rank (the drop-in path: the reference's loop calls
+            # save_checkpoint on rank 0 only): the moments of the other ranks' slices in it are stale.  Resuming from it would be
+            # silently wrong on (world - 1) / world of the arena -- refuse.
+            raise ValueError(
+                f"optimizer.pt is a ZeRO-1 partial state (rank {part.get('rank')} of {part.get('world')}: only that rank's slices of "
+                "exp_avg / exp_avg_sq / shift are current). Call prepare_checkpoint() on every rank before save_checkpoint(), or train "
+                "with training.shard_optimizer = false when the caller's loop saves on rank 0 only (INTEGRATION.md section 3)")
         self.optimizer.load_state_dict(sd)
 
 

@@ -278,8 +278,22 @@ def _worker_checkpoint(rank, world, port, q, tmp):
             d = orig(7, False)
         sd = torch.load(str(d / "optimizer.pt"), weights_only=True)
         ok = ok and sd.get("zero1_partial", {}).get("world") == world and len(wl) == 1
+        # ... and a resume refuses it (the other ranks' slices of the moments in it are stale) instead of loading it silently
+        try:
+            tr.load_optimizer_state(d)
+            ok = False
+        except ValueError as e:
+            ok = ok and "zero1_partial" not in str(e) and "partial" in str(e)
     else:
         ok = ok and orig(7, False) is None
+    dist.barrier()
+    # an epoch without a single step: every rank still enters the save decision's reduction (the guard is on the GLOBAL count, so no
+    # rank can skip the collective on its own), nothing improves on `best`, the final checkpoint is still written
+    tr.train_dataloader = []
+    saved.clear()
+    tr.save_checkpoint = lambda e=0, is_final=False: (saved.append((e, is_final)), None)[1]
+    tr.train(1, save_checkpoints=True)
+    ok = ok and saved == [(1, True)]
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

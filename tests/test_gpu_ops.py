@@ -612,6 +612,37 @@ def test_attention_fwd_bwd(L, B, heads, Nq, Nk, self_attn):
     report("attn dV", dv, vr.grad, 1.5e-2)
 
 
+@pytest.mark.parametrize("B,Nq,N,K,addend", [(1, 1024, 1280, 1280, True), (4, 1024, 1280, 1280, False), (1, 1000, 1280, 1280, True),
+                                             (2, 200, 256, 128, False), (3, 70, 128, 64, True)])
+def test_linear_dgrad_delta_epilogue(L, B, Nq, N, K, addend):
+    """GemmP::delta_out (csrc/gemm.hip epilogue of the 128 x 128 4-wave NN kernel; the plan uses it for the out-projection dgrad of the
+    1280-channel self-attention layers, engine.hip LinearOp::plan_bwd): dO = dY W (+ addend) AND Delta = rowsum_head(bf16(dO) * O).
+    Against fp32 torch, and against the stand-alone Delta pass (attn_delta_kernel, reached through sdxl_op_attention_bwd with the SAME
+    dO and O): the fused form sums 64 products per row in a different order, nothing else.  Ragged M (1000, 400, 210 rows: partial last
+    128-row tile) included; the tolerance on Delta is 2e-3 of max|Delta| -- fp32 sums of 64 bf16 x bf16 products in two orders."""
+    M, heads = B * Nq, N // 64
+    dy, w, o = rnd(M, K, seed=50), rnd(K, N, seed=51, scale=0.05), rnd(M, N, seed=52)
+    add = rnd(M, N, seed=53) if addend else None
+    d_o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+    delta = torch.full((B * heads, Nq), float("nan"), dtype=torch.float32, device=dev())
+    lib.check(L.sdxl_op_linear_dgrad_delta(ptr(dy), ptr(w), ptr(o), ptr(add), ptr(d_o), ptr(delta), B, Nq, N, K, stream()))
+    ref = dy.float() @ w.float() + (add.float() if addend else 0.0)
+    report(f"dgrad+delta dO {M}x{N}x{K}", d_o, ref, 6e-3)
+    # Delta from the bf16 dO the kernel itself stored (that is what the attention backward reads), fp32
+    dref = (d_o.float() * o.float()).view(B, Nq, heads, 64).sum(-1).permute(0, 2, 1).reshape(B * heads, Nq)
+    assert torch.isfinite(delta).all()
+    report("dgrad+delta Delta vs fp32 rowsum", delta, dref, 2e-3)
+    # ... and against the stand-alone pass: attention backward computes Delta itself when it is not told that Delta is ready
+    qkv = rnd(B, Nq, 3 * N, seed=54)
+    q, k, v = qkv[..., :N], qkv[..., N:2 * N], qkv[..., 2 * N:]
+    lse = torch.zeros(B * heads, Nq, dtype=torch.float32, device=dev())
+    delta2 = torch.full_like(delta, float("nan"))
+    dqkv = torch.zeros_like(qkv)
+    lib.check(L.sdxl_op_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(d_o), ptr(lse), ptr(delta2), ptr(dqkv[..., :N]), ptr(dqkv[..., N:2 * N]),
+                                      ptr(dqkv[..., 2 * N:]), B, heads, Nq, Nq, 3 * N, 3 * N, 3 * N, N, stream()))
+    report("dgrad+delta Delta vs attn_delta_kernel", delta, delta2, 2e-3)
+
+
 def test_attention_rescale_branch(L):
     """A late, very large score forces the running max to jump at the last key tile (guide rule 26)."""
     B, heads, Nq, Nk, Cc = 1, 1, 128, 256, 64

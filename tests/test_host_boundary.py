@@ -31,6 +31,15 @@ def test_header_symbols_all_exported_and_bound():
     assert hooks == set(lib.TEST_HOOK_SIGNATURES) and experiments == set(lib.DIAG_SIGNATURES)
     for name in sorted(experiments):
         assert hasattr(L, name) == lib.DIAG, f"{name}: experiment ABI {'missing from the diagnostics' if lib.DIAG else 'present in the PRODUCT'} library"
+    # ... and the library's ACTUAL dynamic surface is that list and nothing else: built with -fvisibility=hidden + a version script
+    # (csrc/exports.map), so no C++ internals (launch_gemm, Engine::build, ...), kernel handles or __device_stub__s leak out
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", str(lib.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    want = declared | hooks | (experiments if lib.DIAG else set())
+    assert exported == want, f"unexpected dynamic symbols: {sorted(exported - want)[:10]}; missing: {sorted(want - exported)[:10]}"
 
 
 def test_fails_loudly_without_gpu():
