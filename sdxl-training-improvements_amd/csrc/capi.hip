@@ -935,7 +935,7 @@ int sdxl_op_linear_dgrad_delta(const void* dy, const void* w, const void* o, con
 int sdxl_profile_gemm_begin(void) { return gemm_profile_begin(); }
 int sdxl_set_gemm_mode(int mode) {
   const int cfg = mode >> 2;
-  ARG_CHECK(mode >= 0 && (mode & 3) <= 2 && (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 3 || cfg == 13 || cfg == 23 || cfg == 43 || cfg == 31 || cfg == 32 || cfg == 33 || cfg == 34 || cfg == 35 || cfg == 36), "gemm mode %d", mode);
+  ARG_CHECK(mode >= 0 && (mode & 3) <= 2 && (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 3 || cfg == 5 || cfg == 6 || cfg == 7 || cfg == 13 || cfg == 23 || cfg == 43 || cfg == 31 || cfg == 32 || cfg == 33 || cfg == 34 || cfg == 35 || cfg == 36), "gemm mode %d", mode);
   gemm_set_mode(mode);
   return 0;
 }

@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
 #include <vector>
 
 #define BM 128
@@ -71,8 +72,16 @@ static constexpr int gemm_occupancy(int BN, int S, int BK, int NW) {
 //        waits -- the matrix pipe and the LDS path alternate by construction (the 4 x 2 layout of the same tile has all
 //        eight waves read, wait and multiply in lockstep: 0.73 us per K-step of a 128x160 tile against 0.3 at the MFMA
 //        rate).  The two partial accumulator tiles are exchanged through LDS once, after the main loop.
-template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW, bool KSP = false>
-__global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_kernel(const GemmP pin) {
+// PL   : four waves, ONE per SIMD, software-pipelined (configurations 5 / 6): the fragments of the NEXT 32-deep half-step are read
+//        (and the DMA pieces of step t + S - 1 issued) between the MFMA groups of the current one, into a second register set -- the
+//        matrix pipe, the LDS read path and the staging stream run side by side inside ONE wave instead of taking turns between two
+//        waves of a SIMD (configuration 3: 0.75 us per K-step for 0.30 of products, 0.43 of staging and 0.3 of fragment reads).
+//        64 x (BN/2) wave tiles: 72 KB of fragment reads per K-step instead of 112 with eight waves; one barrier per K-step, in the
+//        middle of it; the workgroup owns its CU (S x 36 KiB of LDS, up to 512 registers per lane).
+template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW, bool KSP = false, bool PL = false>
+// (PL: the register budget of TWO waves per SIMD, 256 -- with the 512 of one wave hipcc picks the AGPR form of the MFMAs and then moves all 80
+//  accumulators between the two halves of the file every K-step; the loop needs ~210)
+__global__ __launch_bounds__(NW * 64, PL ? 2 : gemm_occupancy(BN, S, BK, NW)) void gemm_kernel(const GemmP pin) {
   GemmP p = pin;
   set_wave_prio(pin.prio);
   if (FORM == GEMM_TN && pin.group > 1) {          // grouped launch: this workgroup's problem
@@ -80,6 +89,7 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
     p.A = pin.gA[gi]; p.B = pin.gB[gi]; p.C = pin.gC[gi]; p.bias_grad = pin.gbias_grad[gi]; p.Cb = pin.gCb[gi];
   }
   static_assert(!KSP || (NW == 8 && BK == 64 && FAST && S >= 3 && FORM != GEMM_TN), "split-K groups: 8 waves, BK 64, FAST staging, ring >= 3");
+  static_assert(!PL || (NW == 4 && BK == 64 && FAST && S >= 3 && FORM != GEMM_TN && !KSP), "pipelined loop: 4 waves, BK 64, FAST staging, ring >= 3, NT / NN");
   constexpr int BMT = BM;
   constexpr int A_TILE_BYTES = BMT * BK * 2;      // [BMT][BK] or [BK][128] bf16
   constexpr int B_TILE_BYTES = BN * BK * 2;       // [BN][BK] or [BK][BN] bf16
@@ -365,7 +375,8 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
           src = live ? pa[j] : zsrc;
         }
         char* dst = (NCA % NW == 0 || c < NCA) ? At + c * 1024 : pad_dst;
-        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
+        if (PL) lds_dma16_global(src, lds_addr_of(dst));      // (from asm: the builtin makes hipcc drain the ring before LDS reads that follow it)
+        else __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
         if (!CF) pa[j] += sa[j];
       }
 #pragma unroll
@@ -384,7 +395,8 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
           src = live ? pb[j] : zsrc;
         }
         char* dst = (NCB % NW == 0 || c < NCB) ? Bt + c * 1024 : pad_dst;
-        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
+        if (PL) lds_dma16_global(src, lds_addr_of(dst));
+        else __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
         if (!CF) pb[j] += sb[j];
       }
   };
@@ -554,6 +566,75 @@ __global__ __launch_bounds__(NW * 64, gemm_occupancy(BN, S, BK, NW)) void gemm_k
     }
     if (!FAST) __builtin_amdgcn_s_setprio(0);
   };
+  if constexpr (PL) {
+    // Software-pipelined loop, one wave per SIMD.  Register sets f0 / f1 hold the fragments of the two 32-deep halves of a K-step.
+    //   phase 0 of step t:  products of (t, half 0) from f0  |  reads of (t, half 1) -> f1        |  first DMA pieces of step t + S - 1
+    //   -- counted vmcnt (my pieces of step t + 1 have landed), lgkmcnt(0), ONE barrier --
+    //   phase 1 of step t:  products of (t, half 1) from f1  |  reads of (t + 1, half 0) -> f0    |  the other DMA pieces
+    // Hazards.  RAW: step t + 1 is first read in phase 1 of step t, behind the barrier that every wave enters after the counted wait
+    // that retires its own pieces of that step (pieces land in issue order; outstanding at the wait, oldest first: step t + 1, the
+    // steps t + 2 .. t + S - 2, the NP0 pieces issued in phase 0).  WAR: the pieces of step t + S - 1 go to the ring slot of step
+    // t - 1, whose last reads (half 1, phase 0 of step t - 1) were retired by that wave's lgkmcnt(0) before the barrier of step t - 1,
+    // which every wave has left before any wave reaches step t.
+    constexpr int NG = MI;                      // MFMA groups per phase (one fragment row of A each)
+    constexpr int NITEM = MI + NJ;              // fragment reads per half-step: B first (every product of a phase's first group needs them), then A
+    constexpr int RG = 3;                       // groups that carry reads (the last group of a phase carries none: its reads would be waited for at once)
+    auto np0 = []() constexpr { int n = 0; for (int pc = 0; pc < NL; ++pc) if (pc % (2 * NG) < NG) ++n; return n; };      // pieces issued in phase 0
+    auto read_item = [&](int slot, int ks, FragK& f, int it) {
+      const char* At = smem + slot * STAGE_BYTES;
+      const char* Bt = At + A_TILE_BYTES;
+      if (dbg & 4) { if (it < NJ) f.b[it] = ones; else f.a[it - NJ] = ones; return; }
+      if (it < NJ) {
+        const int j = it;
+        if (FORM == GEMM_NT) f.b[j] = frag_kc<BK>(Bt, wn * (BN / 2) + j * 16 + l16, ks * 4 + g);
+        else f.b[j] = frag_nc<BN>(Bt, ks * 32 + g * 8, wn * (BN / 2) + j * 16, l16);
+      } else {
+        const int i = it - NJ;
+        f.a[i] = frag_kc<BK>(At, wm * (MI * 16) + i * 16 + l16, ks * 4 + g);
+      }
+    };
+    // one phase: PH = 0 / 1; fc = the fragments multiplied, fn = the set being filled from (rslot, rks)
+    // (the reads of the step after the last one are not skipped: their slot holds zero-fill pieces that the same counted wait retires)
+    auto phase = [&](auto PHC, const FragK& fc, FragK& fn, int rslot, int rks, int wslot, bool live) {
+      constexpr int PH = decltype(PHC)::value;
+#pragma unroll
+      for (int gi = 0; gi < NG; ++gi) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (dbg & 1) acc[gi][j][0] += (float)fc.a[gi][0] + (float)fc.b[j][0];
+          else acc[gi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc.b[j], fc.a[gi], acc[gi][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (gi < RG) {
+#pragma unroll
+          for (int it = 0; it < NITEM; ++it)
+            if (it * RG / NITEM == gi) read_item(rslot, rks, fn, it);
+        }
+#pragma unroll
+        for (int pc = 0; pc < NL; ++pc)
+          if (pc % (2 * NG) == PH * NG + gi) issue_piece(pc, wslot, live);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    FragK f0, f1;
+    wait_vmcnt<(S - 2) * NL>();                       // step 0 landed (mine)
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int it = 0; it < NITEM; ++it) read_item(rd, 0, f0, it);
+    for (int t = 0; t < T; ++t) {
+      const bool live = t + S - 1 < T;
+      phase(std::integral_constant<int, 0>{}, f0, f1, rd, 1, wr, live);
+      wait_vmcnt<(S - 3) * NL + np0()>();             // my pieces of step t + 1 have landed
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      const int rn = rd + 1 == S ? 0 : rd + 1;
+      phase(std::integral_constant<int, 1>{}, f1, f0, rn, 0, wr, live);
+      advance();
+      rd = rn;
+      wr = wr + 1 == S ? 0 : wr + 1;
+    }
+  } else
   if (KSP) {
     // Global barrier sequence b_0, b_1, ...; group 0 reads its half of step t in the interval before b_2t and multiplies it
     // between b_2t and b_2t+1, group 1 one interval later.  DMA of step t+S-1 rides in the MFMA section of step t (after
@@ -1125,28 +1206,36 @@ void gemm_defaults(GemmP* p) {
   p->rows_per_batch = 1;
 }
 
-template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW, bool KSP = false>
+template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW, bool KSP = false, bool PL = false>
 static int launch_k(const GemmP& p, hipStream_t st) {
   static bool attr_set = false;
   constexpr int smem = gemm_smem_bytes(BN, S, BK, NW);
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW, KSP>,
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW, KSP, PL>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
   dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), FORM == GEMM_TN ? (p.group > 1 ? p.group : p.taps * p.splitk) : p.splitk);
-  GEMM_LAUNCH((gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW, KSP>), grid, dim3(NW * 64), smem, st, p);
+  GEMM_LAUNCH((gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW, KSP, PL>), grid, dim3(NW * 64), smem, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-template <int FORM, bool CONV, int BN, int S, int BK, int NW, bool KSP = false>
+// the FAST staging forms only (reduction a multiple of BK; linear, or the same-size stride-1 3x3 gather): can this problem take them?
+static bool gemm_fast_ok(const GemmP& p, bool conv, int BK) {
+  if (p.K % BK) return false;
+  if (!conv) return true;
+  return (p.taps == 9 || p.up2) && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws;
+}
+template <int FORM, bool CONV, int BN, int S, int BK, int NW, bool KSP = false, bool PL = false>
 static int launch_cfg(const GemmP& p, hipStream_t st) {
   constexpr bool KS_OK = KSP && FORM != GEMM_TN;     // (the split-K groups exist for the FAST staging of the NT / NN forms)
-  if (!CONV && p.K % BK == 0) return launch_k<FORM, false, BN, S, BK, true, NW, KS_OK>(p, st);
+  constexpr bool PL_OK = PL && FORM != GEMM_TN;      // (the pipelined loop likewise; launch_one routes only FAST problems to it)
+  if (!CONV && p.K % BK == 0) return launch_k<FORM, false, BN, S, BK, true, NW, KS_OK, PL_OK>(p, st);
   // same-size stride-1 3x3 convolutions (all but the two downsamplers, their transposed dgrads and conv_in)
   if (CONV && (p.taps == 9 || p.up2) && p.sm == 1 && p.sd == 1 && p.Hm == p.Hs && p.Wm == p.Ws && p.K % BK == 0)
-    return launch_k<FORM, true, BN, S, BK, true, NW, KS_OK>(p, st);
-  return launch_k<FORM, CONV, BN, S, BK, false, NW>(p, st);
+    return launch_k<FORM, true, BN, S, BK, true, NW, KS_OK, PL_OK>(p, st);
+  if constexpr (PL) { ARG_CHECK(false, "gemm: the pipelined configurations take FAST-staging problems only"); }
+  else return launch_k<FORM, CONV, BN, S, BK, false, NW>(p, st);
 }
 
 // Tile / pipeline selection of the 128-row kernel.  Four configurations:
@@ -1186,13 +1275,28 @@ static int launch_one(const GemmP& p, hipStream_t st) {
   // (forward only: in the backward a 145 KiB workgroup evicts the other stream from its CU -- dgrads on it: GEMM family
   //  -2 ms, step +2.4 ms, profiles/r02c)
   if (FORM == GEMM_NT && n160 && t160 <= 256 && (long)p.K * p.taps >= 2560) cfg = 23;
+  // the pipelined one-wave-per-SIMD loop on the same tiles (configuration 5; 6 = 128-column tiles): knob 30 (kernels.h) selects where
+  {
+    const int k30 = KNOB(30);
+    const bool one_round = (n160 ? t160 : blocks) <= 256 && (n160 ? t160 : blocks) > 128;
+    const bool fastp = FORM != GEMM_TN && gemm_fast_ok(p, CONV, 64) && p.splitk <= 1;
+    if (fastp && one_round) {
+      const bool fwd_conv = FORM == GEMM_NT && CONV, dg_conv = FORM == GEMM_NN && CONV;      // (linear problems: gemm_pl.hip, launch_gemm_impl)
+      if ((fwd_conv && (k30 & 4)) || (dg_conv && (k30 & 8))) cfg = n160 ? 5 : 6;
+    }
+  }
   if (p.cfg > 0) cfg = p.cfg;
   if (g_force_cfg > 0) cfg = g_force_cfg;
   if (p.delta_out) cfg = 1;      // the epilogue that also writes an attention layer's Delta exists on 128 x 128 tiles only (whatever is forced)
   if (p.ln_x) cfg = 1;      // the LayerNorm-backward epilogue exists on 128 x 128 tiles only (gemm_ln_cfg, launcher-checked)
   if (FORM != GEMM_TN && p.splitk > 1) cfg = n160 ? 13 : 1;     // split-K of the bf16-output forms: the 4-wave FAST configurations
   if (p.geglu == 1 && !g80 && (cfg == 3 || cfg == 13 || cfg == 23 || cfg == 43)) cfg = 1;   // forward, group-64 packing: 128-column tiles
-  if (g80 && cfg != 3 && cfg != 13 && cfg != 23 && cfg != 43) cfg = 13;                 // group-80 packing needs 160-column tiles
+  if (g80 && cfg != 3 && cfg != 5 && cfg != 13 && cfg != 23 && cfg != 43) cfg = 13;                 // group-80 packing needs 160-column tiles
+  // 5 / 6: the pipelined one-wave-per-SIMD loop on 128 x 160 / 128 x 128 tiles (4-deep ring, the workgroup owns its CU): NT / NN problems with
+  // FAST staging only
+  if (cfg == 5 && !n160) cfg = 6;
+  if (cfg == 6 && g80) cfg = 5;
+  if ((cfg == 5 || cfg == 6) && (FORM == GEMM_TN || !gemm_fast_ok(p, CONV, 64))) cfg = cfg == 5 ? 13 : 1;
   if ((cfg == 3 || cfg == 13 || cfg == 23 || cfg == 43) && p.N % 160 != 0) cfg = 1;
   if (cfg == 23 && FORM == GEMM_TN) cfg = 13;
   if (p.geglu == 1 && cfg == 2) cfg = 1;                      // the BK = 32 configuration has no room for the GEGLU staging tile
@@ -1201,6 +1305,8 @@ static int launch_one(const GemmP& p, hipStream_t st) {
     case 3: return launch_cfg<FORM, CONV, 160, 4, 64, 8>(p, st);
     case 23: return launch_cfg<FORM, CONV, 160, 4, 64, 8, true>(p, st);   // split-K wave groups
     case 13: return launch_cfg<FORM, CONV, 160, 2, 64, 4>(p, st);
+    case 5: return launch_cfg<FORM, CONV, 160, 4, 64, 4, false, true>(p, st);      // pipelined, one wave per SIMD, 145 KiB
+    case 6: return launch_cfg<FORM, CONV, 128, 4, 64, 4, false, true>(p, st);      // the same on 128 x 128 tiles, 128 KiB
 #ifdef SDXL_DIAG
     case 43: return launch_cfg<FORM, CONV, 160, 4, 64, 4>(p, st);      // the 4-deep ring with FOUR waves (64 x 80 wave tiles: 74 KB of fragment reads per K-step against 115 with eight): 73.9 vs 67.3 us on NT 4096 x 1280 x 5120, not selected
 #endif
@@ -1304,6 +1410,7 @@ int gemm_pick_splitk_small(int M, int N, int K, int kind) {     // K = the whole
   // 0.9 ms of the step to the slab round trip, the long dgrads are neutral beside the weight-gradient stream.
   const bool conv_kind = (kind == 0 || kind == 1) && KNOB(2) != 1;
   const bool lin_kind = (kind == 2 || kind == 3) && KNOB(2) > 1 && ((KNOB(2) >> kind) & 1);
+  if (conv_kind && (KNOB(30) & (kind == 0 ? 4 : 8)) && tiles > 128 && tiles <= 256) return 1;      // experiment: unsplit on the pipelined loop (launch_one)
   if ((conv_kind || lin_kind) && tiles > 128 && tiles <= 256 && K >= 5120) return 2;
   if (tiles >= 128) return 1;
   long s = 256 / tiles;
@@ -1466,6 +1573,18 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
               (((uintptr_t)p.ln_x | (uintptr_t)p.ln_dx | (uintptr_t)p.ln_addend | (uintptr_t)p.ln_gamma) & 15) == 0,
               "gemm: LayerNorm-backward epilogue: missing or misaligned buffers");
     return launch_one<GEMM_NN, false>(p, st);
+  }
+  {   // software-pipelined one-wave-per-SIMD kernel (gemm_pl.hip): forced configuration 7, or the policy of knob 30 (linear problems whose tiles fit one round)
+    const int fc = p.cfg > 0 ? p.cfg : g_force_cfg;
+    bool use = fc == 7;
+    if (!use && fc == 0 && KNOB(30) && p.taps == 1 && p.form != GEMM_TN) {
+      const int bnp = p.N % 160 == 0 ? 160 : 128;
+      const long tiles = (long)cdiv(p.M, BM) * cdiv(p.N, bnp);
+      const int k30 = KNOB(30);
+      const bool one_round = tiles <= 256 && tiles > 128;
+      use = ((k30 & 1) && p.form == GEMM_NT && one_round) || ((k30 & 2) && p.form == GEMM_NN && one_round) || ((k30 & 16) && tiles > 128 && tiles % 256 == 0) || (k30 & 32);
+    }
+    if (use && pl_applicable(p)) return launch_pl(p, 0, st);
   }
   {   // co-resident 256-row kernel (gemm_cr256.hip): forced configurations 31 (160-column tiles) / 32 (128)
     const int fc = p.cfg > 0 ? p.cfg : g_force_cfg;

@@ -1,0 +1,383 @@
+// Software-pipelined bf16 MFMA GEMM for gfx950, ONE wave per SIMD: 128 x BN x 64 workgroup tile (BN = 160 or 128), 4 waves (2 x 2, wave
+// tile 64 x BN/2), 4-deep LDS-DMA ring (144 / 128 KiB: the workgroup owns its CU), linear NT / NN problems (forward projections, dgrads).
+//
+// Why (profiles/r05a_*): the lockstep kernels of gemm.hip spend a K-step's three resources one after the other -- the 8-wave 4-deep
+// configuration takes 0.75-0.83 us per 64-deep step of a 128 x 160 tile for 0.30 us of products, 0.27 us of L1 -> LDS transfer (64 B/clk: the
+// CU's hard floor, profiles/r05a_stage_rate2.txt) and 0.2-0.3 us of fragment reads; two waves per SIMD alternating (configuration 23, the
+// co-resident pairs of the backward) recover part of it.  Here ONE wave keeps all three busy: the fragments of the NEXT 32-deep half-step
+// are read into a second register set, and the DMA pieces of the step three ahead are issued, BETWEEN the MFMAs of the current half-step --
+// at most one LDS read and one DMA piece per MFMA, so that every non-matrix instruction issues in the shadow of a 16-cycle MFMA instead of
+// in a block of its own (a wave issues in order: 25 instructions between two groups of MFMAs are 100 cycles of idle matrix pipe --
+// the first form of this loop, gemm.hip configuration 5, measured 0.60 us per step).  The instruction count is cut to fit those shadows:
+// buffer_load ... lds through raw descriptors (one constant per-lane offset per piece, one running scalar offset per operand, the LDS
+// destination added straight into M0: 3 instructions per piece instead of 12), out-of-range rows / columns and the pieces beyond the last
+// K-step are offsets beyond num_records (zeros, no traffic, no select in the live loop).
+//
+// Schedule (per K-step t; f0 / f1 = the fragment registers of the two 32-deep halves; S = 4 ring slots):
+//   phase 0:  MFMAs of (t, half 0) from f0  |  reads of (t, half 1) -> f1      |  first pieces of step t + 3 -> slot (t + 3) % 4
+//   -- s_waitcnt vmcnt(NL + NP0): my pieces of step t + 1 have landed; lgkmcnt(0); ONE s_barrier --
+//   phase 1:  MFMAs of (t, half 1) from f1  |  reads of (t + 1, half 0) -> f0  |  the other pieces of step t + 3
+// Hazards: RAW -- step t + 1 is first read in phase 1 of step t, behind the barrier every wave enters after the counted wait that retires
+// its own pieces of that step (pieces land in issue order; outstanding at the wait, oldest first: step t + 1, step t + 2, the NP0 pieces
+// of phase 0).  WAR -- the pieces of step t + 3 overwrite the slot of step t - 1, whose last reads (half 1) were issued in phase 0 of step
+// t - 1, before that step's barrier, and consumed by the MFMAs of its phase 1: the restaging wave has passed that barrier and a whole
+// phase of its own since (the guide's rule: restage a buffer >= 2 phases after its last ds_read), and its pieces land ~1 us after issue.
+// The reads of the step after the last one are not skipped: their slot holds zero-fill pieces retired by the same counted wait.
+// LDS read addresses: a per-lane base per half-step (loop-invariant) + the slot's scalar base, one VALU per operand and phase; fragment
+// rows are immediates.
+//
+// LDS images, swizzles and fragment reads: gemm_tiles.h (the same as gemm.hip: K-contiguous tiles by ds_read_b128, the N-contiguous
+// weight tile of the NN form by ds_read_b64_tr_b16).  Products with the operands swapped (D^T layout): lane (l16, g) holds
+// C[16 i + l16][16 j + 4 g .. + 3]; bf16 rows leave in 16-byte pieces after a v_permlane16_swap of neighbouring fragments.
+// Epilogue: + bias + per-sample row vector + residual / accumulate (bf16).  Everything else (3 x 3 gather, GEGLU, split-K, the Delta
+// epilogue, the TN form) stays on gemm.hip / gemm256.hip / gemm_cr256.hip.
+#include "gemm_tiles.h"
+
+#include <type_traits>
+
+namespace {
+
+constexpr int PL_BM = 128, PL_BK = 64, PL_S = 4;
+constexpr unsigned PL_OOB = 0x80000000u;   // per-lane offset beyond num_records: the load returns zeros
+
+#ifndef SDXL_PL_DIAG      // scratch diagnostics only (never defined in the product build): knock out one pipeline component
+#define SDXL_PL_DIAG 0    // bit 0: no MFMA, bit 1: no DMA in the main loop, bit 2: no LDS fragment reads,
+#endif                    // bit 3: every workgroup stages tile (0, 0) (all L2 hits after the first touch; results wrong)
+
+template <int BN>
+struct PlGeom {
+  static constexpr int A_BYTES = PL_BM * PL_BK * 2;     // 16 KiB
+  static constexpr int B_BYTES = BN * PL_BK * 2;        // 20 / 16 KiB
+  static constexpr int STAGE = A_BYTES + B_BYTES;       // 36 / 32 KiB
+  static constexpr int SMEM = PL_S * STAGE;             // 144 / 128 KiB
+  static constexpr int ACH = A_BYTES / 1024 / 4;        // 4 pieces of the A tile per wave
+  static constexpr int BCH = B_BYTES / 1024 / 4;        // 5 / 4 of the B tile
+  static constexpr int NL = ACH + BCH;                  // LDS-DMA instructions per wave and K-step
+  static constexpr int NP0 = (NL + 1) / 2;              // ... of them in phase 0
+  static constexpr int NJ = BN / 32;                    // B fragments per wave
+  static constexpr int MI = 4;                          // A fragments per wave
+  static constexpr int NMF = MI * NJ;                   // MFMAs per wave and half-step
+};
+
+// one LDS-DMA piece: M0 = slot base + constant, then the load (the s_nop: M0 write -> LDS-DMA needs one wait state).  Nothing else in
+// this kernel uses M0 (no s_movrel, no v_readlane by M0, no builtin LDS-DMA), so it is not restored.
+template <int OFF>
+__device__ __forceinline__ void pl_dma(i32x4 srd, unsigned voff, unsigned soff, unsigned slot_base) {
+  asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+               :: "v"(voff), "s"(srd), "s"(soff), "s"(slot_base), "n"(OFF) : "memory", "scc");
+}
+
+template <int NJ>
+struct PlFrag { bf16x8 a[4], b[NJ]; };
+
+// f(integral_constant<int, 0>{}) ... f(integral_constant<int, N - 1>{}), in order: a loop whose index is a constant expression in the body
+template <typename F, int... I>
+__device__ __forceinline__ void pl_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void pl_static_for(F&& f) { pl_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <int FORM, int BN>
+__global__ __launch_bounds__(256, 2) void pl_kernel(const GemmP p) {      // (register budget 256: with 512 hipcc moves accumulators through AGPRs)
+  using G = PlGeom<BN>;
+  constexpr bool B_KC = FORM == GEMM_NT;
+  constexpr int NJ = G::NJ, MI = G::MI, NL = G::NL, NP0 = G::NP0, NMF = G::NMF;
+  constexpr int dbg = SDXL_PL_DIAG;
+  static_assert(FORM == GEMM_NT || FORM == GEMM_NN, "pipelined kernel: NT / NN");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  set_wave_prio(p.prio);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;          // 2 x 2 waves, wave tile 64 x BN/2
+  const int l16 = lane & 15, g = lane >> 4;
+  int bx, by;
+  xcd_tile_map(p.xcd_px, bx, by);
+  const int n0 = (dbg & 8) ? 0 : bx * BN, m0 = (dbg & 8) ? 0 : by * PL_BM;
+  const int M = p.M, N = p.N;
+  const int lda = (int)p.lda, ldb = (int)p.ldb;
+  const int T = p.K / PL_BK;
+
+  // ---- LDS-DMA addressing: A pieces j = 0..3 = chunks wave + 4 j (8 rows x 128 B each), B pieces likewise ----
+  const i32x4 ra = make_srd(p.A, 0x7FFFFFFFu), rb = make_srd(p.B, 0x7FFFFFFFu);
+  const unsigned lds_w = lds_addr_of(smem) + (unsigned)wave * 1024u;      // slot 0, this wave's first chunk of the A tile
+  unsigned voA[G::ACH], voB[G::BCH];                 // constant per-lane byte offsets (PL_OOB: zeros)
+  {
+    const int kc_row = lane >> 3, kc_vec = (lane & 7) ^ kc_row;      // K-contiguous [R][64] image: lane -> row 8 c + lane / 8, vector swizzled by the row
+#pragma unroll
+    for (int j = 0; j < G::ACH; ++j) {
+      const int row = m0 + 8 * (wave + 4 * j) + kc_row;
+      voA[j] = row < M ? (unsigned)(((long)row * lda + kc_vec * 8) * 2) : PL_OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < G::BCH; ++j) {
+      if (B_KC) {
+        const int row = n0 + 8 * (wave + 4 * j) + kc_row;
+        voB[j] = row < N ? (unsigned)(((long)row * ldb + kc_vec * 8) * 2) : PL_OOB;
+      } else {
+        // N-contiguous [64 k][BN] image: chunk c = vectors 64 c .. 64 c + 63 of the [64][BN / 8] vector grid
+        constexpr int V = BN / 8;
+        const int q = (wave + 4 * j) * 64 + lane;
+        const int krow = q / V, pv = q - krow * V;
+        const int n = n0 + (nc_logical<BN>(krow, pv) << 3);
+        voB[j] = n < N ? (unsigned)(((long)krow * ldb + n) * 2) : PL_OOB;
+      }
+    }
+  }
+  unsigned soA = 0, soB = 0;                         // running scalar byte offsets of the step being staged
+  const unsigned stepA = PL_BK * 2, stepB = B_KC ? PL_BK * 2 : (unsigned)(PL_BK * ldb * 2);
+  const unsigned oob = PL_OOB;
+
+  // piece pc (0 .. NL - 1: A chunks first) of the step being staged -> ring slot whose base (+ this wave's chunk) is `sb`; beyond the last
+  // K-step the pieces are still issued (the counted waits stay uniform), at offsets beyond num_records: zeros, no traffic
+  auto piece = [&](auto PC, auto LIVE, unsigned sb) {
+    constexpr int pc = decltype(PC)::value;
+    constexpr bool live = decltype(LIVE)::value;
+    if constexpr (pc < G::ACH) pl_dma<pc * 4096>(ra, live ? voA[pc] : oob, soA, sb);
+    else pl_dma<G::A_BYTES + (pc - G::ACH) * 4096>(rb, live ? voB[pc - G::ACH] : oob, soB, sb);
+  };
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+
+  using Frag = PlFrag<NJ>;
+  constexpr int NITEM = MI + NJ;                     // fragment reads per half-step: B first (the first MFMAs need all of them), then A
+  // Fragment-read addresses: one per-lane LDS byte address per (32-deep half-step[, B fragment of the NN form]) for ring slot 0, computed
+  // ONCE and made opaque to the compiler (it would otherwise re-derive them inside the loop: one VALU per read in the MFMA shadows);
+  // a phase adds its slot's base once per operand, fragment rows and the +4-row second transpose read are immediates.
+  typedef const __attribute__((address_space(3))) bf16x8 lds_bf16x8;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+  constexpr int NBB = B_KC ? 1 : NJ;                 // B bases per ks: the N-contiguous image's swizzle is not affine in the fragment index
+  unsigned bA[2], bB[2][NBB];
+  {
+    const unsigned l0 = lds_addr_of(smem);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const unsigned x = (unsigned)(((ks * 4 + g) ^ (l16 & 7)) << 4);      // K-contiguous image: vector slot = kv ^ (row & 7); every fragment row has row & 7 = l16 & 7
+      bA[ks] = l0 + (unsigned)(wm * 64 + l16) * 128u + x;
+      asm volatile("" : "+v"(bA[ks]));
+#pragma unroll
+      for (int j = 0; j < NBB; ++j) {
+        if (B_KC) {
+          bB[ks][j] = l0 + G::A_BYTES + (unsigned)(wn * (BN / 2) + l16) * 128u + x;
+        } else {      // (frag_nc<BN>, gemm_tiles.h: 8 k-rows from ks * 32 + g * 8, 16 columns from wn * BN/2 + 16 j)
+          const int krow = ks * 32 + g * 8 + (l16 >> 2);
+          const int v = ((wn * (BN / 2) + j * 16) >> 3) + ((l16 >> 1) & 1);
+          bB[ks][j] = l0 + G::A_BYTES + (unsigned)(krow * (BN * 2) + (nc_phys<BN>(krow, v) << 4) + (l16 & 1) * 8);
+        }
+        asm volatile("" : "+v"(bB[ks][j]));
+      }
+    }
+  }
+  // a phase's read addresses: this lane's base of (half-step KS) + the ring slot's byte offset, opaque again (the compiler would fold
+  // slot offset + fragment-row immediate into a scalar and spend one VALU per read on the sum)
+  struct RAddr { unsigned a, b[NBB]; };
+  auto raddr = [&](unsigned rbase, auto KS) {
+    constexpr int ks = decltype(KS)::value;
+    RAddr r;
+    r.a = bA[ks] + rbase;
+    asm volatile("" : "+v"(r.a));
+#pragma unroll
+    for (int j = 0; j < NBB; ++j) { r.b[j] = bB[ks][j] + rbase; asm volatile("" : "+v"(r.b[j])); }
+    return r;
+  };
+  // the fragments at `ra`: item IT of NITEM
+  auto read_item = [&](const RAddr& ra_, Frag& f, auto IT) {
+    constexpr int it = decltype(IT)::value;
+    if constexpr ((dbg & 4) != 0) { if constexpr (it < NJ) f.b[it] = ones; else f.a[it - NJ] = ones; }
+    else if constexpr (it < NJ) {
+      if constexpr (B_KC) {
+        f.b[it] = *(lds_bf16x8*)(size_t)(ra_.b[0] + (unsigned)(it * 2048));
+      } else {
+        const unsigned a0 = ra_.b[it];
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(size_t)a0);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(size_t)(a0 + 4u * (BN * 2)));      // rows + 4: same swizzle
+        union { s16x4 s2[2]; bf16x8 v; } u;
+        u.s2[0] = lo; u.s2[1] = hi;
+        f.b[it] = u.v;
+      }
+    } else {
+      constexpr int i = it - NJ;
+      f.a[i] = *(lds_bf16x8*)(size_t)(ra_.a + (unsigned)(i * 2048));
+    }
+  };
+  // one phase (PH = 0 / 1): fc = the fragments multiplied, fn = the set being filled from (slot at `rbase`, RKS); pieces [PH NP0, ...) of
+  // the step being staged.  At most ONE read item (behind every second MFMA) or ONE piece (in gaps between) per MFMA: every filler
+  // issues in the shadow of a 16-cycle MFMA.  The last fragments read (A rows 1 .. 3) are the last ones the next phase needs.
+  auto phase = [&](auto PHC, auto LIVE, const Frag& fc, Frag& fn, unsigned rbase, auto RKS, unsigned sb) {
+    constexpr int PH = decltype(PHC)::value;
+    constexpr int NPP = PH == 0 ? NP0 : NL - NP0;    // pieces of this phase
+    static_assert(2 * (NITEM - 1) < NMF && NPP <= NMF / 4, "filler schedule: reads behind the even MFMAs, pieces behind every fourth odd one");
+    const RAddr rad = raddr(rbase, RKS);
+    pl_static_for<NMF>([&](auto KC) {
+      constexpr int k = decltype(KC)::value, i = k / NJ, j = k % NJ;
+      if (dbg & 1) acc[i][j][0] += (float)fc.a[i][0] + (float)fc.b[j][0];
+      else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc.b[j], fc.a[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (k % 2 == 0 && k / 2 < NITEM) read_item(rad, fn, std::integral_constant<int, k / 2>{});
+      if constexpr (!(dbg & 2) && k % 2 == 1) {
+        pl_static_for<NPP>([&](auto QC) {
+          constexpr int q = decltype(QC)::value;
+          if constexpr (k == 1 + 2 * ((q * (NMF / 2)) / NPP)) piece(std::integral_constant<int, PH * NP0 + q>{}, LIVE, sb);
+        });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  // ---- prologue: steps 0 .. 2 in flight, step 0 landed, the first half-step's fragments in f0 ----
+  {
+    unsigned sb = lds_w;
+#pragma unroll
+    for (int d = 0; d < PL_S - 1; ++d) {
+      if (d < T) pl_static_for<NL>([&](auto PC) { piece(PC, std::true_type{}, sb); });
+      else pl_static_for<NL>([&](auto PC) { piece(PC, std::false_type{}, sb); });
+      soA += stepA; soB += stepB;
+      sb += G::STAGE;
+    }
+  }
+  Frag f0, f1;
+  wait_vmcnt<(PL_S - 2) * NL>();
+  __builtin_amdgcn_s_barrier();
+  {
+    const RAddr rad = raddr(0u, std::integral_constant<int, 0>{});
+    pl_static_for<NITEM>([&](auto IT) { read_item(rad, f0, IT); });
+  }
+  int rd = 0, wr = PL_S - 1;
+  auto kstep = [&](auto LIVE) {
+    const unsigned sb = lds_w + (unsigned)wr * G::STAGE;
+    phase(std::integral_constant<int, 0>{}, LIVE, f0, f1, (unsigned)rd * G::STAGE, std::integral_constant<int, 1>{}, sb);
+    wait_vmcnt<(PL_S - 3) * NL + NP0>();            // my pieces of the next step have landed
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    const int rn = rd + 1 == PL_S ? 0 : rd + 1;
+    phase(std::integral_constant<int, 1>{}, LIVE, f1, f0, (unsigned)rn * G::STAGE, std::integral_constant<int, 0>{}, sb);
+    soA += stepA; soB += stepB;
+    rd = rn;
+    wr = wr + 1 == PL_S ? 0 : wr + 1;
+  };
+  const int Tlive = T - (PL_S - 1);                  // steps t < Tlive stage a step t + 3 that exists
+  int t = 0;
+  for (; t < Tlive; ++t) kstep(std::true_type{});
+  for (; t < T; ++t) kstep(std::false_type{});
+  wait_vmcnt<0>();                                   // zero-fill tail pieces must not outlive the workgroup's LDS allocation
+
+  // ---- epilogue, registers -> global.  Lane (l16, g) holds C[m = 16 i + l16][n = 16 j + 4 g .. + 3] of its wave tile ----
+  auto store_bf16 = [&](int m, int n, float (&x)[8], int cnt) {   // cnt = 8 or 4 columns
+    if (m >= M || n >= N) return;
+    if (cnt == 8) {
+      if (p.bias) {
+        const bf16x8 bv = *(const bf16x8*)(p.bias + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += (float)bv[e];
+      }
+      if (p.rowvec) {
+        const bf16x8 tv = *(const bf16x8*)(p.rowvec + (long)(m / p.rows_per_batch) * p.ldv + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += (float)tv[e];
+      }
+      if (p.resid) {
+        const bf16x8 rv = *(const bf16x8*)(p.resid + (long)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += (float)rv[e];
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16)x[e];
+      *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + n) = o;
+    } else {
+      if (p.bias) {
+        const bf16x4 bv = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] += (float)bv[e];
+      }
+      if (p.rowvec) {
+        const bf16x4 tv = *(const bf16x4*)(p.rowvec + (long)(m / p.rows_per_batch) * p.ldv + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] += (float)tv[e];
+      }
+      if (p.resid) {
+        const bf16x4 rv = *(const bf16x4*)(p.resid + (long)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] += (float)rv[e];
+      }
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16)x[e];
+      *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) = o;
+    }
+  };
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // 24 wait states: MFMA results -> inline-asm VALU reads below
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + l16;
+#pragma unroll
+    for (int j = 0; j + 1 < NJ; j += 2) {
+      float x[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float lo = acc[i][j][r], hi = acc[i][j + 1][r];
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));      // (2 wait states: VALU write -> permlane read)
+        x[r] = lo;
+        x[4 + r] = hi;
+      }
+      store_bf16(m, n0 + wn * (BN / 2) + (j + (g & 1)) * 16 + (g >> 1) * 8, x, 8);
+    }
+    if (NJ & 1) {   // odd fragment count (BN = 160): the last fragment goes out in 8-byte pieces
+      float x[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[r] = acc[i][NJ - 1][r];
+      store_bf16(m, n0 + wn * (BN / 2) + (NJ - 1) * 16 + g * 4, x, 4);
+    }
+  }
+}
+
+template <int FORM, int BN>
+int launch_pl_k(const GemmP& p, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)pl_kernel<FORM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, PlGeom<BN>::SMEM));
+    attr_set = true;
+  }
+  dim3 grid(cdiv(p.N, BN), cdiv(p.M, PL_BM), 1);
+  GEMM_LAUNCH((pl_kernel<FORM, BN>), grid, dim3(256), PlGeom<BN>::SMEM, st, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+// can this problem run on the pipelined kernel?  (p as normalised by launch_gemm: accumulate folded into resid, etc.)
+bool pl_applicable(const GemmP& p) {
+  if (p.form != GEMM_NT && p.form != GEMM_NN) return false;
+  if (p.taps != 1 || p.up2 || p.geglu || p.splitk > 1 || p.group > 1 || p.delta_out || p.ln_x || p.out_f32 || p.Cb) return false;
+  if (p.K % PL_BK || p.N % 8 || p.lda % 8 || p.ldb % 8 || p.ldc % 8) return false;
+  // 32-bit buffer offsets
+  const long abytes = 2 * (long)p.M * p.lda;
+  const long bbytes = 2 * (p.form == GEMM_NT ? (long)p.N * p.ldb : (long)p.K * p.ldb);
+  if (abytes >= (1L << 31) || bbytes >= (1L << 31)) return false;
+  return true;
+}
+
+int launch_pl(const GemmP& pin, int bn, hipStream_t st) {
+  ARG_CHECK(pl_applicable(pin), "gemm_pl: problem %dx%dx%d (form %d) does not fit the pipelined kernel", pin.M, pin.N, pin.K, pin.form);
+  GemmP p = pin;
+  if (bn != 128 && bn != 160) bn = p.N % 160 == 0 ? 160 : 128;
+  {   // px x (8/px) XCD grid over the (n, m) tile grid minimising the per-XCD operand footprint ~ N/px + M/py
+    const int gx = cdiv(p.N, bn), gy = cdiv(p.M, PL_BM);
+    double best = 1e30;
+    p.xcd_px = 0;
+    for (int px = 1; px <= 8; px *= 2) {
+      const int py = 8 / px;
+      if (gx % px || gy % py) continue;
+      const double cost = (double)p.N / px + (double)p.M / py;
+      if (cost < best) { best = cost; p.xcd_px = px; }
+    }
+  }
+  if (p.form == GEMM_NT) return bn == 160 ? launch_pl_k<GEMM_NT, 160>(p, st) : launch_pl_k<GEMM_NT, 128>(p, st);
+  return bn == 160 ? launch_pl_k<GEMM_NN, 160>(p, st) : launch_pl_k<GEMM_NN, 128>(p, st);
+}

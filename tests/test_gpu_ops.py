@@ -385,6 +385,59 @@ def test_gemm_splitk_groups_nt_nn(L, M, N, K):
         lib.check(L.sdxl_set_gemm_mode(1))
 
 
+@pytest.mark.parametrize("cfg", [7, 5, 6])
+@pytest.mark.parametrize("M,N,K", [(128, 160, 64), (128, 160, 128), (256, 320, 192), (128, 128, 256), (4096, 1280, 1280), (1000, 640, 2560),
+                                   (308, 1280, 2048), (4096, 1280, 5120), (520, 264, 320), (16384, 640, 640)])
+def test_gemm_pipelined_nt_nn(L, cfg, M, N, K):
+    """The software-pipelined one-wave-per-SIMD kernels: configuration 7 = gemm_pl.hip (the next half-step's fragments are read and the DMA
+    pieces of step t + 3 issued BETWEEN the MFMAs of the current half-step; 128 x 160 tiles where N % 160 == 0, else 128 x 128; 4-deep
+    ring; raw-buffer LDS-DMA with out-of-range offsets for ragged rows / columns and the tail), configurations 5 / 6 = the same loop
+    structure inside gemm.hip's kernel (group-wise interleave; also takes the 3 x 3 gather).  1 ... 5 K-steps exercise the prologue and
+    the zero-fill tail (the loop also READS the slot of the step after the last one), ragged M / N the row predicates; every bf16
+    epilogue input; against fp32 and bit-for-bit against the lockstep kernel on the same tiles (configuration 13 / 1: the same products
+    in the same order per accumulator).  A new barrier / counted-wait structure: each case also runs 20 times and must return the same
+    bits every time (a reader that overtakes its DMA shows up as a run-to-run difference long before a reference check at 6e-3 does)."""
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    wn = rnd(K, N, seed=6, scale=K ** -0.5)
+    base = rnd(M, N, seed=7)
+
+    def run(c):
+        lib.check(L.sdxl_set_gemm_mode(4 * c))
+        try:
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+            lib.check(L.sdxl_op_gemm(0, ptr(a), ptr(w), ptr(out), M, N, K, ptr(bias), ptr(res), 0, 1, stream()))
+            out2 = base.clone()
+            lib.check(L.sdxl_op_gemm(1, ptr(a), ptr(wn), ptr(out2), M, N, K, None, None, 1, 1, stream()))
+            torch.cuda.synchronize()
+            return out, out2
+        finally:
+            lib.check(L.sdxl_set_gemm_mode(1))
+
+    out, out2 = run(cfg)
+    report(f"gemm cfg{cfg} nt {M}x{N}x{K}", out, a.float() @ w.float().t() + bias.float() + res.float(), 6e-3)
+    report(f"gemm cfg{cfg} nn+= {M}x{N}x{K}", out2, a.float() @ wn.float() + base.float(), 6e-3)
+    lock = run(13 if (cfg in (5, 7) and N % 160 == 0) else 1)
+    if cfg == 7 or (cfg == 5) == (N % 160 == 0):           # same tile width on both sides: identical summation order
+        assert torch.equal(out, lock[0]) and torch.equal(out2, lock[1]), "pipelined loop differs from the lockstep loop on the same tiles"
+    for _ in range(20):
+        o, o2 = run(cfg)
+        assert torch.equal(o, out) and torch.equal(o2, out2), "pipelined loop is not run-to-run reproducible"
+
+
+def test_conv_and_geglu_through_pipelined_loop(L):
+    for cfg in (5, 6):
+        lib.check(L.sdxl_set_gemm_mode(4 * cfg))
+        try:
+            test_conv3x3_fwd_dgrad_wgrad(L, 2, 16, 12, 320, 640, 1)
+            test_conv3x3_fwd_dgrad_wgrad(L, 1, 32, 32, 960, 320, 1)
+            test_conv3x3_fwd_dgrad_wgrad(L, 1, 32, 32, 1280, 1280, 1)
+            _ff_geglu_case(L, 308, 320, 1280, 80 if cfg == 5 else 64)
+            _ff_geglu_case(L, 4096, 1280, 5120, 80 if cfg == 5 else 64)
+        finally:
+            lib.check(L.sdxl_set_gemm_mode(1))
+
+
 def test_conv_and_geglu_through_splitk_groups(L):
     lib.check(L.sdxl_set_gemm_mode(4 * 23))
     try:
