@@ -31,6 +31,10 @@ SDXL_API int sdxl_debug_act_checksums(sdxl_handle* h, unsigned long long* out_ho
  * LDS each stream `buf` for `busy_us` microseconds; run beside the backward it prices the co-residency of the gradient exchange. */
 SDXL_API int sdxl_op_exchange_shadow(void* buf, size_t bytes, int workgroups, int lds_bytes, float busy_us, void* stream);
 
+/* sdxl_op_gemm's NT (form 0) / NN (form 1) with explicit leading dimensions (elements) and a configuration forced for this launch only
+ * (cfg as in sdxl_set_gemm_mode's upper bits; 0 = the policy): C [M][N] = A [M][K] . B (+ bias [N]) (+ resid [M][ldr]) */
+SDXL_API int sdxl_op_gemm_ld(int form, const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, const void* bias,
+                    const void* resid, long ldr, int cfg, void* stream);
 /* the out-projection dgrad whose epilogue also writes the self-attention backward's Delta (csrc/kernels.h, GemmP::delta_out; the plan
  * uses it at the 1280-channel level, csrc/engine.hip LinearOp::plan_bwd): dO [M][N] = dY [M][K] . W [K][N] (+ addend, or null), bf16, and
  * Delta[(b * heads + h) * Nq + q] = sum_d bf16(dO[m][64 h + d]) * O[m][64 h + d] with m = b * Nq + q, heads = N / 64.  M = B * Nq,

@@ -49,7 +49,9 @@ for form, M, N, Ks in SHAPES:
             a = r(M, K)
             b = r(N, K) if form == "NT" else r(K, N)
             o = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-            args = (0 if form == "NT" else 1, a.data_ptr(), b.data_ptr(), o.data_ptr(), M, N, K, None, None, 0, 1, st())
+            bias, res = (r(N), r(M, N)) if "--epilogue" in sys.argv else (None, None)      # (--epilogue: + bias + residual, as the forward launches them)
+            args = (0 if form == "NT" else 1, a.data_ptr(), b.data_ptr(), o.data_ptr(), M, N, K, bias.data_ptr() if bias is not None else None,
+                    res.data_ptr() if res is not None else None, 0, 1, st())
             fn = lambda: L.sdxl_op_gemm(*args)
             lib.check(fn())
             us.append(bench(fn))

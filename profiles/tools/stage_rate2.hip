@@ -44,8 +44,8 @@ __device__ __forceinline__ void dma(i32x4 srd, unsigned voff, unsigned soff, uns
 
 // NW waves (4 or 8); PACKED layout or strided; POL cache policy
 template <int NW, bool PACKED, int POL>
-__global__ __launch_bounds__(NW * 64, 1) void stage_kernel(const char* __restrict__ A, const char* __restrict__ B, unsigned lda_b, unsigned ldb_b,
-                                                           int T, int xcd_map, int same_tile, unsigned* sink) {
+__global__ __launch_bounds__(NW * 64 + 64, 1) void stage_kernel(const char* __restrict__ A, const char* __restrict__ B, unsigned lda_b, unsigned ldb_b,
+                                                           int T, int xcd_map, int same_tile, unsigned* sink, int pf_lead = 0) {
   constexpr int PPW = NPC / NW;                     // pieces per wave and K-step (9 or 4.5 -> 36 / 8 is not whole: 8 waves issue 4 or 5)
   constexpr int PPWC = (NPC + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -54,7 +54,25 @@ __global__ __launch_bounds__(NW * 64, 1) void stage_kernel(const char* __restric
   const int id = blockIdx.x;
   if (xcd_map) { const int xcd = id & 7, li = id >> 3; bx = (xcd & 1) * 4 + (li & 3); by = (xcd >> 1) * 8 + (li >> 2); }
   else { bx = id & 7; by = id >> 3; }
-  if (same_tile) { bx = 0; by = 0; }
+  if (same_tile == 1) { bx = 0; by = 0; }
+  if (same_tile == 2) { bx = id; by = id; }      // every workgroup its own operand panels: nothing shared, all of it crosses the fabric (packed arms only)
+  if (wave == NW) {      // the extra L2-prefetch wave (launched only with pf_lead > 0): this workgroup's share of the XCD's lines, pf_lead steps ahead
+    const int ln = bx & 3, lm = by & 7;
+    unsigned snk = 0;
+    auto touch = [&](int tp) {
+      if (tp >= T) return;
+      const char* src = nullptr;
+      if (lane < 32) src = A + (size_t)(by * RA + ln * 32 + lane) * lda_b + (size_t)tp * SEG;
+      else if (lane < 52) src = B + (size_t)(bx * RB + lm * 20 + (lane - 32)) * ldb_b + (size_t)tp * SEG;
+      if (src) asm volatile("global_load_dword %0, %1, off sc1" : "+v"(snk) : "v"(src) : "memory");
+    };
+    for (int tp = S - 1; tp < pf_lead; ++tp) touch(tp);
+    for (int t = 0; t < T; ++t) { __builtin_amdgcn_s_barrier(); touch(t + pf_lead); }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(snk) :: "memory");
+    __syncthreads();
+    if (snk == 0x12345678u) sink[1] = snk;
+    return;
+  }
   const i32x4 ra = make_srd(A, 0x7FFFFFFFu), rb = make_srd(B, 0x7FFFFFFFu);
   const unsigned lds_base = lds_addr_of(smem);
   // per-lane offset inside a piece: strided = 8 rows x 128 B (vector index xor-swizzled by the row, as gemm.hip stages); packed = linear
@@ -94,15 +112,33 @@ __global__ __launch_bounds__(NW * 64, 1) void stage_kernel(const char* __restric
 
 struct Arm { const char* name; int nw; bool packed; int pol; int pad_el; int xcd; int same; };
 
+static int g_pf = 0;                 // > 0: launch the extra prefetch wave with this lead
+static int g_nset = 1;               // > 1: "cold" -- launch i uses operand set i % g_nset (the sets are g_stride bytes apart: > L2 + memory-side cache in total)
+static size_t g_strideA = 0, g_strideB = 0;
 template <int NW, bool PACKED, int POL>
 static float time_one(const char* A, const char* B, unsigned lda_b, unsigned ldb_b, int T, int xcd, int same, unsigned* sink) {
   const int smem = S * STAGE;
+  if (g_nset > 1) {
+    hipFuncSetAttribute((const void*)stage_kernel<NW, PACKED, POL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < g_nset; ++i)
+        hipLaunchKernelGGL((stage_kernel<NW, PACKED, POL>), dim3(256), dim3(NW * 64 + (g_pf ? 64 : 0)), smem, 0, A + (size_t)i * g_strideA, B + (size_t)i * g_strideB, lda_b, ldb_b, T, xcd, same, sink, g_pf);
+      hipEventRecord(e1, 0); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      if (ms / g_nset < best) best = ms / g_nset;
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return best * 1e3f;
+  }
   hipFuncSetAttribute((const void*)stage_kernel<NW, PACKED, POL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float best = 1e9f;
   for (int rep = 0; rep < 5; ++rep) {
     hipEventRecord(e0, 0);
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((stage_kernel<NW, PACKED, POL>), dim3(256), dim3(NW * 64), smem, 0, A, B, lda_b, ldb_b, T, xcd, same, sink);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((stage_kernel<NW, PACKED, POL>), dim3(256), dim3(NW * 64 + (g_pf ? 64 : 0)), smem, 0, A, B, lda_b, ldb_b, T, xcd, same, sink, g_pf);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (ms / 10 < best) best = ms / 10;
@@ -121,17 +157,25 @@ static float dispatch(const Arm& a, const char* A, const char* B, unsigned lda_b
 
 int main(int argc, char** argv) {
   const int only = argc > 1 ? atoi(argv[1]) : -1;            // run ONE arm (for rocprofv3 --pmc passes): its index
+  const bool cold = argc > 2 && !strcmp(argv[2], "cold");    // operands from HBM: 24 operand sets (1.3 GB) in rotation
   const int M = 4096, N = 1280;
   const int Ks[2] = {2560, 5120};
-  const size_t abytes = (size_t)M * (5120 + 128) * 2, bbytes = (size_t)N * (5120 + 128) * 2;
+  size_t abytes = (size_t)M * (5120 + 128) * 2, bbytes = (size_t)N * (5120 + 128) * 2;
+  if (cold) { g_nset = 24; g_strideA = abytes; g_strideB = bbytes; abytes *= g_nset; bbytes *= g_nset; printf("# COLD: %d operand sets in rotation\n", g_nset); }
   char *A, *B; unsigned* sink;
+  {   // the nothing-shared arm: 256 workgroups x 80 K-steps x (16 + 20) KiB
+    const size_t ua = (size_t)256 * 80 * RA * SEG, ub = (size_t)256 * 80 * RB * SEG;
+    if (abytes < ua) abytes = ua;
+    if (bbytes < ub) bbytes = ub;
+  }
   hipMalloc(&A, abytes); hipMalloc(&B, bbytes); hipMalloc(&sink, 64);
   {   // random bytes: the clock under load depends on the data (guide, rule 25)
-    std::vector<unsigned> h(abytes / 4);
+    const size_t fill = (size_t)M * (5120 + 128) * 2;
+    std::vector<unsigned> h(fill / 4);
     unsigned x = 12345u;
     for (auto& v : h) { x = x * 1664525u + 1013904223u; v = x; }
-    hipMemcpy(A, h.data(), abytes, hipMemcpyHostToDevice);
-    hipMemcpy(B, h.data(), bbytes, hipMemcpyHostToDevice);
+    for (size_t o = 0; o + fill <= abytes; o += fill) hipMemcpy(A + o, h.data(), fill, hipMemcpyHostToDevice);
+    for (size_t o = 0; o + fill <= bbytes; o += fill) hipMemcpy(B + o, h.data(), fill, hipMemcpyHostToDevice);
   }
   const Arm arms[] = {
       {"strided ld=K        8w xcd", 8, false, 0, 0, 1, 0},   {"strided ld=K+64     8w xcd", 8, false, 0, 64, 1, 0},
@@ -144,7 +188,12 @@ int main(int argc, char** argv) {
       {"strided ld=K   nt   8w xcd", 8, false, 2, 0, 1, 0},   {"packed         nt   8w xcd", 8, true, 2, 0, 1, 0},
       {"strided ld=K sc0sc1 8w xcd", 8, false, 3, 0, 1, 0},   {"packed       sc0sc1 8w xcd", 8, true, 3, 0, 1, 0},
       {"strided ld=K+64     4w xcd", 4, false, 0, 64, 1, 0},  {"packed         nt   4w xcd", 4, true, 2, 0, 1, 0},
+      {"packed  NOTHING SHARED 8w (755 MB)", 8, true, 0, 0, 1, 2},
   };
+  if (argc > 4 && argv[4][0] == 'A') { g_strideB = 0; printf("# only the A operand (activations) rotates\n"); }
+  if (argc > 4 && argv[4][0] == 'B') { g_strideA = 0; printf("# only the B operand (weights) rotates\n"); }
+  g_pf = argc > 3 ? atoi(argv[3]) : 0;                     // argv[3]: lead of the extra L2-prefetch wave (strided arms; 0 = none)
+  if (g_pf) printf("# with an L2-prefetch wave, lead %d K-steps (strided arms only are meaningful)\n", g_pf);
   const int narms = sizeof(arms) / sizeof(arms[0]);
   printf("%-40s %10s %10s %12s %12s %10s\n", "arm (NT 4096 x 1280 x K, 128x160 tiles)", "K=2560 us", "K=5120 us", "us / K-step", "KB/us per CU", "TB/s chip");
   for (int i = 0; i < narms; ++i) {

@@ -914,6 +914,22 @@ int sdxl_probe_layout(void* out, void* st) { return probe_layout(out, (hipStream
 int sdxl_op_exchange_shadow(void* buf, size_t bytes, int workgroups, int lds_bytes, float busy_us, void* st) {
   return launch_exchange_shadow(buf, bytes, workgroups, lds_bytes, busy_us, (hipStream_t)st);
 }
+// test hook (include/sdxlstep_diag.h part 1): sdxl_op_gemm's NT / NN forms with explicit leading dimensions (padded activations, as the plan's
+// feed-forward hidden tensors are) and a forced configuration for this launch only (0: the policy)
+int sdxl_op_gemm_ld(int form, const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, const void* bias,
+                    const void* resid, long ldr, int cfg, void* st) {
+  ARG_CHECK(form == GEMM_NT || form == GEMM_NN, "gemm_ld: NT / NN only (form %d)", form);
+  GemmP g;
+  gemm_defaults(&g);
+  g.form = form;
+  g.A = (const bf16*)A; g.B = (const bf16*)B; g.C = C;
+  g.M = M; g.N = N; g.K = K;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.bias = (const bf16*)bias;
+  if (resid) { g.resid = (const bf16*)resid; g.ldr = ldr; }
+  g.cfg = cfg;
+  return launch_gemm(g, (hipStream_t)st);
+}
 // test hook (include/sdxlstep_diag.h part 1): the NN dgrad with the Delta epilogue, as LinearOp::bwd launches it for a self-attention
 // layer's out-projection
 int sdxl_op_linear_dgrad_delta(const void* dy, const void* w, const void* o, const void* addend, void* d_o, float* delta, int B, int Nq,
@@ -935,7 +951,7 @@ int sdxl_op_linear_dgrad_delta(const void* dy, const void* w, const void* o, con
 int sdxl_profile_gemm_begin(void) { return gemm_profile_begin(); }
 int sdxl_set_gemm_mode(int mode) {
   const int cfg = mode >> 2;
-  ARG_CHECK(mode >= 0 && (mode & 3) <= 2 && (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 3 || cfg == 5 || cfg == 6 || cfg == 7 || cfg == 13 || cfg == 23 || cfg == 43 || cfg == 31 || cfg == 32 || cfg == 33 || cfg == 34 || cfg == 35 || cfg == 36), "gemm mode %d", mode);
+  ARG_CHECK(mode >= 0 && (mode & 3) <= 2 && (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 3 || cfg == 5 || cfg == 6 || cfg == 7 || cfg == 8 || cfg == 13 || cfg == 23 || cfg == 43 || cfg == 31 || cfg == 32 || cfg == 33 || cfg == 34 || cfg == 35 || cfg == 36), "gemm mode %d", mode);
   gemm_set_mode(mode);
   return 0;
 }

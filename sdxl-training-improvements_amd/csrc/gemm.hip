@@ -1576,11 +1576,15 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
   }
   {   // software-pipelined one-wave-per-SIMD kernel (gemm_pl.hip): forced configuration 7, or the policy of knob 30 (linear problems whose tiles fit one round)
     const int fc = p.cfg > 0 ? p.cfg : g_force_cfg;
-    bool use = fc == 7;
-    if (!use && fc == 0 && KNOB(30) && p.taps == 1 && p.form != GEMM_TN) {
+    bool use = fc == 7 || fc == 8;                       // (8: WITH the L2 prefetch wave -- measured, not used: gemm_pl.hip)
+    pl_set_prefetch(fc == 8 || KNOB(31) == 1);
+    // Policy (knob 30 = 0): the linear problems whose 128 x 160 tiles are ONE round of the chip (129 .. 256 workgroups: the 4096-token level's
+    // 1280-column outputs) -- forward projections and dgrads.  In the step (profiles/r05e_*): NN 4096 x 1280 x 10240 162 -> 106 us, x 3840
+    // 67 -> 46, NT x 5120 66 -> 59; step -0.6 ms (the weight-gradient stream loses its co-resident partner while such a dgrad runs).
+    if (!use && fc == 0 && KNOB(30) != 64 && p.taps == 1 && p.form != GEMM_TN) {
       const int bnp = p.N % 160 == 0 ? 160 : 128;
       const long tiles = (long)cdiv(p.M, BM) * cdiv(p.N, bnp);
-      const int k30 = KNOB(30);
+      const int k30 = KNOB(30) ? KNOB(30) : 3;
       const bool one_round = tiles <= 256 && tiles > 128;
       use = ((k30 & 1) && p.form == GEMM_NT && one_round) || ((k30 & 2) && p.form == GEMM_NN && one_round) || ((k30 & 16) && tiles > 128 && tiles % 256 == 0) || (k30 & 32);
     }

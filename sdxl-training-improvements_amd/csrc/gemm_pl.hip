@@ -29,7 +29,7 @@
 // LDS images, swizzles and fragment reads: gemm_tiles.h (the same as gemm.hip: K-contiguous tiles by ds_read_b128, the N-contiguous
 // weight tile of the NN form by ds_read_b64_tr_b16).  Products with the operands swapped (D^T layout): lane (l16, g) holds
 // C[16 i + l16][16 j + 4 g .. + 3]; bf16 rows leave in 16-byte pieces after a v_permlane16_swap of neighbouring fragments.
-// Epilogue: + bias + per-sample row vector + residual / accumulate (bf16).  Everything else (3 x 3 gather, GEGLU, split-K, the Delta
+// Epilogue: + bias + residual / accumulate (bf16), operands requested before the products drain.  Everything else (3 x 3 gather, GEGLU, split-K, the Delta
 // epilogue, the TN form) stays on gemm.hip / gemm256.hip / gemm_cr256.hip.
 #include "gemm_tiles.h"
 
@@ -67,6 +67,12 @@ __device__ __forceinline__ void pl_dma(i32x4 srd, unsigned voff, unsigned soff, 
                :: "v"(voff), "s"(srd), "s"(soff), "s"(slot_base), "n"(OFF) : "memory", "scc");
 }
 
+__device__ __forceinline__ bf16x8 pl_z8() {
+  bf16x8 z;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
+  return z;
+}
 template <int NJ>
 struct PlFrag { bf16x8 a[4], b[NJ]; };
 
@@ -76,8 +82,18 @@ __device__ __forceinline__ void pl_static_for_impl(F&& f, std::integer_sequence<
 template <int N, typename F>
 __device__ __forceinline__ void pl_static_for(F&& f) { pl_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-template <int FORM, int BN>
-__global__ __launch_bounds__(256, 2) void pl_kernel(const GemmP p) {      // (register budget 256: with 512 hipcc moves accumulators through AGPRs)
+// PF: a FIFTH wave that multiplies nothing: it touches, PL_PF_LEAD K-steps ahead of the step being multiplied, this CU's share of the cache
+//     lines the workgroups of its XCD are about to stage (one 4-byte load per 128-byte line, L1 bypassed) -- an L2 prefetch.  Why: inside the
+//     step a launch's operands come from HBM, not from the L2 / memory-side cache a 20-launch loop leaves them in, and three K-steps in flight
+//     (110 KB per CU) cover ~1.5 us at this kernel's pace: 47 us -> 61 us on NT 4096 x 1280 x 5120 with cold operands
+//     (profiles/r05d_pl_insitu.txt).  MEASURED AND NOT USED (launch_pl: off): with any lead (6 / 10 / 20 steps) the cold staging rate stays at
+//     0.56 us per K-step (profiles/r05e_stage_rate2_prefetch.txt) -- the cold penalty is not the latency of the first touch -- and on
+//     warm operands the extra wave costs 7 %.  Kept behind configuration 8 so that the measurement can be repeated.  The four compute waves of the 4 (n-tiles) x 8 (m-tiles) workgroups of an XCD request every line 4 or
+//     8 times at once; the prefetch waves split the lines among those workgroups (52 lines per CU and K-step: one load instruction).
+//     XCD co-location decides only who warms which L2 (speed); the wave joins the workgroup's barriers, nothing else.
+constexpr int PL_PF_LEAD = 10;
+template <int FORM, int BN, bool PF>
+__global__ __launch_bounds__(PF ? 320 : 256, 2) void pl_kernel(const GemmP p) {      // (register budget 256: with 512 hipcc moves accumulators through AGPRs)
   using G = PlGeom<BN>;
   constexpr bool B_KC = FORM == GEMM_NT;
   constexpr int NJ = G::NJ, MI = G::MI, NL = G::NL, NP0 = G::NP0, NMF = G::NMF;
@@ -95,6 +111,53 @@ __global__ __launch_bounds__(256, 2) void pl_kernel(const GemmP p) {      // (re
   const int M = p.M, N = p.N;
   const int lda = (int)p.lda, ldb = (int)p.ldb;
   const int T = p.K / PL_BK;
+
+  if (PF && wave == 4) {
+    // this workgroup's share: the XCD's workgroups are a tn x tm rectangle of tiles (xcd_tile_map); row panels of A are shared by the tn
+    // workgroups of a tile row, panels of B by the tm workgroups of a tile column
+    int tn = 1, tm = 1, ln = 0, lm = 0;
+    if (p.xcd_px > 0 && gridDim.x % p.xcd_px == 0 && gridDim.y % (8 / p.xcd_px) == 0) {
+      tn = gridDim.x / p.xcd_px; tm = gridDim.y / (8 / p.xcd_px);
+      ln = bx % tn; lm = by % tm;
+    }
+    const int ra_n = (PL_BM + tn - 1) / tn;                 // rows of the A tile this workgroup warms
+    const char* Ab = (const char*)p.A;
+    const char* Bb = (const char*)p.B;
+    // B: K-contiguous (NT): BN rows of one line per K-step; N-contiguous (NN): 64 k-rows of BN * 2 = 320 bytes = 3 lines each
+    constexpr int B_UNITS = B_KC ? BN : PL_BK * ((BN * 2 + 127) / 128);
+    const int rb_n = (B_UNITS + tm - 1) / tm;
+    unsigned sink = 0;      // every load's destination: ONE register the compiler keeps for it (never read before the final wait -- a fresh
+                            // destination per load could be reused for an address while its load is still in flight)
+    auto touch = [&](int tp) {
+      if (tp >= T) return;
+      for (int u = lane; u < ra_n; u += 64) {
+        const int row = m0 + ln * ra_n + u;
+        if (ln * ra_n + u < PL_BM && row < M) {
+          asm volatile("global_load_dword %0, %1, off sc1" : "+v"(sink) : "v"(Ab + ((long)row * lda + (long)tp * PL_BK) * 2) : "memory");
+        }
+      }
+      for (int u = lane; u < rb_n; u += 64) {
+        const int q = lm * rb_n + u;
+        if (q < B_UNITS) {
+          const char* src;
+          bool ok;
+          if (B_KC) { const int row = n0 + q; ok = row < N; src = Bb + ((long)row * ldb + (long)tp * PL_BK) * 2; }
+          else { constexpr int LPR = (BN * 2 + 127) / 128; const int kr = q / LPR, li = q - kr * LPR; const int col = n0 + li * 64; ok = col < N; src = Bb + (((long)tp * PL_BK + kr) * ldb + col) * 2; }
+          if (ok) {
+            asm volatile("global_load_dword %0, %1, off sc1" : "+v"(sink) : "v"(src) : "memory");
+          }
+        }
+      }
+    };
+    for (int tp = PL_S - 1; tp < PL_PF_LEAD; ++tp) touch(tp);
+    __builtin_amdgcn_s_barrier();                           // (the compute waves' prologue barrier)
+    for (int t = 0; t < T; ++t) {
+      touch(t + PL_PF_LEAD);
+      __builtin_amdgcn_s_barrier();                         // (their barrier of step t)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) :: "memory");
+    return;
+  }
 
   // ---- LDS-DMA addressing: A pieces j = 0..3 = chunks wave + 4 j (8 rows x 128 B each), B pieces likewise ----
   const i32x4 ra = make_srd(p.A, 0x7FFFFFFFu), rb = make_srd(p.B, 0x7FFFFFFFu);
@@ -264,59 +327,64 @@ __global__ __launch_bounds__(256, 2) void pl_kernel(const GemmP p) {      // (re
   int t = 0;
   for (; t < Tlive; ++t) kstep(std::true_type{});
   for (; t < T; ++t) kstep(std::false_type{});
-  wait_vmcnt<0>();                                   // zero-fill tail pieces must not outlive the workgroup's LDS allocation
-
-  // ---- epilogue, registers -> global.  Lane (l16, g) holds C[m = 16 i + l16][n = 16 j + 4 g .. + 3] of its wave tile ----
-  auto store_bf16 = [&](int m, int n, float (&x)[8], int cnt) {   // cnt = 8 or 4 columns
-    if (m >= M || n >= N) return;
-    if (cnt == 8) {
-      if (p.bias) {
-        const bf16x8 bv = *(const bf16x8*)(p.bias + n);
+  // ---- epilogue, registers -> global.  Lane (l16, g) holds C[m = 16 i + l16][n = 16 j + 4 g .. + 3] of its wave tile; after a
+  // v_permlane16_swap of neighbouring fragments lane g owns 8 contiguous columns of fragment j + (g & 1) at column 8 (g >> 1).
+  // The epilogue's operands (bias, residual) are requested FIRST, all of them, before the products drain: one 4-wave workgroup per CU
+  // has nobody to hide a chain of 12 dependent load -> add -> store round trips behind (in the step that chain cost 20 us per launch).
+  constexpr int NP = NJ / 2;                         // fragment pairs: 16-byte pieces
+  constexpr bool ODD = (NJ & 1) != 0;                // BN = 160: the fifth fragment goes out in 8-byte pieces
+  const int mrow = m0 + wm * 64 + l16;               // + 16 i
+  const int ncol8 = n0 + wn * (BN / 2) + (g & 1) * 16 + (g >> 1) * 8;      // + 32 jp
+  const int ncol4 = n0 + wn * (BN / 2) + (NJ - 1) * 16 + g * 4;
+  bf16x8 res8[MI][NP], bias8[NP];
+  bf16x4 res4[MI], bias4;
+  const bool has_res = p.resid != nullptr, has_bias = p.bias != nullptr;      // (wave-uniform: kernel arguments)
+  {   // absent operands are zeros: the store section below is branch-free
+    bf16x4 z4; z4[0] = z4[1] = z4[2] = z4[3] = (bf16)0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] += (float)bv[e];
-      }
-      if (p.rowvec) {
-        const bf16x8 tv = *(const bf16x8*)(p.rowvec + (long)(m / p.rows_per_batch) * p.ldv + n);
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] += (float)tv[e];
-      }
-      if (p.resid) {
-        const bf16x8 rv = *(const bf16x8*)(p.resid + (long)m * p.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] += (float)rv[e];
-      }
-      bf16x8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (bf16)x[e];
-      *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + n) = o;
-    } else {
-      if (p.bias) {
-        const bf16x4 bv = *(const bf16x4*)(p.bias + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] += (float)bv[e];
-      }
-      if (p.rowvec) {
-        const bf16x4 tv = *(const bf16x4*)(p.rowvec + (long)(m / p.rows_per_batch) * p.ldv + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] += (float)tv[e];
-      }
-      if (p.resid) {
-        const bf16x4 rv = *(const bf16x4*)(p.resid + (long)m * p.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] += (float)rv[e];
-      }
-      bf16x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (bf16)x[e];
-      *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) = o;
+      for (int jp = 0; jp < NP; ++jp) res8[i][jp] = pl_z8();
+      res4[i] = z4;
     }
-  };
+#pragma unroll
+    for (int jp = 0; jp < NP; ++jp) bias8[jp] = pl_z8();
+    bias4 = z4;
+  }
+  if (has_res) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = mrow + 16 * i;
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp) {
+        const int n = ncol8 + 32 * jp;
+        res8[i][jp] = (m < M && n < N) ? *(const bf16x8*)(p.resid + (long)m * p.ldr + n) : pl_z8();
+      }
+      if (ODD) {
+        bf16x4 z; z[0] = z[1] = z[2] = z[3] = (bf16)0.f;
+        res4[i] = (m < M && ncol4 < N) ? *(const bf16x4*)(p.resid + (long)m * p.ldr + ncol4) : z;
+      }
+    }
+  }
+  if (has_bias) {
+#pragma unroll
+    for (int jp = 0; jp < NP; ++jp) {
+      const int n = ncol8 + 32 * jp;
+      bias8[jp] = n < N ? *(const bf16x8*)(p.bias + n) : pl_z8();
+    }
+    if (ODD) {
+      bf16x4 z; z[0] = z[1] = z[2] = z[3] = (bf16)0.f;
+      bias4 = ncol4 < N ? *(const bf16x4*)(p.bias + ncol4) : z;
+    }
+  }
+  wait_vmcnt<0>();                                   // zero-fill tail pieces must not outlive the workgroup's LDS allocation (also retires the loads above)
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // 24 wait states: MFMA results -> inline-asm VALU reads below
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + l16;
+    const int m = mrow + 16 * i;
 #pragma unroll
-    for (int j = 0; j + 1 < NJ; j += 2) {
+    for (int jp = 0; jp < NP; ++jp) {
+      const int j = 2 * jp;
       float x[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -325,26 +393,41 @@ __global__ __launch_bounds__(256, 2) void pl_kernel(const GemmP p) {      // (re
         x[r] = lo;
         x[4 + r] = hi;
       }
-      store_bf16(m, n0 + wn * (BN / 2) + (j + (g & 1)) * 16 + (g >> 1) * 8, x, 8);
+      const int n = ncol8 + 32 * jp;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { x[e] += (float)bias8[jp][e]; x[e] += (float)res8[i][jp][e]; }      // (this order: the lockstep kernels' bits)
+      if (m < M && n < N) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)x[e];
+        *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + n) = o;
+      }
     }
-    if (NJ & 1) {   // odd fragment count (BN = 160): the last fragment goes out in 8-byte pieces
-      float x[8];
+    if (ODD) {
+      float x[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) x[r] = acc[i][NJ - 1][r];
-      store_bf16(m, n0 + wn * (BN / 2) + (NJ - 1) * 16 + g * 4, x, 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { x[e] += (float)bias4[e]; x[e] += (float)res4[i][e]; }
+      if (m < M && ncol4 < N) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)x[e];
+        *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + ncol4) = o;
+      }
     }
   }
 }
 
-template <int FORM, int BN>
+template <int FORM, int BN, bool PF>
 int launch_pl_k(const GemmP& p, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)pl_kernel<FORM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, PlGeom<BN>::SMEM));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)pl_kernel<FORM, BN, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, PlGeom<BN>::SMEM));
     attr_set = true;
   }
   dim3 grid(cdiv(p.N, BN), cdiv(p.M, PL_BM), 1);
-  GEMM_LAUNCH((pl_kernel<FORM, BN>), grid, dim3(256), PlGeom<BN>::SMEM, st, p);
+  GEMM_LAUNCH((pl_kernel<FORM, BN, PF>), grid, dim3(PF ? 320 : 256), PlGeom<BN>::SMEM, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -354,7 +437,7 @@ int launch_pl_k(const GemmP& p, hipStream_t st) {
 // can this problem run on the pipelined kernel?  (p as normalised by launch_gemm: accumulate folded into resid, etc.)
 bool pl_applicable(const GemmP& p) {
   if (p.form != GEMM_NT && p.form != GEMM_NN) return false;
-  if (p.taps != 1 || p.up2 || p.geglu || p.splitk > 1 || p.group > 1 || p.delta_out || p.ln_x || p.out_f32 || p.Cb) return false;
+  if (p.taps != 1 || p.up2 || p.geglu || p.splitk > 1 || p.group > 1 || p.delta_out || p.ln_x || p.out_f32 || p.Cb || p.rowvec) return false;
   if (p.K % PL_BK || p.N % 8 || p.lda % 8 || p.ldb % 8 || p.ldc % 8) return false;
   // 32-bit buffer offsets
   const long abytes = 2 * (long)p.M * p.lda;
@@ -363,6 +446,8 @@ bool pl_applicable(const GemmP& p) {
   return true;
 }
 
+static int g_pl_prefetch = 0;      // the L2 prefetch wave: OFF (measured: no gain on cold operands, -7 % on warm ones); sdxl_set_gemm_mode(4 * 8) forces the kernel with it
+void pl_set_prefetch(int on) { g_pl_prefetch = on; }
 int launch_pl(const GemmP& pin, int bn, hipStream_t st) {
   ARG_CHECK(pl_applicable(pin), "gemm_pl: problem %dx%dx%d (form %d) does not fit the pipelined kernel", pin.M, pin.N, pin.K, pin.form);
   GemmP p = pin;
@@ -378,6 +463,11 @@ int launch_pl(const GemmP& pin, int bn, hipStream_t st) {
       if (cost < best) { best = cost; p.xcd_px = px; }
     }
   }
-  if (p.form == GEMM_NT) return bn == 160 ? launch_pl_k<GEMM_NT, 160>(p, st) : launch_pl_k<GEMM_NT, 128>(p, st);
-  return bn == 160 ? launch_pl_k<GEMM_NN, 160>(p, st) : launch_pl_k<GEMM_NN, 128>(p, st);
+  const bool pf = g_pl_prefetch && p.K / PL_BK > PL_PF_LEAD;      // (short reductions: the prologue's three steps are most of it)
+  if (p.form == GEMM_NT) {
+    if (bn == 160) return pf ? launch_pl_k<GEMM_NT, 160, true>(p, st) : launch_pl_k<GEMM_NT, 160, false>(p, st);
+    return pf ? launch_pl_k<GEMM_NT, 128, true>(p, st) : launch_pl_k<GEMM_NT, 128, false>(p, st);
+  }
+  if (bn == 160) return pf ? launch_pl_k<GEMM_NN, 160, true>(p, st) : launch_pl_k<GEMM_NN, 160, false>(p, st);
+  return pf ? launch_pl_k<GEMM_NN, 128, true>(p, st) : launch_pl_k<GEMM_NN, 128, false>(p, st);
 }

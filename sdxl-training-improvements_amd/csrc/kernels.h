@@ -23,9 +23,10 @@
 //   27 timing knock-outs by op type (bit mask, wrong results): 1 GroupNorm backward, 2 GroupNorm forward, 4 LayerNorm forward, 8 cross-attention
 //      backward, 16 self-attention backward, 32 self-attention forward, 64 cross-attention forward
 //   28 wave priority (s_setprio 0..3) of the LayerNorm backward dx kernel
-//   30 pipelined one-wave-per-SIMD kernels, bit mask: 1 = the forward's one-round linear problems on gemm_pl.hip, 2 = the one-round linear dgrads,
+//   30 pipelined one-wave-per-SIMD kernels, bit mask (0 = the shipped policy = 3; 64 = none): 1 = the forward's one-round linear problems on gemm_pl.hip, 2 = the one-round linear dgrads,
 //      16 = every plain linear NT / NN problem whose tiles are whole rounds of 256, 32 = every plain linear NT / NN problem;
 //      4 = the one-round 3x3 convolutions forward on gemm.hip's configuration 5 / 6 (unsplit instead of two co-resident halves), 8 = their dgrads
+//   31 = 1: gemm_pl.hip WITH its L2 prefetch wave (measured: no gain)
 //   29 = 1: weight-gradient GEMMs that use no split-K slab and whose operands come from the caller's stream are launched any-order on the side stream
 // The product library has NO knobs: KNOB(i) is the constant 0 (= the shipped policy) and every experiment branch below it folds away.
 // The diagnostics build (`build.py --diag`: -DSDXL_DIAG -> libsdxlstep_diag.so, include/sdxlstep_diag.h) keeps the table, sdxl_set_knob,
@@ -202,6 +203,7 @@ int launch_cr256(const GemmP& p, int bn, hipStream_t st, bool deep = false, bool
 int cr256_wgrad_cfg(int M, int N, long red, bool bias);
 // software-pipelined one-wave-per-SIMD kernel (gemm_pl.hip): 128 x 160 / 128 x 128 x 64 tiles, 4 waves, 4-deep ring; linear NT / NN, plain bf16 epilogue
 bool pl_applicable(const GemmP& p);
+void pl_set_prefetch(int on);
 int launch_pl(const GemmP& p, int bn, hipStream_t st);      // bn = 160 / 128 / 0 (160 where N % 160 == 0)
 int gemm_ln_cfg(int M, int N, int K);                  // GemmP::ln_x: the configuration such a launch takes (GemmP::cfg), 0 = not possible for this shape
 size_t gemm_ln_part_floats(int M, int N);

@@ -123,6 +123,7 @@ TEST_HOOK_SIGNATURES = {
     "sdxl_set_gemm_mode": [_i],
     "sdxl_debug_act_checksums": [_vp, _P(C.c_ulonglong), _i, _P(_i), _i],
     "sdxl_op_exchange_shadow": [_vp, _sz, _i, _i, _f, _vp],
+    "sdxl_op_gemm_ld": [_i, _vp, _vp, _vp, _i, _i, _i, C.c_long, C.c_long, C.c_long, _vp, _vp, C.c_long, _i, _vp],
     "sdxl_op_linear_dgrad_delta": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
 }
 # include/sdxlstep_diag.h part 2: experiment ABI, exported by libsdxlstep_diag.so only
