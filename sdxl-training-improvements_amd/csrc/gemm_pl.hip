@@ -86,8 +86,8 @@ __device__ __forceinline__ void pl_static_for(F&& f) { pl_static_for_impl(f, std
 //     lines the workgroups of its XCD are about to stage (one 4-byte load per 128-byte line, L1 bypassed) -- an L2 prefetch.  Why: inside the
 //     step a launch's operands come from HBM, not from the L2 / memory-side cache a 20-launch loop leaves them in, and three K-steps in flight
 //     (110 KB per CU) cover ~1.5 us at this kernel's pace: 47 us -> 61 us on NT 4096 x 1280 x 5120 with cold operands
-//     (profiles/r05d_pl_insitu.txt).  MEASURED AND NOT USED (launch_pl: off): with any lead (6 / 10 / 20 steps) the cold staging rate stays at
-//     0.56 us per K-step (profiles/r05e_stage_rate2_prefetch.txt) -- the cold penalty is not the latency of the first touch -- and on
+//     (profiles/r05e_pl_insitu.txt).  MEASURED AND NOT USED (launch_pl: off): with any lead (6 / 10 / 20 steps) the cold staging rate stays at
+//     0.56 us per K-step (profiles/r05a_stage_rate2.txt) -- the cold penalty is not the latency of the first touch -- and on
 //     warm operands the extra wave costs 7 %.  Kept behind configuration 8 so that the measurement can be repeated.  The four compute waves of the 4 (n-tiles) x 8 (m-tiles) workgroups of an XCD request every line 4 or
 //     8 times at once; the prefetch waves split the lines among those workgroups (52 lines per CU and K-step: one load instruction).
 //     XCD co-location decides only who warms which L2 (speed); the wave joins the workgroup's barriers, nothing else.
