@@ -33,7 +33,7 @@ FLOP_PER_IMAGE_1344x768 = 19.93e12          # 1344x768 (lat
 FLOP_PER_IMAGE_512 = 4.77e12
 PEAK_BF16_TFLOPS = 2516.6           # 256 CU x 2.4 GHz x 4096 FLOP/clk/CU (MI355X dense bf16 MFMA)
 ATTN_FLOP_PER_IMAGE_1024 = 2.351e12   # of those, attention QK^T / PV fwd + bwd (3.135 of 27.045 TFLOP per B = 4 forward)
-PMC_SUMMARY = "r04_pmc_step_summary.json"     # committed PMC passes (profiles/tools/measure_step.sh), stamped with the commit they were taken at
+PMC_SUMMARY = "r05_pmc_step_summary.json"     # committed PMC passes (profiles/tools/measure_step.sh), stamped with the commit they were taken at
 
 
 def kernels_changed_since(commit):
@@ -432,7 +432,7 @@ def main():
                                  "profiles/tools/measure_step.sh" % traffic_commit) if stale else
                                 ("bytes per step over all launches of the family (fabric side, MALL hits included), PMC passes at commit %s; "
                                  "algorithmic operand + result bytes ~94e9" % traffic_commit),
-                "kernel": "gemm_kernel<NT|NN|TN, conv|linear> (128-row tiles) + gemm256_kernel (256x256 tiles) + conv_wgrad3_kernel (3x3 wgrad, three taps per workgroup) + wgrad256_kernel (long-reduction linear wgrad, 256x160 tiles) + cr256_kernel (co-resident 256-row tiles: level-2 linear wgrads): bf16 MFMA 16x16x32",
+                "kernel": "gemm_kernel<NT|NN|TN, conv|linear> (128-row tiles) + gemm256_kernel (256x256 tiles) + conv_wgrad3_kernel (3x3 wgrad, three taps per workgroup) + wgrad256_kernel (long-reduction linear wgrad, 256x160 tiles) + cr256_kernel (co-resident 256-row tiles: level-2 linear wgrads) + pl_kernel (software-pipelined one-wave-per-SIMD 128x160 tiles: one-round linear forward / dgrad): bf16 MFMA 16x16x32",
                 "launches_per_step": n.value // args.profile_steps,
                 "gemm_ms_per_step": round(ms.value / args.profile_steps, 2),
                 "gemm_tflop_per_step": round(fl.value / args.profile_steps / 1e12, 2)}

@@ -64,10 +64,14 @@ __global__ __launch_bounds__(NW * 64 + 64, 1) void stage_kernel(const char* __re
       const char* src = nullptr;
       if (lane < 32) src = A + (size_t)(by * RA + ln * 32 + lane) * lda_b + (size_t)tp * SEG;
       else if (lane < 52) src = B + (size_t)(bx * RB + lm * 20 + (lane - 32)) * ldb_b + (size_t)tp * SEG;
-      if (src) asm volatile("global_load_dword %0, %1, off sc1" : "+v"(snk) : "v"(src) : "memory");
+      if (src) {
+        if (pf_lead < 100) asm volatile("global_load_dword %0, %1, off sc1" : "+v"(snk) : "v"(src) : "memory");
+        else asm volatile("global_load_dword %0, %1, off" : "+v"(snk) : "v"(src) : "memory");      // (lead + 100: plain loads, L1 + L2 allocate)
+      }
     };
-    for (int tp = S - 1; tp < pf_lead; ++tp) touch(tp);
-    for (int t = 0; t < T; ++t) { __builtin_amdgcn_s_barrier(); touch(t + pf_lead); }
+    const int lead = pf_lead % 100;
+    for (int tp = S - 1; tp < lead; ++tp) touch(tp);
+    for (int t = 0; t < T; ++t) { __builtin_amdgcn_s_barrier(); touch(t + lead); }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(snk) :: "memory");
     __syncthreads();
     if (snk == 0x12345678u) sink[1] = snk;
@@ -79,7 +83,11 @@ __global__ __launch_bounds__(NW * 64 + 64, 1) void stage_kernel(const char* __re
   const unsigned vo_a = PACKED ? lane * 16u : (unsigned)(lane >> 3) * lda_b + (((lane & 7) ^ (lane >> 3)) << 4);
   const unsigned vo_b = PACKED ? lane * 16u : (unsigned)(lane >> 3) * ldb_b + (((lane & 7) ^ (lane >> 3)) << 4);
   (void)PPW;
-  auto issue = [&](int t, int slot) {
+  // pf_lead == 1000: every XCD walks K from its own starting point (xcd * T / 8, wrapping): the 2 (A panels) / 4 (B panels) XCDs that share a
+  // panel never ask the memory side for the same lines at the same time
+  const int rot = pf_lead == 1000 ? ((id & 7) * T) / 8 : 0;
+  auto issue = [&](int t0, int slot) {
+    const int t = t0 + rot >= T ? t0 + rot - T : t0 + rot;
 #pragma unroll
     for (int j = 0; j < PPWC; ++j) {
       const int pc = wave + NW * j;                 // 0 .. 35: pieces 0-15 = A tile, 16-35 = B tile
@@ -125,7 +133,7 @@ static float time_one(const char* A, const char* B, unsigned lda_b, unsigned ldb
     for (int rep = 0; rep < 3; ++rep) {
       hipEventRecord(e0, 0);
       for (int i = 0; i < g_nset; ++i)
-        hipLaunchKernelGGL((stage_kernel<NW, PACKED, POL>), dim3(256), dim3(NW * 64 + (g_pf ? 64 : 0)), smem, 0, A + (size_t)i * g_strideA, B + (size_t)i * g_strideB, lda_b, ldb_b, T, xcd, same, sink, g_pf);
+        hipLaunchKernelGGL((stage_kernel<NW, PACKED, POL>), dim3(256), dim3(NW * 64 + ((g_pf && g_pf != 1000) ? 64 : 0)), smem, 0, A + (size_t)i * g_strideA, B + (size_t)i * g_strideB, lda_b, ldb_b, T, xcd, same, sink, g_pf);
       hipEventRecord(e1, 0); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       if (ms / g_nset < best) best = ms / g_nset;
@@ -138,7 +146,7 @@ static float time_one(const char* A, const char* B, unsigned lda_b, unsigned ldb
   float best = 1e9f;
   for (int rep = 0; rep < 5; ++rep) {
     hipEventRecord(e0, 0);
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((stage_kernel<NW, PACKED, POL>), dim3(256), dim3(NW * 64 + (g_pf ? 64 : 0)), smem, 0, A, B, lda_b, ldb_b, T, xcd, same, sink, g_pf);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((stage_kernel<NW, PACKED, POL>), dim3(256), dim3(NW * 64 + ((g_pf && g_pf != 1000) ? 64 : 0)), smem, 0, A, B, lda_b, ldb_b, T, xcd, same, sink, g_pf);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (ms / 10 < best) best = ms / 10;
