@@ -1,0 +1,104 @@
+// How much of another instruction's issue does an MFMA hide when ONE wave owns its SIMD?  (review item 12: the 32x32x16 arm)
+// 256 workgroups x 4 waves (one per SIMD); per "K-step" the same 655 360 flops per wave either as 40 v_mfma_f32_16x16x32_bf16 or as 20
+// v_mfma_f32_32x32x16_bf16, alone or with the fillers of gemm_pl.hip's K-step between them: 18 (20) ds_read_b128 of fragments into a second
+// register set, 9 LDS-DMA pieces (s_add m0 / s_nop / buffer_load ... lds) from an L2-resident buffer.  Reports shader cycles per K-step (s_memtime).
+//   hipcc --offload-arch=gfx950 -O3 -I sdxl-training-improvements_amd/csrc profiles/tools/mfma_shadow.hip -o profiles/tools/mfma_shadow
+#include "common.h"
+#include <cstdio>
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+template <int OFF>
+__device__ __forceinline__ void dma(i32x4 srd, unsigned voff, unsigned soff, unsigned base) {
+  asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff), "s"(srd), "s"(soff), "s"(base), "n"(OFF) : "memory", "scc");
+}
+typedef const __attribute__((address_space(3))) bf16x8 lds_bf16x8;
+
+// SHAPE 16 / 32; READS: fragment reads between the MFMAs; DMA: the nine pieces
+template <int SHAPE, bool READS, bool DMA>
+__global__ __launch_bounds__(256, 2) void k(const bf16* __restrict__ src, float* out, unsigned long long* cyc, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const i32x4 srd = make_srd(src, 0x7FFFFFFFu);
+  const unsigned voff = lane * 16u;
+  const unsigned lbase = lds_addr_of(smem) + wave * 36864u;
+  unsigned raddr = lds_addr_of(smem) + wave * 36864u + lane * 16u;
+  asm volatile("" : "+v"(raddr));
+  bf16x8 fa[2][10], fb[2][10];
+  for (int s = 0; s < 2; ++s) for (int i = 0; i < 10; ++i) { for (int e = 0; e < 8; ++e) { fa[s][i][e] = (bf16)(0.001f * (lane + i + e)); fb[s][i][e] = (bf16)(0.002f * (lane - i + e)); } }
+  f32x4 a16[20];
+  f32x16_t a32[5];
+  for (int i = 0; i < 20; ++i) a16[i] = (f32x4){0, 0, 0, 0};
+  for (int i = 0; i < 5; ++i) for (int e = 0; e < 16; ++e) a32[i][e] = 0.f;
+  unsigned so = 0;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+    // two half-steps; set cur = it-half parity
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      constexpr int NM = SHAPE == 16 ? 20 : 10;      // MFMAs per half-step
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        if (SHAPE == 16) a16[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[h][m % 5], fb[h][m / 5], a16[m], 0, 0, 0);
+        else a32[m % 5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][m % 5], fb[h][m / 5 + 5], a32[m % 5], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (READS) {
+          // gemm_pl: 9 reads per half-step behind every second 16x16 MFMA; the 32x32 decomposition: 10 reads, one per MFMA
+          if (SHAPE == 16 ? (m % 2 == 0 && m / 2 < 9) : true) {
+            const int r = SHAPE == 16 ? m / 2 : m;
+            bf16x8 v = *(lds_bf16x8*)(size_t)(raddr + (unsigned)(r * 2048));
+            if (r < 5) fa[h ^ 1][r] = v; else fb[h ^ 1][r - 5 + (SHAPE == 16 ? 0 : 0)] = v;
+          }
+        }
+        if (DMA) {
+          // 5 pieces in the first half-step, 4 in the second, spread evenly
+          constexpr int NP = 5;
+          const int np = h == 0 ? 5 : 4;
+          if (SHAPE == 16) { if (m % 4 == 1 && m / 4 < np) { if (m / 4 == 0) dma<0>(srd, voff, so, lbase); else if (m / 4 == 1) dma<4096>(srd, voff, so, lbase); else if (m / 4 == 2) dma<8192>(srd, voff, so, lbase); else if (m / 4 == 3) dma<12288>(srd, voff, so, lbase); else dma<16384>(srd, voff, so, lbase); } }
+          else { if (m % 2 == 1 && m / 2 < np) { if (m / 2 == 0) dma<0>(srd, voff, so, lbase); else if (m / 2 == 1) dma<4096>(srd, voff, so, lbase); else if (m / 2 == 2) dma<8192>(srd, voff, so, lbase); else if (m / 2 == 3) dma<12288>(srd, voff, so, lbase); else dma<16384>(srd, voff, so, lbase); } }
+          (void)NP;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (DMA && h == 0) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    }
+    so = (so + 1024u) & 0xFFFFu;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int i = 0; i < 20; ++i) s += a16[i][0];
+  for (int i = 0; i < 5; ++i) s += a32[i][0];
+  for (int i = 0; i < 10; ++i) s += (float)fa[0][i][0] + (float)fb[1][i][0];
+  if (s == 12345.678f) out[0] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+template <int SHAPE, bool READS, bool DMA>
+static void run(const bf16* src, float* out, unsigned long long* cyc, const char* name) {
+  const int iters = 2000, smem = 4 * 36864;
+  hipFuncSetAttribute((const void*)k<SHAPE, READS, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((k<SHAPE, READS, DMA>), dim3(256), dim3(256), smem, 0, src, out, cyc, 200);
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL((k<SHAPE, READS, DMA>), dim3(256), dim3(256), smem, 0, src, out, cyc, iters);
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+  const double us = ms * 1e3 / iters;
+  printf("%-58s %8.1f cycles / K-step  %6.3f us  -> %7.1f TFLOP/s chip-wide (4 waves x 256 CUs)\n", name, (double)c / iters, us, 655360.0 * 4 * 256 / us / 1e6);
+}
+
+int main() {
+  bf16* src; float* out; unsigned long long* cyc;
+  hipMalloc(&src, 1 << 20); hipMemset(src, 0x11, 1 << 20); hipMalloc(&out, 64); hipMalloc(&cyc, 64);
+  run<16, false, false>(src, out, cyc, "40 x 16x16x32, nothing else");
+  run<32, false, false>(src, out, cyc, "20 x 32x32x16, nothing else");
+  run<16, true, false>(src, out, cyc, "40 x 16x16x32 + 18 ds_read_b128");
+  run<32, true, false>(src, out, cyc, "20 x 32x32x16 + 20 ds_read_b128");
+  run<16, false, true>(src, out, cyc, "40 x 16x16x32 + 9 LDS-DMA pieces");
+  run<32, false, true>(src, out, cyc, "20 x 32x32x16 + 9 LDS-DMA pieces");
+  run<16, true, true>(src, out, cyc, "40 x 16x16x32 + 18 reads + 9 pieces (gemm_pl's K-step)");
+  run<32, true, true>(src, out, cyc, "20 x 32x32x16 + 20 reads + 9 pieces");
+  return 0;
+}

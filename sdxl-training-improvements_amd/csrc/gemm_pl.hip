@@ -8,7 +8,8 @@
 // are read into a second register set, and the DMA pieces of the step three ahead are issued, BETWEEN the MFMAs of the current half-step --
 // at most one LDS read and one DMA piece per MFMA, so that every non-matrix instruction issues in the shadow of a 16-cycle MFMA instead of
 // in a block of its own (a wave issues in order: 25 instructions between two groups of MFMAs are 100 cycles of idle matrix pipe --
-// the first form of this loop, gemm.hip configuration 5, measured 0.60 us per step).  The instruction count is cut to fit those shadows:
+// the first form of this loop, gemm.hip configuration 5, measured 0.60 us per step).  In cycles the fillers are then nearly free
+// (profiles/r05l_mfma_shadow.txt: 676 -> 728 per K-step); in time they are not: the package clocks down under the added LDS / L1 traffic.  The instruction count is cut to fit those shadows:
 // buffer_load ... lds through raw descriptors (one constant per-lane offset per piece, one running scalar offset per operand, the LDS
 // destination added straight into M0: 3 instructions per piece instead of 12), out-of-range rows / columns and the pieces beyond the last
 // K-step are offsets beyond num_records (zeros, no traffic, no select in the live loop).
