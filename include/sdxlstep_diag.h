@@ -62,6 +62,9 @@ SDXL_API int sdxl_set_knob(int id, int value);
  * gradient accumulator or NULL, C fp32). */
 SDXL_API int sdxl_set_sk_mode(int mode, int workers);
 SDXL_API int sdxl_sk_error(void* stream, unsigned* out);
+/* *out != 0 iff a LayerNorm-backward epilogue (sdxl_op_linear_dgrad_ln_bwd, knob 26) gave up its in-launch meeting since the last call (bit 0: the ready
+ * flags of its row block's other column tiles, bit 1: a granule): the results of that launch are invalid.  Synchronises the device; clears the word. */
+SDXL_API int sdxl_ln_error(unsigned* out);
 SDXL_API int sdxl_op_gemm_sk(int n, const int* form, const void* const* A, const void* const* B, void* const* C, const int* M,
                     const int* N, const int* K, const void* const* bias, const void* const* resid, const int* accumulate,
                     void* stream);

@@ -1006,6 +1006,10 @@ int sdxl_set_sk_mode(int mode, int workers) {
   gemm_sk_set_workers(workers);
   return 0;
 }
+int sdxl_ln_error(unsigned* out) {
+  ARG_CHECK(out != nullptr, "ln_error: null output");
+  return gemm_ln_error(out);
+}
 int sdxl_sk_error(void* st, unsigned* out) {
   ARG_CHECK(out, "null output");
   return gemm_sk_error((hipStream_t)st, out);

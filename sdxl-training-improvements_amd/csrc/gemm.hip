@@ -33,6 +33,9 @@ static int g_sk_mode = 0;     // stream-K kernel (gemm_sk.hip, diagnostics build
 #endif
 
 static constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
+// LayerNorm-backward epilogue (diagnostics build): set when a workgroup gave up waiting for the other column tiles of its row block (bit 0: their
+// ready flags, bit 1: a granule) -- the results of that launch are invalid; read and cleared by gemm_ln_error (sdxl_ln_error)
+__device__ unsigned g_ln_spin_error = 0;
 // sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), valid in the row's lane 15: four row_shr steps on the VALU, zeros shifted in
 __device__ __forceinline__ float row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
@@ -907,6 +910,7 @@ __global__ __launch_bounds__(NW * 64, PL ? 2 : gemm_occupancy(BN, S, BK, NW)) vo
         ok = __all(f == (unsigned)p.ln_epoch);
         if (!ok) __builtin_amdgcn_s_sleep(4);
       } while (!ok && ++spins < (1 << 22));
+      if (!ok && tid == 0) atomicOr(&g_ln_spin_error, 1u);      // gave up: surfaced by sdxl_ln_error, like the stream-K kernel's error word
     }
     __syncthreads();
     {   // thread (row, h) gathers the tiles c = 2 k + h (the tags are still checked: a granule that is not there yet is polled for)
@@ -931,6 +935,7 @@ __global__ __launch_bounds__(NW * 64, PL ? 2 : gemm_occupancy(BN, S, BK, NW)) vo
         for (int k = 0; k < KC; ++k) ok = ok && (a[k] >> 32) == (tag >> 32) && (b[k] >> 32) == (tag >> 32);
         if (!ok) __builtin_amdgcn_s_sleep(8);
       } while (!ok && ++spins < (1 << 20));
+      if (!ok) atomicOr(&g_ln_spin_error, 2u);
       float S1 = 0.f, S2 = 0.f;      // fixed order: the same sums in every workgroup of the row block, run to run
 #pragma unroll
       for (int k = 0; k < KC; ++k)
@@ -1195,6 +1200,15 @@ size_t gemm_ln_part_floats(int M, int N) {      // GemmP::ln_part: two 8-byte gr
 size_t gemm_ln_pcol_floats(int M, int N) { return (size_t)cdiv(M, BM) * 2 * N; }                      // GemmP::ln_pcol
 int gemm_ln_rowblocks(int M) { return cdiv(M, BM); }
 
+#ifdef SDXL_DIAG
+int gemm_ln_error(unsigned* out) {      // != 0: a LayerNorm-backward epilogue gave up its in-launch meeting since the last call (results invalid); clears the word
+  HIP_CHECK_RET(hipDeviceSynchronize());
+  HIP_CHECK_RET(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ln_spin_error), sizeof(unsigned)));
+  const unsigned z = 0;
+  HIP_CHECK_RET(hipMemcpyToSymbol(HIP_SYMBOL(g_ln_spin_error), &z, sizeof(unsigned)));
+  return 0;
+}
+#endif
 size_t gemm_slab_floats(int M, int N, int taps, int splitk) { return splitk > 1 ? (size_t)splitk * M * N * taps : 0; }
 
 void gemm_defaults(GemmP* p) {

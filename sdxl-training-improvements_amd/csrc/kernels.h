@@ -183,6 +183,7 @@ void gemm_set_sk_mode(int mode);                      // 0 never / 1 policy (gem
 int gemm_sk_mode();
 bool gemm_use_sk(const GemmP& p);
 void gemm_sk_set_workers(int n);                      // > 0: force the worker count (microbenchmarks), 0: policy
+int gemm_ln_error(unsigned* out);                         // != 0: a LayerNorm-backward epilogue (GemmP::ln_x) gave up waiting for its row block's other tiles; clears it
 int gemm_sk_error(hipStream_t st, unsigned* out);     // != 0: an owner gave up waiting for a partial tile (results invalid)
 #endif
 // 3x3 weight gradient, three taps per workgroup (conv_wgrad3.hip): same-size stride-1 convolutions whose image width is a multiple of 64

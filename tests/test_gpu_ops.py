@@ -830,6 +830,9 @@ def test_linear_dgrad_with_layernorm_backward_epilogue(L, M, Cc, Kr, acc, keep_d
     lib.check(L.sdxl_op_linear_dgrad_ln_bwd(ptr(dyl), ptr(w), ptr(x), C.cast(stats.data_ptr(), C.POINTER(C.c_float)), ptr(gamma), ptr(addend),
                                             ptr(dx), ptr(dy_out), C.cast(pcol.data_ptr(), C.POINTER(C.c_float)), M, Cc, Kr, stream()))
     torch.cuda.synchronize()
+    err = C.c_uint(99)
+    lib.check(L.sdxl_ln_error(C.byref(err)))
+    assert err.value == 0, f"LayerNorm-backward epilogue gave up its in-launch meeting (error word {err.value})"
     # reference: dy = bf16(dY W), then the LayerNorm backward of it in fp32
     dy_ref = (dyl.float() @ w.float()).to(torch.bfloat16)
     xr = x.float().requires_grad_(True)
