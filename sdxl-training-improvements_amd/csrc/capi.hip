@@ -807,7 +807,14 @@ int sdxl_op_layernorm_bwd(const void* x, const void* dy, const void* gamma, cons
   if (KNOB(10) != 2) {     // the plan's default: lean dx kernel + parameter gradients as a pass of their own
     CHK(launch_layernorm_bwd((const bf16*)x, (const bf16*)dy, (const bf16*)gamma, stats, (bf16*)dx,
                              accumulate ? (const bf16*)dx : nullptr, nullptr, nullptr, M, C, (hipStream_t)st));
-    return launch_layernorm_param_grads((const bf16*)x, (const bf16*)dy, stats, dgamma, dbeta, M, C, (hipStream_t)st);
+    if (KNOB(10) == 3) return launch_layernorm_param_grads((const bf16*)x, (const bf16*)dy, stats, dgamma, dbeta, M, C, (hipStream_t)st);
+    LnRedBatch b;
+    b.n = 1;
+    float* part;
+    CHK(test_slab(layernorm_bwd_part_floats(M, C), &part));
+    b.e[0].part = part; b.e[0].dgamma = dgamma; b.e[0].dbeta = dbeta; b.e[0].C = C; b.e[0].nblk = layernorm_param_partial_rows(M, C);
+    CHK(launch_layernorm_param_partials((const bf16*)x, (const bf16*)dy, stats, part, M, C, (hipStream_t)st));
+    return launch_ln_param_reduce(b, (hipStream_t)st);
   }
   LnRedBatch b;
   b.n = 1;

@@ -549,9 +549,18 @@ struct LayerNormOp : Op {
       if (KNOB(25) != 3)
       CHK(launch_layernorm_bwd(p.P(x), p.GP(dy_off), p.eng->Wp(gm), p.F(stats_off), p.GP(dx.out), p.GP(dx.addend), nullptr, nullptr, (int)x->rows, C, st));
       const bf16* xp = p.P(x); const bf16* dyp = p.GP(dy_off); const float* sp = p.F(stats_off);
-      float* dg = p.eng->Gp(gm); float* db = p.eng->Gp(bt); const int Mr = (int)x->rows, Cc = C;
+      const int Mr = (int)x->rows, Cc = C;
       if (KNOB(25) == 1) return 0;
-      return side_leaf(p, st, [=](hipStream_t s2) -> int { return launch_layernorm_param_grads(xp, dyp, sp, dg, db, Mr, Cc, s2); });
+      if (KNOB(10) == 3) {      // (A/B runs: the column-sum pass with one atomic per column and block)
+        float* dg = p.eng->Gp(gm); float* db = p.eng->Gp(bt);
+        return side_leaf(p, st, [=](hipStream_t s2) -> int { return launch_layernorm_param_grads(xp, dyp, sp, dg, db, Mr, Cc, s2); });
+      }
+      // partial rows by plain stores into the op's own buffer; the segment's flush folds them (queued leaves run before it on the side stream)
+      float* part = p.F(part_off);
+      LnRedEntry r;
+      r.part = part; r.dgamma = p.eng->Gp(gm); r.dbeta = p.eng->Gp(bt); r.C = C; r.nblk = layernorm_param_partial_rows(Mr, Cc);
+      p.eng->ln_pending.push_back(r);
+      return side_leaf(p, st, [=](hipStream_t s2) -> int { return launch_layernorm_param_partials(xp, dyp, sp, part, Mr, Cc, s2); });
     }
     LnRedEntry r;
     r.part = p.F(part_off); r.dgamma = p.eng->Gp(gm); r.dbeta = p.eng->Gp(bt); r.C = C;

@@ -12,7 +12,7 @@
 //       gather; = 512: stride-2 forward / weight gradient on phase planes (OFF by default: neutral in the step)
 //   3, 4 split-K factor of the long linear dgrads and its N threshold; 5 = 80: GEGLU packed in groups of 80
 //   6, 7 forced configuration of the linear / conv dgrads, 8 N threshold of knob 6
-//   9 = 1: no wgrad256 kernel; 10 = 2: fused LayerNorm backward; 11 = 1: the round-2 LayerNorm dx kernel
+//   9 = 1: no wgrad256 kernel; 10 = 2: fused LayerNorm backward, 3: LayerNorm parameter gradients by the atomic column-sum pass; 11 = 1: the round-2 LayerNorm dx kernel
 //   12 = 1: no three-tap conv weight gradient; 13 split-K workgroup target of conv_wgrad3 / wgrad256 (144); 14 = 2: its W = 32 form
 //   15 = 1: no half-height tail workgroups in the 256 x 256 kernel
 //   16 co-resident 256-row kernel for the level-2 linear weight gradients: 0 policy, 1 off, 2 / 3 = 128 / 160-column tiles wherever allowed;
@@ -272,6 +272,10 @@ size_t layernorm_bwd_part_floats(int M, int C);
 int launch_layernorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const float* stats, bf16* dx,
                          const bf16* addend, float* part, int* nblk_out, int M, int C, hipStream_t st);
 int launch_layernorm_param_grads(const bf16* x, const bf16* dy, const float* stats, float* dgamma, float* dbeta, int M, int C, hipStream_t st);
+// the same sums as layernorm_param_partial_rows(M, C) partial rows part[rows][2][C] (plain stores, inside layernorm_bwd_part_floats(M, C));
+// an LnRedEntry with nblk = that row count folds them into the gradients (launch_ln_param_reduce)
+int layernorm_param_partial_rows(int M, int C);
+int launch_layernorm_param_partials(const bf16* x, const bf16* dy, const float* stats, float* part, int M, int C, hipStream_t st);
 #define LN_RED_MAX 64
 struct LnRedEntry { const float* part; float* dgamma; float* dbeta; int nblk, C; };
 struct LnRedBatch { LnRedEntry e[LN_RED_MAX]; int n; };   // passed by value as the kernel argument (2 KiB)

@@ -692,6 +692,77 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const bf16* __restrict_
   }
 }
 
+// dgamma | dbeta partial sums of one LayerNorm as PLAIN STORES: part[chunk][2][C], folded by ln_param_reduce_kernel for a whole batch of
+// LayerNorms at the segment's end.  (The column-sum form above adds every block's 2 C sums with device-scope atomics: 128 chunks x 2 560
+// columns = 327 k fabric atomics per LayerNorm, 30 us for a 21 MB pass that reads at 7 us -- profiles/r05m_ln_params.txt.)
+// CV = 16-byte column vectors per block row: 32 (256 columns x 8 row lanes) or 16 (128 columns x 16 row lanes: C = 640 is 5 whole blocks).
+template <int CV>
+__global__ __launch_bounds__(256) void ln_param_partials_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                                                const float* __restrict__ stats, float* __restrict__ part, int M, int C,
+                                                                int rows_per_chunk) {
+  constexpr int RL = 256 / CV, W = CV * 8;
+  __shared__ float sred[2][RL][W + 8];
+  const int cv = threadIdx.x % CV, rl = threadIdx.x / CV;
+  const int c0 = blockIdx.x * W + cv * 8;
+  float sg[8], sb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sg[e] = 0.f; sb[e] = 0.f; }
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+  if (c0 < C) {
+    for (int r = r0 + rl; r < r1; r += 4 * RL) {      // four rows in flight per thread
+      bf16x8 d[4], v[4];
+      float mean[4], rstd[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int rr = min(r + k * RL, M - 1);
+        d[k] = *(const bf16x8*)(dy + (long)rr * C + c0);
+        v[k] = *(const bf16x8*)(x + (long)rr * C + c0);
+        mean[k] = stats[(long)rr * 2];
+        rstd[k] = stats[(long)rr * 2 + 1];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (r + k * RL >= r1) break;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dv = (float)d[k][e];
+          sg[e] += dv * ((float)v[k][e] - mean[k]) * rstd[k];
+          sb[e] += dv;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sred[0][rl][cv * 8 + e] = sg[e]; sred[1][rl][cv * 8 + e] = sb[e]; }
+  __syncthreads();
+  const int c = blockIdx.x * W + threadIdx.x;
+  if (threadIdx.x < W && c < C) {
+    float g = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < RL; ++k) { g += sred[0][k][threadIdx.x]; b += sred[1][k][threadIdx.x]; }
+    float* o = part + (size_t)blockIdx.y * 2 * C;
+    o[c] = g;
+    o[C + c] = b;
+  }
+}
+// chunks (= partial rows) of launch_layernorm_param_partials: ~1024 blocks, whole unrolled iterations per chunk, at most 256 chunks
+static void ln_partials_geom(int M, int C, int* cv, int* colblocks, int* rows_per_chunk, int* chunks) {
+  *cv = C % 256 == 0 ? 32 : 16;
+  const int W = *cv * 8, quantum = 4 * (256 / *cv);
+  *colblocks = cdiv(C, W);
+  int want = 1024 / *colblocks;
+  want = want < 1 ? 1 : (want > 256 ? 256 : want);
+  int rpc = cdiv(M, want);
+  rpc = cdiv(rpc, quantum) * quantum;
+  *rows_per_chunk = rpc;
+  *chunks = cdiv(M, rpc);
+}
+int layernorm_param_partial_rows(int M, int C) {
+  int cv, cb, rpc, chunks;
+  ln_partials_geom(M, C, &cv, &cb, &rpc, &chunks);
+  return chunks;
+}
+
 static void col_reduce_geom(int M, int C, dim3* grid, int* rows_per_chunk) {
   int colblocks = cdiv(C, 256);
   int chunks = 1024 / colblocks;
@@ -714,7 +785,8 @@ static void ln_bwd_geometry(int M, int C, int* lpr, int* iters, int* nblk) {
 size_t layernorm_bwd_part_floats(int M, int C) {
   int lpr, iters, nblk;
   ln_bwd_geometry(M, C, &lpr, &iters, &nblk);
-  return (size_t)nblk * 2 * C;
+  const int rows = layernorm_param_partial_rows(M, C);      // (the parameter-gradient leaf pass writes its partial rows into the same buffer)
+  return (size_t)(nblk > rows ? nblk : rows) * 2 * C;
 }
 // dx, and with `part` the per-block dgamma | dbeta partial sums (part[nblk][2][C], *nblk returned) in the same pass
 int launch_layernorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const float* stats, bf16* dx, const bf16* addend,
@@ -766,9 +838,14 @@ int launch_layernorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const
 int launch_ln_param_reduce(const LnRedBatch& b, hipStream_t st) {
   if (b.n <= 0) return 0;
   ARG_CHECK(b.n <= LN_RED_MAX, "ln_param_reduce: %d entries", b.n);
-  int cmax = 0;
-  for (int i = 0; i < b.n; ++i) cmax = b.e[i].C > cmax ? b.e[i].C : cmax;
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * cmax, 256), 16, b.n), dim3(256), 0, st, b);
+  int cmax = 0, nmax = 0;
+  for (int i = 0; i < b.n; ++i) {
+    cmax = b.e[i].C > cmax ? b.e[i].C : cmax;
+    nmax = b.e[i].nblk > nmax ? b.e[i].nblk : nmax;
+  }
+  // up to 256 partial rows: one thread walks a column's rows in order and adds ONE value to the gradient (bitwise reproducible); more
+  // (the fused dx + partials form, 512 rows and up): 16 row chunks, one atomic each
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * cmax, 256), nmax <= 256 ? 1 : 16, b.n), dim3(256), 0, st, b);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -779,6 +856,16 @@ int launch_layernorm_param_grads(const bf16* x, const bf16* dy, const float* sta
   dim3 g2; int rpc;
   col_reduce_geom(M, C, &g2, &rpc);
   hipLaunchKernelGGL(col_reduce_kernel, g2, dim3(256), 0, st, x, dy, (long)C, stats, dgamma, dbeta, M, C, rpc, 0L, 0L);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+// the same sums as partial rows part[layernorm_param_partial_rows(M, C)][2][C] (plain stores; launch_ln_param_reduce folds them)
+int launch_layernorm_param_partials(const bf16* x, const bf16* dy, const float* stats, float* part, int M, int C, hipStream_t st) {
+  ARG_CHECK(C % 128 == 0, "layernorm param partials: C=%d must be a multiple of 128", C);
+  int cv, cb, rpc, chunks;
+  ln_partials_geom(M, C, &cv, &cb, &rpc, &chunks);
+  if (cv == 32) hipLaunchKernelGGL(ln_param_partials_kernel<32>, dim3(cb, chunks), dim3(256), 0, st, x, dy, stats, part, M, C, rpc);
+  else hipLaunchKernelGGL(ln_param_partials_kernel<16>, dim3(cb, chunks), dim3(256), 0, st, x, dy, stats, part, M, C, rpc);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
