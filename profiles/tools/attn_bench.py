@@ -9,6 +9,8 @@ if '--lib' in sys.argv:      # knock-out builds (tools/build_diag_attn.sh)
 L = lib.load(); dev = torch.device('cuda:0')
 import os
 if os.environ.get('SDXL_KNOB20') == '1': lib.check(L.sdxl_set_knob(20, 1))      # diagnostics build: the two-launch self-attention backward
+for kv in os.environ.get('SDXL_KNOBS', '').split(','):      # diagnostics build: SDXL_KNOBS=32=1,20=1
+    if kv: lib.check(L.sdxl_set_knob(int(kv.split('=')[0]), int(kv.split('=')[1])))
 ptr = lambda t: C.c_void_p(t.data_ptr())
 r = lambda *s: torch.randn(*s, device=dev).to(torch.bfloat16)
 ITERS = int(sys.argv[sys.argv.index('--iters') + 1]) if '--iters' in sys.argv else 20
