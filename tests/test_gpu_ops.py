@@ -776,7 +776,7 @@ def test_groupnorm_large_offset_inputs(L):
     report("groupnorm offset 2e4", y, ref.float(), 1e-2)
 
 
-@pytest.mark.parametrize("M,Cc", [(64, 128), (308, 640), (1000, 1280), (16, 256)])
+@pytest.mark.parametrize("M,Cc", [(64, 128), (308, 640), (1000, 1280), (16, 256), (4096, 1280), (4100, 640)])
 def test_layernorm_fwd_bwd(L, M, Cc):
     x = (rnd(M, Cc, seed=50) * 2.0 + 0.5).to(torch.bfloat16)
     gamma, beta = (rnd(Cc, seed=51) * 0.1 + 1.0).to(torch.bfloat16), rnd(Cc, seed=52)
@@ -793,7 +793,8 @@ def test_layernorm_fwd_bwd(L, M, Cc):
     dg = torch.zeros(Cc, dtype=torch.float32, device=dev())
     db = torch.zeros(Cc, dtype=torch.float32, device=dev())
     # 0: the plan's form (lean dx kernel + parameter-gradient pass); 2 (diagnostics build): dx and parameter partial sums in one pass
-    for form in ((0, 2) if lib.DIAG else (0,)):
+    # 3 (diagnostics build): parameter gradients by the column-sum pass with one atomic per column and block (the form before round 5)
+    for form in ((0, 2, 3) if lib.DIAG else (0,)):
         knob(L, 10, form)
         dx.zero_(); dg.zero_(); db.zero_()
         try:
@@ -803,6 +804,10 @@ def test_layernorm_fwd_bwd(L, M, Cc):
         report(f"layernorm dx (form {form})", dx, xr.grad, 1e-2)
         report("layernorm dgamma", dg, gr.grad, 2e-3)
         report("layernorm dbeta", db, br.grad, 2e-3)
+        if form == 0:      # partial rows + one fixed-order sum per column: the same bits on every run
+            dg2, db2 = torch.zeros_like(dg), torch.zeros_like(db)
+            lib.check(L.sdxl_op_layernorm_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(stats), ptr(dx), ptr(dg2), ptr(db2), M, Cc, 0, stream()))
+            assert torch.equal(dg, dg2) and torch.equal(db, db2), "layernorm parameter gradients are not reproducible"
     base = rnd(M, Cc, seed=54)          # accumulate form: dx = addend + grad
     dx2 = base.clone()
     lib.check(L.sdxl_op_layernorm_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(stats), ptr(dx2), ptr(dg), ptr(db), M, Cc, 1, stream()))
