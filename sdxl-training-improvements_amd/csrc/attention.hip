@@ -95,6 +95,20 @@ __device__ __forceinline__ void tile_dma(const TileSrc& s, int t, int nrows, bf1
 __device__ __forceinline__ void landed(bf16x8& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void landed(float& v) { asm volatile("" : "+v"(v)); }
 
+// XCD-aware (block, pair) of a grid of n_inner x nbh workgroups from the linear workgroup id: consecutive ids go round the 8 XCDs, and all
+// workgroups that stream the SAME K / V (or Q / dO) tiles -- the blocks of one (batch, head) pair -- should meet in ONE XCD's L2.  With the
+// plain (block, pair) order every XCD fetched every pair's tiles through the fabric: 55.7 GB per step for ~13 GB of algorithmic attention
+// traffic (profiles/r05_pmc_step_summary.json).
+__device__ __forceinline__ void attn_xcd_map(const AttnP& p, int i, int n_inner, int& inner, int& bh) {
+  if (p.xcd) {
+    const int slot = i >> 3, grp = slot / n_inner;
+    bh = grp * 8 + (i & 7);
+    inner = slot - grp * n_inner;
+  } else {
+    bh = i / n_inner;
+    inner = i - bh * n_inner;
+  }
+}
 // cross-row lane exchanges without the LDS crossbar (ds_bpermute + lgkmcnt wait): gfx950 v_permlane16_swap / v_permlane32_swap
 // trade 16-lane rows (odd rows of the first operand <-> even rows of the second) / wave halves between two registers; with
 // both operands holding x the pair afterwards holds x and x from the partner row / half in every lane.
@@ -152,8 +166,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
 #endif
   __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE_ELEMS];  // K0 V0 K1 V1
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l16 = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  int qblk, bh;
+  attn_xcd_map(p, blockIdx.x, (p.Nq + 127) >> 7, qblk, bh);
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int q0 = qblk * 128 + wave * 32;
   const bf16* Qb = p.Q + (long)b * p.Nq * p.ldq + h * HD;
   const bf16* Kb = p.K + (long)b * p.Nk * p.ldk + h * HD;
   const bf16* Vb = p.V + (long)b * p.Nk * p.ldv + h * HD;
@@ -348,8 +364,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
   }
 #if defined(ATTN_DIAG) && (ATTN_DIAG & 128)
   acc_ph[4] = __builtin_amdgcn_s_memrealtime() - rt0;
-  if (lane == 0 && blockIdx.x < 4 && blockIdx.y == 5)
-    for (int i = 0; i < 6; ++i) g_attn_stamps[(blockIdx.x * 4 + wave) * 6 + i] = acc_ph[i];
+  if (lane == 0 && qblk < 4 && bh == 5)
+    for (int i = 0; i < 6; ++i) g_attn_stamps[(qblk * 4 + wave) * 6 + i] = acc_ph[i];
 #endif
   // finalize
 #pragma unroll
@@ -371,7 +387,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP p) {
   }
 #if defined(ATTN_DIAG) && (ATTN_DIAG & 256)
   if (threadIdx.x == 0) {
-    const int id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int id = blockIdx.x;
     if (id < 4096) {
       unsigned hwid, xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -528,7 +544,9 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnP& p, bf16* sm, const
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   set_wave_prio(p.prio);
   __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE_ELEMS];
-  attn_bwd_dq_body<true>(p, sm, blockIdx.x, blockIdx.y);
+  int qblk, bh;
+  attn_xcd_map(p, blockIdx.x, (p.Nq + 127) >> 7, qblk, bh);
+  attn_bwd_dq_body<true>(p, sm, qblk, bh);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -766,8 +784,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const AttnP p, c
   set_wave_prio(p.prio);
   __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE_ELEMS + 512];
   const int id = blockIdx.x;
-  if (id < ndkv) attn_bwd_dkv_body<KB>(p, sm, id % nkb, id / nkb, 0, p.B * p.H);
-  else attn_bwd_dq_body<false>(p, sm, (id - ndkv) % nqb, (id - ndkv) / nqb);
+  int blk, bh;
+  if (id < ndkv) {
+    attn_xcd_map(p, id, nkb, blk, bh);
+    attn_bwd_dkv_body<KB>(p, sm, blk, bh, 0, p.B * p.H);
+  } else {
+    attn_xcd_map(p, id - ndkv, nqb, blk, bh);      // (ndkv is a multiple of 8 whenever the map is on)
+    attn_bwd_dq_body<false>(p, sm, blk, bh);
+  }
 }
 
 // dK/dV = sum over query splits of the fp32 partials (fixed order), cast to bf16
@@ -816,8 +840,9 @@ static int check_attn(const AttnP& p) {
 int launch_attn_fwd(const AttnP& p, hipStream_t st) {
   if (int e = check_attn(p)) return e;
   if (FILE* f = launch_log()) { fprintf(f, "A,0,%d,%d,%d,%d\n", p.B, p.H, p.Nq, p.Nk); fflush(f); }
-  dim3 grid(cdiv(p.Nq, 128), p.B * p.H);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, st, p);
+  AttnP q = p;
+  q.xcd = (p.B * p.H) % 8 == 0 && KNOB(32) != 1;      // (knob 32 = 1: plain (block, pair) order, A/B runs)
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(p.Nq, 128) * p.B * p.H), dim3(256), 0, st, q);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -832,7 +857,9 @@ static int check_attn_bwd(const AttnP& p) {
 int launch_attn_bwd_dq(const AttnP& p, hipStream_t st) {
   if (int e = check_attn_bwd(p)) return e;
   if (FILE* f = launch_log()) { fprintf(f, "A,1,%d,%d,%d,%d\n", p.B, p.H, p.Nq, p.Nk); fflush(f); }
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(cdiv(p.Nq, 128), p.B * p.H), dim3(256), 0, st, p);
+  AttnP q = p;
+  q.xcd = (p.B * p.H) % 8 == 0 && KNOB(32) != 1;
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(cdiv(p.Nq, 128) * p.B * p.H), dim3(256), 0, st, q);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -861,6 +888,7 @@ int launch_attn_bwd_fused(const AttnP& p, hipStream_t st) {
   if (FILE* f = launch_log()) { fprintf(f, "A,1,%d,%d,%d,%d\nA,2,%d,%d,%d,%d\n", p.B, p.H, p.Nq, p.Nk, p.B, p.H, p.Nq, p.Nk); fflush(f); }
   AttnP q = p;
   q.qsplit = 1;
+  q.xcd = (p.B * p.H) % 8 == 0 && KNOB(32) != 1;
   const long total = (long)p.B * p.Nq * p.H;
   if (!p.delta_ready) hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, q);
   const int nkb = cdiv(p.Nk, 128), nqb = cdiv(p.Nq, 128), nbh = p.B * p.H;

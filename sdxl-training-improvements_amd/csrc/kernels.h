@@ -27,12 +27,13 @@
 //      16 = every plain linear NT / NN problem whose tiles are whole rounds of 256, 32 = every plain linear NT / NN problem;
 //      4 = the one-round 3x3 convolutions forward on gemm.hip's configuration 5 / 6 (unsplit instead of two co-resident halves), 8 = their dgrads
 //   31 = 1: gemm_pl.hip WITH its L2 prefetch wave (measured: no gain)
+//   32 = 1: attention workgroups in plain (block, pair) order instead of the XCD-aware one
 //   29 = 1: weight-gradient GEMMs that use no split-K slab and whose operands come from the caller's stream are launched any-order on the side stream
 // The product library has NO knobs: KNOB(i) is the constant 0 (= the shipped policy) and every experiment branch below it folds away.
 // The diagnostics build (`build.py --diag`: -DSDXL_DIAG -> libsdxlstep_diag.so, include/sdxlstep_diag.h) keeps the table, sdxl_set_knob,
 // the stream-K kernel (gemm_sk.hip), the stride-2 forward / weight gradient on phase planes (GemmP::up2 == 3) and the W = 32 three-tap form:
 // measured, parity-tested experiments the step does not run (DESIGN.md sections 10, 11).
-#define SDXL_NKNOBS 34
+#define SDXL_NKNOBS 36
 #ifdef SDXL_DIAG
 extern int g_knobs[SDXL_NKNOBS];
 #define KNOB(i) (g_knobs[(i)])
@@ -240,6 +241,7 @@ struct AttnP {
   float* part;         // qsplit * B*H * kvtiles*64 * 64 * 2 floats
   int prio;            // wave priority of the backward kernels (see GemmP::prio)
   int delta_ready;     // fused backward: Delta is already in place (written by the epilogue of the GEMM that produced dO, GemmP::delta_out)
+  int xcd;             // set by the launchers: XCD-aware (block, pair) order of the workgroups (attention.hip: attn_xcd_map)
 };
 size_t attn_part_floats(int B, int H, int Nk, int qsplit);
 int attn_pick_qsplit(int B, int H, int Nq, int Nk);
