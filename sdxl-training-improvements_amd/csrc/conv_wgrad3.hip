@@ -41,8 +41,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3_kernel(const GemmP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;               // 4 x 2 waves, wave tile 32 x 80
   const int l16 = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * W3_BN, m0 = blockIdx.y * W3_BM;
-  const int dyrow = blockIdx.z / p.splitk, split = blockIdx.z - dyrow * p.splitk;     // stencil row 0..2, reduction split
+  int bx = blockIdx.x, by = blockIdx.y, dyrow = blockIdx.z / p.splitk, split = blockIdx.z - dyrow * p.splitk;     // stencil row 0..2, reduction split
+  if (p.xcd_bh > 0) xcd_seq_map(p.xcd_bh, 3, bx, by, dyrow, split);      // (gemm_tiles.h: a tile's three stencil rows side by side, splits apart)
+  const int n0 = bx * W3_BN, m0 = by * W3_BM;
   const int tdy = dyrow - 1;
   const int Wm = p.Wm, Hm = p.Hm;
   const int ktiles = p.K / W3_BK;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3_kernel(const GemmP p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 5; ++j) acc[t3][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bool do_bias = p.bias_grad != nullptr && blockIdx.x == 0 && dyrow == 0 && wn == 0;
+  const bool do_bias = p.bias_grad != nullptr && bx == 0 && dyrow == 0 && wn == 0;
   f32x4 accb[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
   bf16x8 ones;
 #pragma unroll
@@ -287,11 +288,13 @@ int launch_conv_wgrad3(const GemmP& p, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(cdiv(p.N, W3_BN), cdiv(p.M, W3_BM), 3 * p.splitk);
+  GemmP q = p;
+  q.xcd_bh = KNOB(34) == 1 ? 0 : xcd_band_rows(grid.x, grid.y, grid.z, W3_BM, W3_BN, 3);
 #ifdef SDXL_DIAG
-  if (p.Wm == 32) hipLaunchKernelGGL(conv_wgrad3_kernel<2>, grid, dim3(512), w3_smem(2), st, p);
+  if (p.Wm == 32) hipLaunchKernelGGL(conv_wgrad3_kernel<2>, grid, dim3(512), w3_smem(2), st, q);
   else
 #endif
-  GEMM_LAUNCH(conv_wgrad3_kernel<1>, grid, dim3(512), w3_smem(1), st, p);
+  GEMM_LAUNCH(conv_wgrad3_kernel<1>, grid, dim3(512), w3_smem(1), st, q);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -87,8 +87,13 @@ template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW, bool KS
 __global__ __launch_bounds__(NW * 64, PL ? 2 : gemm_occupancy(BN, S, BK, NW)) void gemm_kernel(const GemmP pin) {
   GemmP p = pin;
   set_wave_prio(pin.prio);
+  int bx, by, bz = blockIdx.z, ztap = 0;
+  if (FORM == GEMM_TN && pin.xcd_bh > 0) {      // generic XCD-aware order (weight gradients whose grid fits no rectangle): taps inner, splits / problems outer
+    const int tz = pin.group > 1 ? 1 : (int)gridDim.z / pin.splitk;
+    xcd_seq_map(pin.xcd_bh, tz, bx, by, ztap, bz);
+  } else xcd_tile_map(pin.xcd_px, bx, by);                                           // XCD-aware tile order (gemm_tiles.h)
   if (FORM == GEMM_TN && pin.group > 1) {          // grouped launch: this workgroup's problem
-    const int gi = blockIdx.z;
+    const int gi = bz;
     p.A = pin.gA[gi]; p.B = pin.gB[gi]; p.C = pin.gC[gi]; p.bias_grad = pin.gbias_grad[gi]; p.Cb = pin.gCb[gi];
   }
   static_assert(!KSP || (NW == 8 && BK == 64 && FAST && S >= 3 && FORM != GEMM_TN), "split-K groups: 8 waves, BK 64, FAST staging, ring >= 3");
@@ -119,8 +124,6 @@ __global__ __launch_bounds__(NW * 64, PL ? 2 : gemm_occupancy(BN, S, BK, NW)) vo
   const int kg = KSP ? wave >> 2 : 0;             // K-group
   const int wm = KSP ? (wave >> 1) & 1 : wave >> 1, wn = wave & 1;
   const int l16 = lane & 15, g = lane >> 4;
-  int bx, by;
-  xcd_tile_map(p.xcd_px, bx, by);   // XCD-aware tile order (gemm_tiles.h)
 #ifdef SDXL_GEMM_DIAG   // scratch diagnostics only (never defined in the product build): knock out one pipeline component
   constexpr int dbg = SDXL_GEMM_DIAG;       // bit 0: no MFMA, bit 1: no DMA in the main loop, bit 2: no fragment reads,
 #else                                       // bit 3: every workgroup works on tile (0, 0) (all L2 hits after the first touch)
@@ -132,14 +135,19 @@ __global__ __launch_bounds__(NW * 64, PL ? 2 : gemm_occupancy(BN, S, BK, NW)) vo
   // reduction schedule
   int tap_fixed = 0, split = 0;
   if (FORM == GEMM_TN && p.group <= 1) {
-    tap_fixed = blockIdx.z / p.splitk;
-    split = blockIdx.z - tap_fixed * p.splitk;
+    if (pin.xcd_bh > 0) {
+      split = bz;
+      tap_fixed = ztap;
+    } else {
+      tap_fixed = bz / p.splitk;
+      split = bz - tap_fixed * p.splitk;
+    }
   }
   // NT / NN with split-K (linear FAST staging only, launcher-checked: small-M problems -- a 256-row batch is 16 tiles for 256 CUs
   // and a 160-step reduction per tile): split `blockIdx.z` multiplies its K range, the fp32 partial tile goes to its slab,
   // splitk_epilogue_kernel sums the slabs in a fixed order and applies the bf16 epilogue
   constexpr bool NSPLIT = FORM != GEMM_TN && FAST && !KSP;      // (linear, or the same-size stride-1 3x3 gather: K range = taps x channels)
-  if (NSPLIT && p.splitk > 1) split = blockIdx.z;
+  if (NSPLIT && p.splitk > 1) split = bz;
   const int ktiles_per_tap = (p.K + BK - 1) / BK;
   int kt_begin = 0, kt_end;
   if (FORM == GEMM_TN) {
@@ -1230,6 +1238,14 @@ static int launch_k(const GemmP& p, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), FORM == GEMM_TN ? (p.group > 1 ? p.group : p.taps * p.splitk) : p.splitk);
+  if (FORM == GEMM_TN) {      // weight gradients whose tile grid fits no px x py rectangle of XCDs: the generic compact order (gemm_tiles.h)
+    GemmP q = p;
+    const bool rect = p.xcd_px > 0 && grid.x % p.xcd_px == 0 && grid.y % (8 / p.xcd_px) == 0;
+    q.xcd_bh = (!rect && KNOB(34) != 1) ? xcd_band_rows(grid.x, grid.y, grid.z, BM, BN, p.group > 1 ? 1 : p.taps) : 0;
+    GEMM_LAUNCH((gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW, KSP, PL>), grid, dim3(NW * 64), smem, st, q);
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
+  }
   GEMM_LAUNCH((gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW, KSP, PL>), grid, dim3(NW * 64), smem, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;

@@ -81,12 +81,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmP p) {
       xcd_tile_map_id(p.xcd_px, id, p.tail_n0, gy, bx, by);
       by *= 2;                                          // (by counts 128-row halves below)
     } else {
-      half = true;
-      xcd_tile_map_id(0, id - full, p.N / 256 - p.tail_n0, 2 * gy, bx, by);
+      half = true;      // (full is a multiple of 8 whenever a band height is set: the launcher checks)
+      if (p.xcd_bh > 0) xcd_seq_map_id(p.xcd_bh, id - full, p.N / 256 - p.tail_n0, 2 * gy, bx, by);
+      else xcd_tile_map_id(0, id - full, p.N / 256 - p.tail_n0, 2 * gy, bx, by);
       bx += p.tail_n0;
     }
   } else {
-    xcd_tile_map(p.xcd_px, bx, by);
+    int bz;
+    if (p.xcd_bh > 0) xcd_seq_map(p.xcd_bh, bx, by, bz);      // no XCD rectangle fits the grid (16 x 15 tiles): the generic order (one z slice here)
+    else xcd_tile_map(p.xcd_px, bx, by);
     by *= 2;
   }
   const int n0 = bx * 256, m0 = by * 128;
@@ -459,6 +462,17 @@ int launch_gemm256(const GemmP& pin, hipStream_t st) {
       if (cost < best) { best = cost; p.xcd_px = px; }
     }
   }
+  p.xcd_bh = 0;
+  if (KNOB(34) != 1 && !(p.form == GEMM_TN && p.splitk > 1)) {
+    // the generic compact order (gemm_tiles.h: xcd_seq_map) where no rectangle fits -- or fits badly: 16 x 15 tiles (the QKV projection) only
+    // divide as 2 rows x 15 columns per XCD, 4 352 operand rows against 2 816 of a 5 x 6 block
+    const int gx = p.N / 256, gy = p.M / 256;
+    const int bh = xcd_band_rows(gx, gy, 1, 256, 256);
+    const long per = (long)gx * gy / 8 > 0 ? (long)gx * gy / 8 : 1;
+    const double seq_cost = 256.0 * (bh + (double)((per + bh - 1) / bh));
+    const double rect_cost = p.xcd_px > 0 ? (double)p.N / p.xcd_px + (double)p.M / (8 / p.xcd_px) : 1e30;
+    if (seq_cost < 0.85 * rect_cost) p.xcd_bh = bh;
+  }
   // tail mode (NT): the tiles beyond the last full round of 256, when they are at most half a round and whole tile columns,
   // go out as twice as many half-height workgroups in the same launch (see the kernel)
   p.tail_n0 = 0;
@@ -476,6 +490,9 @@ int launch_gemm256(const GemmP& pin, hipStream_t st) {
         const double cost = 256.0 * p.tail_n0 / px + (double)p.M / py;
         if (cost < best) { best = cost; p.xcd_px = px; }
       }
+      // the half-height workgroups of the tail: compact blocks per XCD too (they ran in identity order: every XCD fetched every panel)
+      p.xcd_bh = 0;
+      if (KNOB(34) != 1 && (p.tail_n0 * gy) % 8 == 0) p.xcd_bh = xcd_band_rows(gx - p.tail_n0, 2 * gy, 1, 128, 256);
     }
   }
   switch (p.form) {

@@ -67,8 +67,11 @@ __global__ __launch_bounds__(512, S != CR_S ? 2 : (PH && (BIASG || BN == 160)) ?
   void* Cp = pin.C;
   float* bias_grad = pin.bias_grad;
   bf16* Cb = pin.Cb;
+  int bx, by, bz = blockIdx.z;
+  if (pin.xcd_bh > 0) xcd_seq_map(pin.xcd_bh, bx, by, bz);
+  else xcd_tile_map(pin.xcd_px, bx, by);
   if (FORM == GEMM_TN && pin.group > 1) {          // grouped launch: this workgroup's problem
-    const int gi = blockIdx.z;
+    const int gi = bz;
     Ap = pin.gA[gi]; Bp = pin.gB[gi]; Cp = pin.gC[gi]; bias_grad = pin.gbias_grad[gi]; Cb = pin.gCb[gi];
   }
   set_wave_prio(pin.prio);
@@ -76,8 +79,6 @@ __global__ __launch_bounds__(512, S != CR_S ? 2 : (PH && (BIASG || BN == 160)) ?
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;          // 4 x 2 waves, wave tile 64 x BN/2
   const int l16 = lane & 15, g = lane >> 4;
-  int bx, by;
-  xcd_tile_map(pin.xcd_px, bx, by);
   const int n0 = (dbg & 8) ? 0 : bx * BN, m0 = (dbg & 8) ? 0 : by * CR_BM;
   const int M = pin.M, N = pin.N;
   const int lda = (int)pin.lda, ldb = (int)pin.ldb;
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(512, S != CR_S ? 2 : (PH && (BIASG || BN == 160)) ?
   const int ktiles = pin.K / CR_BK;
   int split = 0, kt_begin = 0, kt_end = ktiles;
   if (pin.splitk > 1 && pin.group <= 1) {
-    split = blockIdx.z;
+    split = bz;
     const int chunk = (ktiles + pin.splitk - 1) / pin.splitk;
     kt_begin = split * chunk;
     kt_end = min(ktiles, kt_begin + chunk);
@@ -484,6 +485,10 @@ int launch_cr256(const GemmP& pin, int bn, hipStream_t st, bool deep, bool phase
       const double cost = (double)p.N / px + (double)p.M / py;
       if (cost < best) { best = cost; p.xcd_px = px; }
     }
+    // no rectangle fits (15 x 10 tiles, grouped 5 x 10 ...): the generic order (knob 34 = 1: identity as before, = 2: generic everywhere)
+    const int gz = p.form == GEMM_TN && p.group > 1 ? p.group : (p.splitk > 1 ? p.splitk : 1);
+    p.xcd_bh = 0;
+    if (KNOB(34) != 1 && (p.xcd_px == 0 || KNOB(34) == 2)) p.xcd_bh = xcd_band_rows(gx, gy, gz, CR_BM, bn);
   }
   if (p.splitk > 1) p.slab_ld = p.N;
 #ifdef SDXL_DIAG      // the exclusive 6-deep form (forced configurations 33 / 34): experiment, diagnostics build only

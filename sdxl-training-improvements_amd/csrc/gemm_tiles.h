@@ -123,6 +123,55 @@ __device__ __forceinline__ void xcd_tile_map_id(int xcd_px, int id, int gx, int 
     by = (xcd / px) * tm + lm;
   }
 }
+// Locality order for ANY 3-D grid (no divisibility needed): the launch's linear workgroup id i (x fastest, then y, then z; consecutive ids
+// go round the 8 XCDs) -> position s in the sequence "for z: for band of bh tile rows: for tile column: for row of the band".  XCD x owns a
+// contiguous range of that sequence (sizes differ by at most one), handed out in order, so what an XCD runs at any time is a compact
+// block of tiles of one z: its operand panels cross the fabric once and are shared in that XCD's L2.  (Weight gradients whose tile grid
+// does not divide over 8 XCDs -- 15 x 10 tiles, 3 tiles x 12 splits -- ran in identity order: every XCD fetched nearly every panel,
+// 3 - 8 x the algorithmic bytes: profiles/r05q_fetch_by_kernel.txt.)  bh <= 0: identity.
+// The z slices come in two kinds: OUTER ones share nothing (reduction splits, the problems of a grouped launch) and are kept apart -- the
+// sequence runs through one outer slice's tiles before the next --; INNER ones (zin of them: the filter taps / stencil rows of a
+// convolution's weight gradient, which read the same dY panel and shifted copies of the same pixels) sit next to each other at every tile.
+// Returns the inner index in zi and the outer in zo (gridDim.z = zin x outer count).
+__device__ __forceinline__ void xcd_seq_map(int bh, int zin, int& bx, int& by, int& zi, int& zo) {
+  const int gx = gridDim.x, gy = gridDim.y, T = gx * gy, W = T * gridDim.z;
+  const int i = (blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x;
+  const int q = W >> 3, rem = W & 7, x = i & 7;
+  const int s = x * q + min(x, rem) + (i >> 3);
+  const int r0 = s / zin;
+  zi = s - r0 * zin;
+  zo = r0 / T;
+  const int t = r0 - zo * T;
+  const int band_tiles = bh * gx, band = t / band_tiles, r = t - band * band_tiles;
+  const int h = min(bh, gy - band * bh);
+  bx = r / h;
+  by = band * bh + (r - bx * h);
+}
+__device__ __forceinline__ void xcd_seq_map(int bh, int& bx, int& by, int& bz) {
+  bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+  if (bh <= 0) return;
+  int zi;
+  xcd_seq_map(bh, 1, bx, by, zi, bz);
+}
+// the same order for a linear workgroup id over a gx x gy tile grid (regions of a 1-D launch whose first id is a multiple of 8)
+__device__ __forceinline__ void xcd_seq_map_id(int bh, int i, int gx, int gy, int& bx, int& by) {
+  const int T = gx * gy;
+  const int q = T >> 3, rem = T & 7, x = i & 7;
+  const int t = x * q + min(x, rem) + (i >> 3);
+  const int band_tiles = bh * gx, band = t / band_tiles, r = t - band * band_tiles;
+  const int h = min(bh, gy - band * bh);
+  bx = r / h;
+  by = band * bh + (r - bx * h);
+}
+// band height (tile rows) of xcd_seq_map for a gx x gy grid of bm x bn tiles with gz slices: the block an XCD holds is ~square in elements
+__host__ __device__ inline int xcd_band_rows(int gx, int gy, int gz, int bm, int bn, int zin = 1) {
+  const long T = (long)gx * gy, W = T * gz;
+  long per = W / 8 / zin < T ? W / 8 / zin : T;
+  if (per < 1) per = 1;
+  int bh = 1;
+  while ((long)(bh + 1) * (bh + 1) * bm <= per * bn && bh + 1 <= gy) ++bh;      // bh ~ sqrt(per * bn / bm)
+  return bh;
+}
 __device__ __forceinline__ void xcd_tile_map(int xcd_px, int& bx, int& by) {
   bx = blockIdx.x;
   by = blockIdx.y;

@@ -28,12 +28,13 @@
 //      4 = the one-round 3x3 convolutions forward on gemm.hip's configuration 5 / 6 (unsplit instead of two co-resident halves), 8 = their dgrads
 //   31 = 1: gemm_pl.hip WITH its L2 prefetch wave (measured: no gain)
 //   32 = 1: attention workgroups in plain (block, pair) order instead of the XCD-aware one
+//   34 = 1: no generic XCD order (xcd_seq_map) in the weight-gradient kernels: identity where no XCD rectangle fits, = 2: the generic order also where a rectangle fits (cr256)
 //   29 = 1: weight-gradient GEMMs that use no split-K slab and whose operands come from the caller's stream are launched any-order on the side stream
 // The product library has NO knobs: KNOB(i) is the constant 0 (= the shipped policy) and every experiment branch below it folds away.
 // The diagnostics build (`build.py --diag`: -DSDXL_DIAG -> libsdxlstep_diag.so, include/sdxlstep_diag.h) keeps the table, sdxl_set_knob,
 // the stream-K kernel (gemm_sk.hip), the stride-2 forward / weight gradient on phase planes (GemmP::up2 == 3) and the W = 32 three-tap form:
 // measured, parity-tested experiments the step does not run (DESIGN.md sections 10, 11).
-#define SDXL_NKNOBS 36
+#define SDXL_NKNOBS 38
 #ifdef SDXL_DIAG
 extern int g_knobs[SDXL_NKNOBS];
 #define KNOB(i) (g_knobs[(i)])
@@ -146,6 +147,7 @@ struct GemmP {
   int ln_epoch;            // > 0
   float* ln_pcol;          // or nullptr: [gridDim.y][2][N]
   int xcd_px;      // set by the launcher: XCD grid width over n-tiles (0 = identity order)
+  int xcd_bh;      // set by the launcher: band height of the generic XCD order (gemm_tiles.h: xcd_seq_map) where no px x py rectangle fits; 0 = off
   int tail_n0;     // 256 x 256 kernel, set by its launcher: > 0 = the tile columns from tail_n0 on are computed by HALF-HEIGHT workgroups
                    // (128 x 256: waves 4-7 only stage data) so that a launch of 2.5 rounds of tiles takes ~2.6 rounds, not 3
   int anyorder;    // host side, experiment (knob 29): launch without the in-stream barrier (hipExtAnyOrderLaunch): the kernel depends on nothing the stream ran before it

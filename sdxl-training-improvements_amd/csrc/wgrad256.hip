@@ -24,8 +24,9 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const GemmP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;               // 4 x 2 waves, wave tile 64 x 80
   const int l16 = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * WL_BN, m0 = blockIdx.y * WL_BM;
-  const int split = blockIdx.z;
+  int bx, by, split;
+  xcd_seq_map(p.xcd_bh, bx, by, split);      // (gemm_tiles.h: XCD-aware order of tiles and reduction splits)
+  const int n0 = bx * WL_BN, m0 = by * WL_BM;
   const int ktiles = p.K / WL_BK;
   const int chunk = (ktiles + p.splitk - 1) / p.splitk;
   const int kt_begin = split * chunk;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const GemmP p) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 5; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bool do_bias = p.bias_grad != nullptr && blockIdx.x == 0 && wn == 0;
+  const bool do_bias = p.bias_grad != nullptr && bx == 0 && wn == 0;
   f32x4 accb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -207,7 +208,9 @@ int launch_wgrad256(const GemmP& p, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(cdiv(p.N, WL_BN), cdiv(p.M, WL_BM), p.splitk);
-  GEMM_LAUNCH(wgrad256_kernel, grid, dim3(512), WL_SMEM, st, p);
+  GemmP q = p;
+  q.xcd_bh = KNOB(34) == 1 ? 0 : xcd_band_rows(grid.x, grid.y, grid.z, WL_BM, WL_BN);
+  GEMM_LAUNCH(wgrad256_kernel, grid, dim3(512), WL_SMEM, st, q);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
