@@ -129,7 +129,7 @@ def test_gemm_nt_nn_splitk_small_problems(L, M, N, K, splitk):
 
 
 @pytest.mark.parametrize("M,N,K,splitk", [(128, 128, 64, 1), (320, 384, 1000, 1), (1280, 640, 4096, 4),
-                                          (8, 320, 65536, 16), (640, 640, 308, 2)])
+                                          (8, 320, 65536, 16), (640, 640, 308, 2), (896, 1120, 2048, 3)])      # 7 x 7 tiles x 3 splits (generic XCD order)
 def test_gemm_tn_wgrad(L, M, N, K, splitk):
     a, b = rnd(K, M, seed=8), rnd(K, N, seed=9)
     out = torch.zeros(M, N, dtype=torch.float32, device=dev())
@@ -206,7 +206,8 @@ def test_gemm_stream_k_fused_dgrad_wgrad_is_reproducible(L):
 
 
 @pytest.mark.parametrize("M,N,K", [(5120, 640, 16384), (640, 2560, 16384), (1920, 640, 16384), (640, 640, 16384), (200, 72, 16384),
-                                   (256, 160, 32768)])
+                                   (256, 160, 32768),
+                                   (1792, 480, 16384)])      # 7 x 3 tiles: a grid no XCD rectangle divides, a short last band (xcd_seq_map)
 @pytest.mark.parametrize("splitk", [0, 1, 3])
 def test_gemm_tn_long_reduction_wgrad256(L, M, N, K, splitk):
     """wgrad256.hip (linear weight gradients over >= 16 384 rows: 256 x 160 tiles, two stacked dY tiles per staged X tile): fp32 result
@@ -265,7 +266,8 @@ def test_gemm_cr256_nt_nn(cr256, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,splitk", [(256, 160, 32, 1), (256, 128, 64, 1), (512, 320, 96, 1), (1280, 1280, 4096, 3), (3840, 1280, 4096, 1),
-                                          (200, 72, 1024, 4), (640, 640, 16384, 5)])
+                                          (200, 72, 1024, 4), (640, 640, 16384, 5),
+                                          (1792, 896, 512, 1), (1792, 896, 1536, 3)])      # 7 x 7 tiles (x 3 splits): 49 / 147 workgroups, not a multiple of 8
 def test_gemm_cr256_tn_wgrad_bias(cr256, M, N, K, splitk):
     L = cr256
     a, b = rnd(K, M, seed=8), rnd(K, N, seed=9)
