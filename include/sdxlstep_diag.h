@@ -65,6 +65,9 @@ SDXL_API int sdxl_sk_error(void* stream, unsigned* out);
 /* *out != 0 iff a LayerNorm-backward epilogue (sdxl_op_linear_dgrad_ln_bwd, knob 26) gave up its in-launch meeting since the last call (bit 0: the ready
  * flags of its row block's other column tiles, bit 1: a granule): the results of that launch are invalid.  Synchronises the device; clears the word. */
 SDXL_API int sdxl_ln_error(unsigned* out);
+/* L2 prefetch of the weight (B operand) of a coming one-round launch of the pipelined kernel (form 0 NT: B [N][ldb]; 1 NN: B [K][ldb]), on `stream`:
+ * workgroup i (XCD i % 8) reads the columns that XCD's tiles will stage, `parts` workgroups per XCD (profiles/tools/l2_prefetch_bench.py). */
+SDXL_API int sdxl_op_pl_prefetch_b(int form, const void* B, int M, int N, int K, long ldb, int parts, void* stream);
 SDXL_API int sdxl_op_gemm_sk(int n, const int* form, const void* const* A, const void* const* B, void* const* C, const int* M,
                     const int* N, const int* K, const void* const* bias, const void* const* resid, const int* accumulate,
                     void* stream);

@@ -1013,6 +1013,12 @@ int sdxl_set_sk_mode(int mode, int workers) {
   gemm_sk_set_workers(workers);
   return 0;
 }
+int sdxl_op_pl_prefetch_b(int form, const void* B, int M, int N, int K, long ldb, int parts, void* st) {
+  GemmP p;
+  gemm_defaults(&p);
+  p.form = form; p.B = (const bf16*)B; p.M = M; p.N = N; p.K = K; p.ldb = ldb;
+  return launch_pl_prefetch_b(p, parts, (hipStream_t)st);
+}
 int sdxl_ln_error(unsigned* out) {
   ARG_CHECK(out != nullptr, "ln_error: null output");
   return gemm_ln_error(out);

@@ -133,6 +133,7 @@ DIAG_SIGNATURES = {
     "sdxl_set_sk_mode": [_i, _i],
     "sdxl_sk_error": [_vp, _P(C.c_uint)],
     "sdxl_ln_error": [_P(C.c_uint)],
+    "sdxl_op_pl_prefetch_b": [_i, _vp, _i, _i, _i, C.c_long, _i, _vp],
     "sdxl_op_gemm_sk": [_i, _P(_i), _P(_vp), _P(_vp), _P(_vp), _P(_i), _P(_i), _P(_i), _P(_vp), _P(_vp), _P(_i), _vp],
     "sdxl_op_conv3x3_s2_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "sdxl_op_conv3x3_s2_wgrad": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
