@@ -447,6 +447,7 @@ bool pl_applicable(const GemmP& p) {
   return true;
 }
 
+#ifdef SDXL_DIAG      // experiment (profiles/r05s_l2_prefetch_across_kernels.txt): diagnostics build only
 // L2 prefetch of the B operand (the weight) of a COMING one-round launch of pl_kernel, as a kernel of its own for another stream: workgroup i
 // runs on XCD i % 8 and reads the part of B that XCD's tiles will stage (the same px x py rectangle as launch_pl), so that the weight is in
 // that XCD's L2 when the GEMM starts -- issued while the kernel BEFORE the GEMM runs (an attention kernel leaves the fabric idle), not
@@ -482,6 +483,7 @@ int launch_pl_prefetch_b(const GemmP& p, int parts, hipStream_t st) {
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
+#endif
 
 static int g_pl_prefetch = 0;      // the L2 prefetch wave: OFF (measured: no gain on cold operands, -7 % on warm ones); sdxl_set_gemm_mode(4 * 8) forces the kernel with it
 void pl_set_prefetch(int on) { g_pl_prefetch = on; }
