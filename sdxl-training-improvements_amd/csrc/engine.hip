@@ -493,6 +493,7 @@ struct GroupNormOp : Op {
   }
   int fwd(Plan& p, hipStream_t st) override {
     if (KNOB(27) & 2) return 0;      // (knob 27: timing knock-outs, wrong results -- kernels.h)
+    if (KNOB(27) & 128) return launch_silu_fwd(p.P(x), p.P(y), (long)Bn * HW * C, st);      // (timing only: ONE elementwise launch, live data downstream)
     return launch_groupnorm_fwd(p.P(x), p.P(y), p.eng->Wp(gm), p.eng->Wp(bt), p.F(stats_off), p.F(p.gn_ws_off), Bn, HW, C, G,
                                 eps, silu, st);
   }
@@ -518,6 +519,7 @@ struct LayerNormOp : Op {
   }
   int fwd(Plan& p, hipStream_t st) override {
     if (KNOB(27) & 4) return 0;
+    if (KNOB(27) & 256) return launch_silu_fwd(p.P(x), p.P(y), (long)x->rows * C, st);      // (timing only: an elementwise launch with the same bytes)
     return launch_layernorm_fwd(p.P(x), p.P(y), p.eng->Wp(gm), p.eng->Wp(bt), p.F(stats_off), (int)x->rows, C, eps, st);
   }
   void plan_bwd(Plan& p) override {

@@ -21,7 +21,8 @@
 //   25 LayerNorm backward knock-outs (timing only, wrong gradients): 1 no dgamma / dbeta pass, 2 no dx pass either, 3 no dx pass
 //   26 LayerNorm backward in the consumer's dgrad epilogue (GemmP::ln_x): 0 separate passes (shipped), 1 fused (dx + dgamma | dbeta partials), 2 fused dx, dy stored and the parameter pass kept
 //   27 timing knock-outs by op type (bit mask, wrong results): 1 GroupNorm backward, 2 GroupNorm forward, 4 LayerNorm forward, 8 cross-attention
-//      backward, 16 self-attention backward, 32 self-attention forward, 64 cross-attention forward
+//      backward, 16 self-attention backward, 32 self-attention forward, 64 cross-attention forward; 128 / 256 GroupNorm / LayerNorm forward replaced by ONE elementwise launch
+//      (live data downstream: the skipped ops leave stale zeros behind, and a chip at its power cap runs zeros ~5 % faster -- profiles/r05t_knockouts_live_data.txt)
 //   28 wave priority (s_setprio 0..3) of the LayerNorm backward dx kernel
 //   30 pipelined one-wave-per-SIMD kernels, bit mask (0 = the shipped policy = 3; 64 = none): 1 = the forward's one-round linear problems on gemm_pl.hip, 2 = the one-round linear dgrads,
 //      16 = every plain linear NT / NN problem whose tiles are whole rounds of 256, 32 = every plain linear NT / NN problem;
