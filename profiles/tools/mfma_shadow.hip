@@ -5,6 +5,8 @@
 //   hipcc --offload-arch=gfx950 -O3 -I sdxl-training-improvements_amd/csrc profiles/tools/mfma_shadow.hip -o profiles/tools/mfma_shadow
 #include "common.h"
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 template <int OFF>
@@ -24,7 +26,10 @@ __global__ __launch_bounds__(256, 2) void k(const bf16* __restrict__ src, float*
   unsigned raddr = lds_addr_of(smem) + wave * 36864u + lane * 16u;
   asm volatile("" : "+v"(raddr));
   bf16x8 fa[2][10], fb[2][10];
-  for (int s = 0; s < 2; ++s) for (int i = 0; i < 10; ++i) { for (int e = 0; e < 8; ++e) { fa[s][i][e] = (bf16)(0.001f * (lane + i + e)); fb[s][i][e] = (bf16)(0.002f * (lane - i + e)); } }
+  for (int s = 0; s < 2; ++s) for (int i = 0; i < 10; ++i) {      // random operand data (the buffer holds random bf16 in [-1, 1)): constant data draw less power
+    fa[s][i] = *(const bf16x8*)(src + ((threadIdx.x * 40 + s * 20 + i) * 8) % 500000);
+    fb[s][i] = *(const bf16x8*)(src + ((threadIdx.x * 40 + s * 20 + 10 + i) * 8 + 4096) % 500000);
+  }
   f32x4 a16[20];
   f32x16_t a32[5];
   for (int i = 0; i < 20; ++i) a16[i] = (f32x4){0, 0, 0, 0};
@@ -74,9 +79,10 @@ __global__ __launch_bounds__(256, 2) void k(const bf16* __restrict__ src, float*
   if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+static int g_iters = 2000;
 template <int SHAPE, bool READS, bool DMA>
 static void run(const bf16* src, float* out, unsigned long long* cyc, const char* name) {
-  const int iters = 2000, smem = 4 * 36864;
+  const int iters = g_iters, smem = 4 * 36864;
   hipFuncSetAttribute((const void*)k<SHAPE, READS, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipLaunchKernelGGL((k<SHAPE, READS, DMA>), dim3(256), dim3(256), smem, 0, src, out, cyc, 200);
@@ -89,9 +95,25 @@ static void run(const bf16* src, float* out, unsigned long long* cyc, const char
   printf("%-58s %8.1f cycles / K-step  %6.3f us  -> %7.1f TFLOP/s chip-wide (4 waves x 256 CUs)\n", name, (double)c / iters, us, 655360.0 * 4 * 256 / us / 1e6);
 }
 
-int main() {
+int main(int argc, char** argv) {
   bf16* src; float* out; unsigned long long* cyc;
-  hipMalloc(&src, 1 << 20); hipMemset(src, 0x11, 1 << 20); hipMalloc(&out, 64); hipMalloc(&cyc, 64);
+  hipMalloc(&src, 1 << 20); hipMalloc(&out, 64); hipMalloc(&cyc, 64);
+  {   // random bf16 in [-1, 1): LDS-DMA'd tiles and register fragments then toggle like real operands
+    unsigned short* h = (unsigned short*)malloc(1 << 20);
+    unsigned x = 12345u;
+    for (int i = 0; i < (1 << 19); ++i) { x = x * 1664525u + 1013904223u; float f = ((x >> 8) & 0xFFFF) / 32768.0f - 1.0f; unsigned u; memcpy(&u, &f, 4); h[i] = (unsigned short)(u >> 16); }
+    hipMemcpy(src, h, 1 << 20, hipMemcpyHostToDevice); free(h);
+  }
+  if (argc > 1) {      // sustained mode: `mfma_shadow <iters>` -- long launches (600000 K-steps ~ 0.25 s: the package reaches its power cap), the two shapes alternating
+    g_iters = atoi(argv[1]);
+    for (int rep = 0; rep < 3; ++rep) {
+      run<16, false, false>(src, out, cyc, "sustained 40 x 16x16x32, nothing else");
+      run<32, false, false>(src, out, cyc, "sustained 20 x 32x32x16, nothing else");
+      run<16, true, true>(src, out, cyc, "sustained 40 x 16x16x32 + 18 reads + 9 pieces");
+      run<32, true, true>(src, out, cyc, "sustained 20 x 32x32x16 + 20 reads + 9 pieces");
+    }
+    return 0;
+  }
   run<16, false, false>(src, out, cyc, "40 x 16x16x32, nothing else");
   run<32, false, false>(src, out, cyc, "20 x 32x32x16, nothing else");
   run<16, true, false>(src, out, cyc, "40 x 16x16x32 + 18 ds_read_b128");
