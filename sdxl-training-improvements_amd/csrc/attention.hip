@@ -823,7 +823,10 @@ size_t attn_part_floats(int B, int H, int Nk, int qsplit) {
 int attn_pick_qsplit(int B, int H, int Nq, int Nk) {
   long blocks = (long)((Nk + 63) / 64) * B * H;
   int qt = (Nq + 63) / 64;
-  int s = (int)(640 / blocks);
+  // ~160 workgroups (knob 36: the target, A/B runs; 640 until round 5): the 4096-query level-2 prompt attention then runs UNSPLIT -- 160 workgroups write
+  // bf16 dK | dV directly, no fp32 partials (42 MB per attention), no reduce launch -- and the 16 384-query level splits in two; step -0.5 ms
+  // (profiles/r05v_ab_cross_dkv_split.txt)
+  int s = (int)((KNOB(36) > 0 ? KNOB(36) : 160) / blocks);
   if (s < 1) s = 1;
   if (s > qt / 2) s = qt / 2 > 0 ? qt / 2 : 1;
   if (s > 16) s = 16;
