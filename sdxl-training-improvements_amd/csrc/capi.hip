@@ -804,7 +804,7 @@ int sdxl_op_layernorm_bwd(const void* x, const void* dy, const void* gamma, cons
     return launch_layernorm_bwd((const bf16*)x, (const bf16*)dy, (const bf16*)gamma, stats, (bf16*)dx,
                                 accumulate ? (const bf16*)dx : nullptr, nullptr, nullptr, M, C, (hipStream_t)st);
   ARG_CHECK(dbeta, "layernorm bwd: dgamma and dbeta go together");
-  if (KNOB(10) != 2) {     // the plan's default: lean dx kernel + parameter gradients as a pass of their own
+  if (KNOB(10) == 1 || KNOB(10) == 3) {     // (A/B runs) lean dx kernel + parameter gradients as a pass of their own; the plan's default is the one-pass form below
     CHK(launch_layernorm_bwd((const bf16*)x, (const bf16*)dy, (const bf16*)gamma, stats, (bf16*)dx,
                              accumulate ? (const bf16*)dx : nullptr, nullptr, nullptr, M, C, (hipStream_t)st));
     if (KNOB(10) == 3) return launch_layernorm_param_grads((const bf16*)x, (const bf16*)dy, stats, dgamma, dbeta, M, C, (hipStream_t)st);

@@ -530,10 +530,10 @@ struct LayerNormOp : Op {
   int bwd(Plan& p, hipStream_t st, bool) override {
     // dx and the per-block dgamma | dbeta partial sums in one pass (norm.hip); the partials of all LayerNorms of the segment
     // are folded into the gradients by one launch at its end (Engine::flush_ln_params)
-    // Default: the lean dx kernel (120 VGPRs, no LDS: two blocks per CU beside a wgrad workgroup) on the caller's stream, dgamma /
-    // dbeta as a leaf pass of their own on the side stream (re-reads x, dy: 21 MB, from L2 / MALL) -- step -0.7 ms against the fused
-    // form (dx + per-block parameter partial sums in one pass: 180 VGPRs + 40 KiB LDS, one block per CU when co-running;
-    // knob 10 = 2 selects it, A/B runs).  Round 2 measured the two forms equal; since then the main stream became the critical one.
+    // Default (again, since round 5): dx + per-block parameter partial sums in ONE pass over x, dy (180 VGPRs + 40 KiB LDS).  Rounds 3 - 4 ran
+    // the lean dx kernel (120 VGPRs, no LDS) on the caller's stream + the parameter gradients as a leaf pass on the side stream (knob 10 = 1):
+    // -0.7 ms then; with the side stream's passes costing the step their full duration now (210 x 5.8 us re-reading 21 MB each beside the GEMMs:
+    // knob 25 = 1 is worth -1.2 ms) the one-pass form is -0.4 ms again, five alternations (profiles/r05w_ab_ln_fused.txt).
     if (fused) {      // dx is in place (or will be: this op runs after the consumer in the backward order); the parameter gradients:
       if (fused == 2) {
         const bf16* xp = p.P(x); const bf16* dyp = p.GP(dy_off); const float* sp = p.F(stats_off);
@@ -547,7 +547,7 @@ struct LayerNormOp : Op {
     }
     // knob 25 (timing knock-outs, wrong gradients): 1 = no parameter-gradient pass, 2 = no dx pass either, 3 = dx pass only skipped
     if (KNOB(25) == 2) return 0;
-    if (KNOB(10) != 2) {
+    if (KNOB(10) == 1 || KNOB(10) == 3) {      // (A/B runs: the lean dx kernel + the parameter gradients as a leaf pass of their own -- the form of rounds 4 / 5a)
       if (KNOB(25) != 3)
       CHK(launch_layernorm_bwd(p.P(x), p.GP(dy_off), p.eng->Wp(gm), p.F(stats_off), p.GP(dx.out), p.GP(dx.addend), nullptr, nullptr, (int)x->rows, C, st));
       const bf16* xp = p.P(x); const bf16* dyp = p.GP(dy_off); const float* sp = p.F(stats_off);

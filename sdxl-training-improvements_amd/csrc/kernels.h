@@ -12,7 +12,7 @@
 //       gather; = 512: stride-2 forward / weight gradient on phase planes (OFF by default: neutral in the step)
 //   3, 4 split-K factor of the long linear dgrads and its N threshold; 5 = 80: GEGLU packed in groups of 80
 //   6, 7 forced configuration of the linear / conv dgrads, 8 N threshold of knob 6
-//   9 = 1: no wgrad256 kernel; 10 = 2: fused LayerNorm backward, 3: LayerNorm parameter gradients by the atomic column-sum pass; 11 = 1: the round-2 LayerNorm dx kernel
+//   9 = 1: no wgrad256 kernel; 10 = 1: LayerNorm backward as lean dx kernel + parameter-gradient leaf pass (0 / 2: dx and parameter partials in one pass, shipped), 3: lean + the atomic column-sum pass; 11 = 1: the round-2 LayerNorm dx kernel
 //   12 = 1: no three-tap conv weight gradient; 13 split-K workgroup target of conv_wgrad3 / wgrad256 (144); 14 = 2: its W = 32 form
 //   15 = 1: no half-height tail workgroups in the 256 x 256 kernel
 //   16 co-resident 256-row kernel for the level-2 linear weight gradients: 0 policy, 1 off, 2 / 3 = 128 / 160-column tiles wherever allowed;

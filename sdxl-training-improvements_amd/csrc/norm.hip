@@ -626,22 +626,28 @@ __global__ __launch_bounds__(256) void ln_bwd_lean_kernel(const bf16* __restrict
   }
 }
 
-// dgamma / dbeta += the block partials of up to LN_RED_MAX LayerNorm backward launches.  grid (column chunk of 256 over
-// [dgamma | dbeta], row chunk, entry): a thread sums its chunk of partials of one column and adds the result with one atomic.
+// dgamma / dbeta += the block partials of up to LN_RED_MAX LayerNorm backward launches.  grid (64-column chunk of [dgamma | dbeta], row chunk,
+// entry), block = 64 columns x 4 row slices: a thread sums the rows r = slice (mod 4) of its chunk of one column, the four slices are added in a
+// fixed order through LDS, and ONE value goes into the gradient.  With one row chunk (the launcher's choice up to 1024 partial rows) the sum is
+// bitwise reproducible; more chunks: one atomic each.
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const LnRedBatch b) {
+  __shared__ float sl[4][64];
   const LnRedEntry e = b.e[blockIdx.z];
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= 2 * e.C) return;
+  const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + col;
   const int per = (e.nblk + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * per, r1 = min(e.nblk, r0 + per);
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  const float* p = e.part + (size_t)r0 * 2 * e.C + c;
-  int r = r0;
-  for (; r + 4 <= r1; r += 4, p += (size_t)8 * e.C) {
-    s0 += p[0]; s1 += p[(size_t)2 * e.C]; s2 += p[(size_t)4 * e.C]; s3 += p[(size_t)6 * e.C];
+  float s0 = 0.f, s1 = 0.f;
+  if (c < 2 * e.C) {
+    const float* p = e.part + (size_t)(r0 + slice) * 2 * e.C + c;
+    int r = r0 + slice;
+    for (; r + 4 < r1; r += 8, p += (size_t)16 * e.C) { s0 += p[0]; s1 += p[(size_t)8 * e.C]; }
+    if (r < r1) s0 += p[0];
   }
-  for (; r < r1; ++r, p += (size_t)2 * e.C) s0 += p[0];
-  if (r1 > r0) atomicAdd((c < e.C ? e.dgamma : e.dbeta - e.C) + c, (s0 + s1) + (s2 + s3));
+  sl[slice][col] = s0 + s1;
+  __syncthreads();
+  if (slice == 0 && c < 2 * e.C && r1 > r0)
+    atomicAdd((c < e.C ? e.dgamma : e.dbeta - e.C) + c, (sl[0][col] + sl[1][col]) + (sl[2][col] + sl[3][col]));
 }
 
 // backward, dgamma/dbeta: column-oriented (thread = fixed 8-column vector, 8 row lanes per block,
@@ -843,9 +849,9 @@ int launch_ln_param_reduce(const LnRedBatch& b, hipStream_t st) {
     cmax = b.e[i].C > cmax ? b.e[i].C : cmax;
     nmax = b.e[i].nblk > nmax ? b.e[i].nblk : nmax;
   }
-  // up to 256 partial rows: one thread walks a column's rows in order and adds ONE value to the gradient (bitwise reproducible); more
-  // (the fused dx + partials form, 512 rows and up): 16 row chunks, one atomic each
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * cmax, 256), nmax <= 256 ? 1 : 16, b.n), dim3(256), 0, st, b);
+  // up to 1024 partial rows (the one-pass dx + partials form writes 512): one thread walks a column's rows in order and adds ONE value to the
+  // gradient (bitwise reproducible); more: 16 row chunks, one atomic each
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * cmax, 64), nmax <= 1024 ? 1 : 16, b.n), dim3(256), 0, st, b);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
