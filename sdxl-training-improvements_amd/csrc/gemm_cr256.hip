@@ -447,8 +447,11 @@ static int cr256_wgrad_cfg_tiles(int M, int N, long red, bool bias) {
 }
 int cr256_wgrad_cfg(int M, int N, long red, bool bias) {
   int cfg = cr256_wgrad_cfg_tiles(M, N, red, bias);
-  // 128-column tiles: the phased loop (configuration 35; knob 23 = 1: the lockstep loop everywhere, = 2: phased only for >= 256 tiles)
-  if (cfg == 32 && KNOB(23) != 1 && (KNOB(23) != 2 || (long)cdiv(M, CR_BM) * cdiv(N, 128) >= 256)) cfg = 35;
+  // 128-column tiles: the LOCKSTEP loop (configuration 32) since the end of round 5 -- same-box, six alternations: 107.24 -> 106.54 ms per step against the
+  // phased loop (configuration 35), which had won by 2 ms in round 4: beside the exclusive one-wave-per-SIMD dgrads (gemm_pl.hip) and with its operands
+  // fetched once per XCD the phased form's barrier pairs no longer pay (profiles/r05y_ab_cr256_lockstep.txt).  knob 23 = 5: phased everywhere (rounds 4-5),
+  // = 2: phased only for >= 256 tiles (106.85 against 106.53).
+  if (cfg == 32 && (KNOB(23) == 5 || KNOB(23) == 3 || KNOB(23) == 4 || (KNOB(23) == 2 && (long)cdiv(M, CR_BM) * cdiv(N, 128) >= 256))) cfg = 35;
   // (knob 23 = 3 / 4, experiment: the phased loop on 160-column tiles for outputs of >= 8192 rows / wherever N % 160 == 0)
   if (cfg == 35 && N % 160 == 0 && ((KNOB(23) == 3 && M >= 8192) || KNOB(23) == 4)) cfg = 36;
   return cfg;
