@@ -1456,7 +1456,7 @@ int gemm_pick_group(int M, int N, int taps, long red, int splitk) {
   if (taps != 1 || splitk < 2 || red > 8192 || red % 64) return 1;
   const long tiles = (long)cdiv(M, 128) * cdiv(N, 160);
   if (tiles < 64 || tiles > 128) return 1;
-  const int g = (int)(256 / tiles);
+  const int g = KNOB(37) > 0 ? KNOB(37) : (int)(256 / tiles);      // (knob 37: problems per grouped launch, A/B runs)
   return g < 2 ? 1 : (g > GEMM_MAX_GROUP ? GEMM_MAX_GROUP : g);
 }
 void gemm_set_mode(int mode) { g_mode256 = mode & 3; g_force_cfg = mode >> 2; }

@@ -18,6 +18,7 @@
 //   16 co-resident 256-row kernel for the level-2 linear weight gradients: 0 policy, 1 off, 2 / 3 = 128 / 160-column tiles wherever allowed;
 //   17 its split-K workgroup target for long reductions (0: 256); 19 = 1: also the 16 384-row level's linear weight gradients on it; 20 = 1: self-attention backward as two launches (dQ, then dK / dV); 23: loop of the co-resident 256-row kernel's 128-column tiles: 0 / 1 lockstep (shipped), 5 phased everywhere (rounds 4-5), 2 phased only for >= 256 tiles, 3 / 4 phased + 160-column tiles for >= 8192 rows / wherever they divide; 22 configuration of the GEGLU (FF2) dgrad; 21 = 1: Delta always from its own pass; 18 = 1: no padding columns on the feed-forward hidden tensors
 //   24 = 1: GroupNorm backward partial sums by the LDS-free row-lane kernel (neutral in the step: r04i_ab_gn_nolds.txt)
+//   37 problems per grouped weight-gradient launch (0: 256 / tiles = 3 for the 1280 x 1280 ones; 1 = alone with their split-K, 2, 4)
 //   36 workgroup target of the cross-attention dK / dV kernel's query split (0: the shipped 160; 640 = rounds 2 - 4)
 //   25 LayerNorm backward knock-outs (timing only, wrong gradients): 1 no dgamma / dbeta pass, 2 no dx pass either, 3 no dx pass
 //   26 LayerNorm backward in the consumer's dgrad epilogue (GemmP::ln_x): 0 separate passes (shipped), 1 fused (dx + dgamma | dbeta partials), 2 fused dx, dy stored and the parameter pass kept
