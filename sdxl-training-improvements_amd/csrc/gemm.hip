@@ -1617,7 +1617,7 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
       const int k30 = KNOB(30) ? KNOB(30) : 3;
       const bool one_round = tiles <= 256 && tiles > 128;
       use = ((k30 & 1) && p.form == GEMM_NT && one_round) || ((k30 & 2) && p.form == GEMM_NN && one_round) || ((k30 & 512) && p.form == GEMM_NN && one_round && p.K >= 2560) ||
-            ((k30 & 16) && tiles > 128 && tiles % 256 == 0) || (k30 & 32);
+            ((k30 & 16) && tiles > 128 && tiles % 256 == 0) || ((k30 & 1024) && p.form == GEMM_NT && tiles > 256 && tiles % 256 == 0) || (k30 & 32);
     }
     if (use && pl_applicable(p)) return launch_pl(p, 0, st);
   }

@@ -27,7 +27,7 @@
 //      (live data downstream: the skipped ops leave stale zeros behind, and a chip at its power cap runs zeros ~5 % faster -- profiles/r05t_knockouts_live_data.txt)
 //   28 wave priority (s_setprio 0..3) of the LayerNorm backward dx kernel
 //   30 pipelined one-wave-per-SIMD kernels, bit mask (0 = the shipped policy = 3; 64 = none): 1 = the forward's one-round linear problems on gemm_pl.hip, 2 = the one-round linear dgrads,
-//      16 = every plain linear NT / NN problem whose tiles are whole rounds of 256, 32 = every plain linear NT / NN problem;
+//      16 = every plain linear NT / NN problem whose tiles are whole rounds of 256, 1024 = the FORWARD ones of those with more than one round, 32 = every plain linear NT / NN problem;
 //      4 = the one-round 3x3 convolutions forward on gemm.hip's configuration 5 / 6 (unsplit instead of two co-resident halves), 8 = their dgrads
 //   31 = 1: gemm_pl.hip WITH its L2 prefetch wave (measured: no gain)
 //   32 = 1: attention workgroups in plain (block, pair) order instead of the XCD-aware one
