@@ -10,7 +10,7 @@ done
 cd $O/pmc && python - <<'PY'
 import csv, glob, collections, json, os
 def fam(n):
-    if 'gemm_kernel' in n or 'gemm256_kernel' in n or 'gemm_sk_kernel' in n or 'conv_wgrad3_kernel' in n or 'cr256_kernel' in n or 'wgrad256_kernel' in n: return 'gemm'
+    if 'gemm_kernel' in n or 'gemm256_kernel' in n or 'gemm_sk_kernel' in n or 'conv_wgrad3_kernel' in n or 'cr256_kernel' in n or 'wgrad256_kernel' in n or 'pl_kernel' in n: return 'gemm'
     if 'attn_' in n: return 'attention'
     if 'splitk' in n: return 'splitk_reduce'
     if n.startswith('void at::') or 'at::native' in n or 'repack' in n or 'elementwise_kernel' in n or 'distribution' in n: return None
