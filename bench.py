@@ -106,6 +106,28 @@ def _physical_cores_per_socket():
         return os.cpu_count() or 8
 
 
+def _usable_cores():
+    """cores this process may actually run on: the affinity mask, cut by the cgroup CPU quota (a container with 8 CPUs' worth of quota on a
+    64-core host runs 64 threads SLOWER than 8: round 5's socket-wide run measured 0.40 TFLOP/s against 0.79 at 8 threads)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, int(q / int(f.read()) + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(threads_list=None, timed_steps: int = 3):
     """the fp32 CPU oracle (the restatement pinned to the reference's loss-side goldens), cfg 1 (ddpm, B=1, 512^2,
     single process): 1 warm-up + `timed_steps` timed forward+backward steps, at threads = one socket's physical cores and at
@@ -140,19 +162,27 @@ def cpu_baseline(threads_list=None, timed_steps: int = 3):
         out["loss"].backward()
         return time.time() - t0
 
+    usable = _usable_cores()
     if not threads_list:
-        threads_list = sorted({_physical_cores_per_socket(), 8}, reverse=True)
+        # one socket's physical cores, but never more threads than the process may run on (affinity mask, cgroup quota), and 8 (the
+        # authoring container's count) for comparison; the process is pinned to that many CPUs of its mask for each run
+        threads_list = sorted({min(_physical_cores_per_socket(), usable), min(8, usable)}, reverse=True)
+    mask0 = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
     runs = []
     for n in threads_list:
         torch.set_num_threads(int(n))
+        if mask0 and len(mask0) >= int(n) and len(mask0) == usable:      # (under a quota without a mask the kernel places the threads)
+            os.sched_setaffinity(0, set(mask0[:int(n)]))
         one_step()                                       # warm-up (allocator, thread pool, oneDNN primitive cache)
         dts = [one_step() for _ in range(timed_steps)]
         dt = sum(dts) / len(dts)
         runs.append({"threads": torch.get_num_threads(), "s_per_step_512": round(dt, 3), "img_per_s_512": round(B / dt, 4),
                      "tflops": round(FLOP_PER_IMAGE_512 / dt / 1e12, 3)})
+    if mask0:
+        os.sched_setaffinity(0, set(mask0))
     best = max(runs, key=lambda r: r["img_per_s_512"])
     return {"value": best["img_per_s_512"] * FLOP_PER_IMAGE_512 / FLOP_PER_IMAGE_1024, "unit": "images/sec", "cores": best["threads"],
-            "kind": "port", "runs": runs,
+            "kind": "port", "runs": runs, "usable_cores": usable,
             "sample": f"oracle (fp32 torch CPU restatement), cfg1: ddpm B=1 512^2 fwd+bwd, 1 warm-up + {timed_steps} timed steps per "
                       f"thread count {[r['threads'] for r in runs]}; value = best ({best['s_per_step_512']} s/step at {best['threads']} "
                       f"threads) scaled to 1024^2-equivalent images by the FLOP ratio 4.77/20.28; weight init {t_init:.1f} s untimed"}
@@ -232,10 +262,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="skip the (untimed) fused-optimizer measurement")
     ap.add_argument("--cpu-threads", type=int, nargs="*", default=None, help="thread counts of the CPU baseline (default: one socket's cores, 8)")
-    ap.add_argument("--exchange", default="allreduce", choices=["zero1", "allreduce"],
-                    help="N > 1: all-reduce of the bf16 gradient buckets overlapped with the backward (default: what north_star "
-                         "names), or zero1 = reduce-scatter of the buckets + the all-gather of the (updated) parameters, BOTH inside "
-                         "the timed step (the same bytes on the wire as the all-reduce; the sharded update itself is reported apart)")
+    ap.add_argument("--exchange", default="zero1", choices=["zero1", "allreduce"],
+                    help="N > 1: zero1 (default = the trainer's default, training.shard_optimizer: DESIGN.md section 6) = reduce-scatter of the bf16 "
+                         "gradient buckets overlapped with the backward + the all-gather of the parameter slices, BOTH inside the timed step "
+                         "(the same bytes on the wire as an all-reduce; the sharded update itself is reported apart), or allreduce = the "
+                         "all-reduce of the buckets north_star names, kept as the reference point")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="N = 1: initialise a ONE-rank process group on the backend (nccl = RCCL) and run the complete exchange through it "
+                         "every step (casts, collectives on the engine's side stream, all-gather): no byte leaves the GPU, but RCCL's "
+                         "stream / dtype / alignment handling is the real one.  Not the headline configuration.")
     ap.add_argument("--exchange-shadow", default=None, metavar="CH[:LDS_KB[:GBPS]]",
                     help="N = 1 only: price the co-residency of the exchange's device kernels without a node -- after every backward segment "
                          "a stand-in kernel of CH workgroups x 256 threads (LDS_KB of LDS each, default 64) streams a bucket-sized buffer on "
@@ -265,11 +300,15 @@ def main():
         local_rank = 0
     if args.max_nchannels:
         os.environ["NCCL_MAX_NCHANNELS"] = str(args.max_nchannels)
-    if world > 1 and backend == "nccl" and rank == 0 and "NCCL_DEBUG" not in os.environ:
+    forced = bool(args.force_exchange) and world == 1
+    if (world > 1 or forced) and backend == "nccl" and rank == 0 and "NCCL_DEBUG" not in os.environ:
         # rank 0 logs RCCL's topology / algorithm choices to a file; the lines end up in config.exchange.rccl
         os.environ["SDXL_RCCL_LOG"] = f"/tmp/sdxl_rccl_{os.getpid()}.log"
         os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,TUNING", NCCL_DEBUG_FILE=os.environ["SDXL_RCCL_LOG"])
-    D.init_process_group(backend if world > 1 else None)
+    if forced:
+        os.environ["SDXL_FORCE_EXCHANGE"] = "1"
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    D.init_process_group(backend if (world > 1 or forced) else None)
     wl = WORKLOADS[args.workload]
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -296,7 +335,7 @@ def main():
     batches = [make_batch(wl, rank, dev, hw=hw) for hw in buckets]
     L = net.L
 
-    emit = world > 1 and not args.no_emit and hasattr(L, "sdxl_set_grad_emit")
+    emit = (world > 1 or forced) and not args.no_emit and hasattr(L, "sdxl_set_grad_emit")
 
     def cast(off, n, dst):
         if emit:           # the wgrad GEMMs write bf16 into the exchange arena themselves: only biases / norm parameters are cast
@@ -310,7 +349,7 @@ def main():
     # update + parameter all-gather that follow belong to the optimizer phase, which the metric excludes at every N (measured
     # separately below).
     sync = D.make_grad_sync(net.param_elems, cast, torch.bfloat16, dev, sharded=args.exchange == "zero1",
-                            segment_sizes=[n for _o, n in net.segment_ranges()])
+                            segment_sizes=[n for _o, n in net.segment_ranges()], force=forced)
     sharded_exchange = isinstance(sync, D.ShardedGradSync)
     scale = 1.0 / world / accum
     micro = [0]
@@ -339,7 +378,7 @@ def main():
         if first:
             net.zero_grads()
         net.forward_loss(wl["method"], b["lat"], b["noise"], b["sigma_or_t"], b["timestep"], b["ehs"], b["pooled"], b["tid"])
-        exch = world > 1 and last
+        exch = (world > 1 or forced) and last
         if exch and emit:
             net.set_grad_emit(sync.comm, 1.0)
         net.backward(scale, first, on_segment=sync.on_segment if exch else (shadow_on_segment if shadow else None), segment_stream=True)
@@ -443,14 +482,14 @@ def main():
     if not args.no_optimizer:
         from sdxl_amd.optimizer import AdamWBF16
         opt = AdamWBF16(net, lr=4e-7, weight_decay=0.01)
-        sharded = world > 1 and sharded_exchange
+        sharded = (world > 1 or forced) and sharded_exchange
 
         def update():
             if sharded:           # ZeRO-1: this rank's slices of every bucket, then the parameters are all-gathered
                 opt.step(sync.reduced(), pieces=sync.pieces)
                 sync.gather_params(net.weights)
             else:
-                opt.step(sync.reduced() if world > 1 else None)
+                opt.step(sync.reduced() if (world > 1 or forced) else None)
 
         for _ in range(2):
             update()
@@ -490,11 +529,11 @@ def main():
                "config": {"workload": wl["desc"], "global_batch": wl["B"] * world, "parallelism": f"dp{world}",
                           "exchange": ({"shadow": shadow, "what": "single GPU: a stand-in kernel per backward segment on a third stream (no bytes "
                                         "leave the GPU); the step time beside it prices the exchange kernels' co-residency"} if shadow else None)
-                          if world == 1 else {
+                          if (world == 1 and not forced) else {
                               "what": ("reduce-scatter of the bf16 gradient buckets overlapped with the backward + all-gather of the parameter slices, "
                                        "both inside the timed step (ZeRO-1 wire pattern; the sharded update is in `optimizer`)") if sharded_exchange
                                       else "all-reduce of the bf16 gradient buckets overlapped with the backward, complete inside the timed step",
-                              "every_n_micro_steps": accum,
+                              "every_n_micro_steps": accum, "forced_single_rank": forced,
                               "exchange_bytes_timed": 2 * net_param_elems,     # bf16 gradient arena per rank and exchange (in: RS / AR; out: AG / AR)
                               "backend": backend, "rccl": rccl_info(),
                               "rccl_env": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS",
@@ -513,7 +552,7 @@ def main():
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(args.cpu_threads or None)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or forced:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -48,8 +48,11 @@ class TrainingConfig:                    # data/config.py:152-168
     prediction_type: str = "v_prediction"
     clip_grad_norm: float = 1.0
     num_workers: int = 4
+    save_final_model: bool = True        # data/config.py:170, config.yaml:39: main.py:108 saves on rank 0 after train() when set
     shard_optimizer: bool = True         # build-only key: data parallel = ZeRO-1 (reduce-scatter -> sharded fused AdamW ->
                                          # all-gather) instead of all-reduce + a full update on every rank
+    force_exchange: bool = False         # build-only key: drive the gradient exchange through the backend even at world size 1
+                                         # (one-GPU RCCL test, tests/test_gpu_rccl.py); SDXL_FORCE_EXCHANGE=1 does the same
 
 
 @dataclass

@@ -1607,7 +1607,7 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
   {   // software-pipelined one-wave-per-SIMD kernel (gemm_pl.hip): forced configuration 7, or the policy of knob 30 (linear problems whose tiles fit one round)
     const int fc = p.cfg > 0 ? p.cfg : g_force_cfg;
     bool use = fc == 7 || fc == 8;                       // (8: WITH the L2 prefetch wave -- measured, not used: gemm_pl.hip)
-    pl_set_prefetch(fc == 8 || KNOB(31) == 1);
+    const bool pl_pf = fc == 8 || KNOB(31) == 1;            // diagnostics build only (the product has no such instantiation)
     // Policy (knob 30 = 0): the linear problems whose 128 x 160 tiles are ONE round of the chip (129 .. 256 workgroups: the 4096-token level's
     // 1280-column outputs) -- forward projections and dgrads.  In the step (profiles/r05e_*): NN 4096 x 1280 x 10240 162 -> 106 us, x 3840
     // 67 -> 46, NT x 5120 66 -> 59; step -0.6 ms (the weight-gradient stream loses its co-resident partner while such a dgrad runs).
@@ -1619,7 +1619,7 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
       use = ((k30 & 1) && p.form == GEMM_NT && one_round) || ((k30 & 2) && p.form == GEMM_NN && one_round) || ((k30 & 512) && p.form == GEMM_NN && one_round && p.K >= 2560) ||
             ((k30 & 16) && tiles > 128 && tiles % 256 == 0) || ((k30 & 1024) && p.form == GEMM_NT && tiles > 256 && tiles % 256 == 0) || (k30 & 32);
     }
-    if (use && pl_applicable(p)) return launch_pl(p, 0, st);
+    if (use && pl_applicable(p)) return launch_pl(p, 0, st, pl_pf);
   }
   {   // co-resident 256-row kernel (gemm_cr256.hip): forced configurations 31 (160-column tiles) / 32 (128)
     const int fc = p.cfg > 0 ? p.cfg : g_force_cfg;

@@ -60,12 +60,14 @@ struct PlGeom {
   static constexpr int NMF = MI * NJ;                   // MFMAs per wave and half-step
 };
 
-// one LDS-DMA piece: M0 = slot base + constant, then the load (the s_nop: M0 write -> LDS-DMA needs one wait state).  Nothing else in
-// this kernel uses M0 (no s_movrel, no v_readlane by M0, no builtin LDS-DMA), so it is not restored.
+// one LDS-DMA piece: M0 = slot base + constant, then the load (the s_nop: M0 write -> LDS-DMA needs one wait state).  M0 is written and
+// read inside this one statement and NOT restored: it is declared clobbered, so a value hipcc might ever keep in M0 (s_movrel-style indexing
+// after some future edit) is not silently lost (hipcc warns that m0 is a reserved register: that warning is the point, -Wno-inline-asm is
+// not set).
 template <int OFF>
 __device__ __forceinline__ void pl_dma(i32x4 srd, unsigned voff, unsigned soff, unsigned slot_base) {
   asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-               :: "v"(voff), "s"(srd), "s"(soff), "s"(slot_base), "n"(OFF) : "memory", "scc");
+               :: "v"(voff), "s"(srd), "s"(soff), "s"(slot_base), "n"(OFF) : "memory", "scc", "m0");
 }
 
 __device__ __forceinline__ bf16x8 pl_z8() {
@@ -316,6 +318,11 @@ __global__ __launch_bounds__(PF ? 320 : 256, 2) void pl_kernel(const GemmP p) { 
     const unsigned sb = lds_w + (unsigned)wr * G::STAGE;
     phase(std::integral_constant<int, 0>{}, LIVE, f0, f1, (unsigned)rd * G::STAGE, std::integral_constant<int, 1>{}, sb);
     wait_vmcnt<(PL_S - 3) * NL + NP0>();            // my pieces of the next step have landed
+    // WAR on the ring slot, by a count instead of by timing: phase 0 of the NEXT step issues pieces into the slot whose half-1 fragments were
+    // read in phase 1 of the step before -- those reads must have RETIRED (not merely issued) in every wave before this barrier releases
+    // anyone into that phase.  gfx950 barriers do not wait for LDS traffic by themselves; the reads issued above are consumed right behind
+    // the barrier anyway, so the wait is close to free.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     const int rn = rd + 1 == PL_S ? 0 : rd + 1;
@@ -485,9 +492,9 @@ int launch_pl_prefetch_b(const GemmP& p, int parts, hipStream_t st) {
 }
 #endif
 
-static int g_pl_prefetch = 0;      // the L2 prefetch wave: OFF (measured: no gain on cold operands, -7 % on warm ones); sdxl_set_gemm_mode(4 * 8) forces the kernel with it
-void pl_set_prefetch(int on) { g_pl_prefetch = on; }
-int launch_pl(const GemmP& pin, int bn, hipStream_t st) {
+// prefetch: the L2 prefetch wave (configuration 8) -- measured, not used (no gain on cold operands, -7 % on warm ones); its instantiations exist in the
+// diagnostics build only, the product library carries the four plain kernels and ignores the flag.
+int launch_pl(const GemmP& pin, int bn, hipStream_t st, bool prefetch) {
   ARG_CHECK(pl_applicable(pin), "gemm_pl: problem %dx%dx%d (form %d) does not fit the pipelined kernel", pin.M, pin.N, pin.K, pin.form);
   GemmP p = pin;
   if (bn != 128 && bn != 160) bn = p.N % 160 == 0 ? 160 : 128;
@@ -502,11 +509,13 @@ int launch_pl(const GemmP& pin, int bn, hipStream_t st) {
       if (cost < best) { best = cost; p.xcd_px = px; }
     }
   }
-  const bool pf = g_pl_prefetch && p.K / PL_BK > PL_PF_LEAD;      // (short reductions: the prologue's three steps are most of it)
-  if (p.form == GEMM_NT) {
-    if (bn == 160) return pf ? launch_pl_k<GEMM_NT, 160, true>(p, st) : launch_pl_k<GEMM_NT, 160, false>(p, st);
-    return pf ? launch_pl_k<GEMM_NT, 128, true>(p, st) : launch_pl_k<GEMM_NT, 128, false>(p, st);
+#ifdef SDXL_DIAG
+  if (prefetch && p.K / PL_BK > PL_PF_LEAD) {      // (short reductions: the prologue's three steps are most of it)
+    if (p.form == GEMM_NT) return bn == 160 ? launch_pl_k<GEMM_NT, 160, true>(p, st) : launch_pl_k<GEMM_NT, 128, true>(p, st);
+    return bn == 160 ? launch_pl_k<GEMM_NN, 160, true>(p, st) : launch_pl_k<GEMM_NN, 128, true>(p, st);
   }
-  if (bn == 160) return pf ? launch_pl_k<GEMM_NN, 160, true>(p, st) : launch_pl_k<GEMM_NN, 160, false>(p, st);
-  return pf ? launch_pl_k<GEMM_NN, 128, true>(p, st) : launch_pl_k<GEMM_NN, 128, false>(p, st);
+#endif
+  (void)prefetch;
+  if (p.form == GEMM_NT) return bn == 160 ? launch_pl_k<GEMM_NT, 160, false>(p, st) : launch_pl_k<GEMM_NT, 128, false>(p, st);
+  return bn == 160 ? launch_pl_k<GEMM_NN, 160, false>(p, st) : launch_pl_k<GEMM_NN, 128, false>(p, st);
 }

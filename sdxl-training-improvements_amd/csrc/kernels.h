@@ -210,8 +210,7 @@ int launch_cr256(const GemmP& p, int bn, hipStream_t st, bool deep = false, bool
 int cr256_wgrad_cfg(int M, int N, long red, bool bias);
 // software-pipelined one-wave-per-SIMD kernel (gemm_pl.hip): 128 x 160 / 128 x 128 x 64 tiles, 4 waves, 4-deep ring; linear NT / NN, plain bf16 epilogue
 bool pl_applicable(const GemmP& p);
-void pl_set_prefetch(int on);
-int launch_pl(const GemmP& p, int bn, hipStream_t st);
+int launch_pl(const GemmP& p, int bn, hipStream_t st, bool prefetch = false);
 int launch_pl_prefetch_b(const GemmP& p, int parts, hipStream_t st);      // diagnostics build: L2 prefetch of B for a coming launch_pl (another stream)      // bn = 160 / 128 / 0 (160 where N % 160 == 0)
 int gemm_ln_cfg(int M, int N, int K);                  // GemmP::ln_x: the configuration such a launch takes (GemmP::cfg), 0 = not possible for this shape
 size_t gemm_ln_part_floats(int M, int N);

@@ -32,9 +32,10 @@ def init_process_group(backend: Optional[str] = None) -> None:
     if dist.is_initialized():
         return
     rank, local_rank, world = env_rank_world()
-    if world <= 1:
+    if world <= 1 and os.environ.get("SDXL_FORCE_EXCHANGE", "0") != "1":      # (a forced single-rank group: GradSync(force=True))
         return
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -71,11 +72,16 @@ class GradSync:
     torch copy in the CPU tests); buckets are reduced in the order their segments finish."""
 
     def __init__(self, total_elems: int, cast: Callable[[int, int, torch.Tensor], None], comm_dtype=torch.bfloat16,
-                 device="cuda", group=None):
+                 device="cuda", group=None, force: bool = False):
         self.world = get_world_size()
         self.group = group
         self.cast = cast
-        self.comm = torch.zeros(total_elems, dtype=comm_dtype, device=device) if self.world > 1 else None
+        # active: the exchange really runs.  At world size 1 there is nothing to exchange and every method is a no-op -- unless `force`
+        # is set on an initialised process group: then a single rank drives the SAME calls (casts into the exchange arena, collectives on
+        # the engine's side stream, sharded update, all-gather) through the backend.  That is how one GPU exercises RCCL's stream, dtype
+        # and alignment checks (tests/test_gpu_rccl.py); the result equals the unexchanged step on the bf16-rounded gradients.
+        self.active = self.world > 1 or (bool(force) and dist.is_initialized())
+        self.comm = torch.zeros(total_elems, dtype=comm_dtype, device=device) if self.active else None
         self.pending: List = []
         self.enabled = True
 
@@ -84,7 +90,7 @@ class GradSync:
         return 1.0 / self.world
 
     def on_segment(self, k: int, offset: int, count: int) -> None:
-        if self.world < 2 or not self.enabled:
+        if not self.active or not self.enabled:
             return
         buf = self.comm[offset:offset + count]
         self.cast(offset, count, buf)
@@ -117,11 +123,11 @@ class ShardedGradSync(GradSync):
     Every bucket (= backward segment, sizes multiples of 8 * world elements) is reduce-scattered as soon as its segment
     is enqueued; this rank's slices land back to back in `gshard` (bf16, total / world elements)."""
 
-    def __init__(self, total_elems: int, cast, comm_dtype=torch.bfloat16, device="cuda", group=None):
-        super().__init__(total_elems, cast, comm_dtype, device, group)
-        self.rank = dist.get_rank(group) if self.world > 1 else 0
+    def __init__(self, total_elems: int, cast, comm_dtype=torch.bfloat16, device="cuda", group=None, force: bool = False):
+        super().__init__(total_elems, cast, comm_dtype, device, group, force)
+        self.rank = dist.get_rank(group) if self.active else 0
         self.gshard = torch.zeros((total_elems + self.world - 1) // self.world + 8, dtype=comm_dtype, device=device) \
-            if self.world > 1 else None
+            if self.active else None
         self.pieces: List = []          # (arena offset of this rank's slice, count, offset into gshard), in exchange order
         self.buckets: List = []         # (arena offset, count) of every bucket
         self._cursor = 0
@@ -141,7 +147,7 @@ class ShardedGradSync(GradSync):
         return offset + rank * n, n
 
     def on_segment(self, k: int, offset: int, count: int) -> None:
-        if self.world < 2 or not self.enabled:
+        if not self.active or not self.enabled:
             return
         if k == 0:
             self.begin()
@@ -158,11 +164,11 @@ class ShardedGradSync(GradSync):
 
     def reduced(self) -> Optional[torch.Tensor]:
         """This rank's averaged gradient slices (bf16), `pieces` says where each lives in the arena."""
-        return None if self.world < 2 else self.gshard[:self._cursor]
+        return None if not self.active else self.gshard[:self._cursor]
 
     def global_sumsq(self, local_sumsq: torch.Tensor) -> torch.Tensor:
         """sum over ranks of the slices' squared norms: one float on the wire, the same bits on every rank."""
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(local_sumsq, op=dist.ReduceOp.SUM, group=self.group)
         return local_sumsq
 
@@ -174,7 +180,7 @@ class ShardedGradSync(GradSync):
         """all-gather this rank's slices of any arena-layout tensor (parameters after the sharded update; the optimizer's
         exp_avg / exp_avg_sq / shift before a checkpoint, so that optimizer.pt holds every rank's state, not rank 0's stale copy)
         into every rank's full copy, bucket by bucket (same buckets / slices as the exchange).  Collective: every rank calls it."""
-        if self.world < 2:
+        if not self.active:
             return
         works = []
         for (off, cnt), (poff, n, _g) in zip(self.buckets, self.pieces):
@@ -187,7 +193,7 @@ class ShardedGradSync(GradSync):
 
 
 def make_grad_sync(total_elems: int, cast, comm_dtype=torch.bfloat16, device="cuda", sharded: bool = True,
-                   segment_sizes: Optional[List[int]] = None, group=None) -> GradSync:
+                   segment_sizes: Optional[List[int]] = None, group=None, force: bool = False) -> GradSync:
     """ShardedGradSync (ZeRO-1) where every backward segment splits into `world` slices of whole 16-byte vectors, else the
     all-reduce GradSync.  Segments are multiples of 64 elements (the arena's alignment), so reduce-scatter works for world sizes
     that divide 8 (2, 4, 8); any other world size (3, 5, 6, 7, 16 = 2 nodes x 8, ...) falls back to all-reduce + the full update
@@ -199,4 +205,4 @@ def make_grad_sync(total_elems: int, cast, comm_dtype=torch.bfloat16, device="cu
                       f"falling back to all-reduce + unsharded optimizer update (world size {world})")
         sharded = False
     cls = ShardedGradSync if sharded else GradSync
-    return cls(total_elems, cast, comm_dtype, device, group)
+    return cls(total_elems, cast, comm_dtype, device, group, force)

@@ -30,6 +30,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import math
+import os
 import time
 from collections import defaultdict
 from pathlib import Path
@@ -104,8 +105,10 @@ class NativeSDXLTrainer:
         # data parallel: ZeRO-1 (reduce-scatter, sharded fused AdamW, all-gather) with the fused optimizer, else all-reduce
         want_sharded = bool(getattr(self.config.training, "shard_optimizer", True)) and isinstance(self.optimizer, AdamWBF16)
         seg_sizes = [n for _off, n in self.net.segment_ranges()] if hasattr(self.net, "segment_ranges") else None
+        # force_exchange (build-only key / SDXL_FORCE_EXCHANGE=1): run the exchange through the backend even at world size 1
+        force = bool(getattr(self.config.training, "force_exchange", False)) or os.environ.get("SDXL_FORCE_EXCHANGE", "0") == "1"
         self.sync = D.make_grad_sync(self.net.param_elems, self._cast, torch.bfloat16, getattr(self.net, "device", "cpu"),
-                                     sharded=want_sharded, segment_sizes=seg_sizes)
+                                     sharded=want_sharded, segment_sizes=seg_sizes, force=force)
         self.sharded = isinstance(self.sync, D.ShardedGradSync)      # (falls back to all-reduce where the segments do not split)
         self._emit = False                   # this backward's weight-gradient GEMMs write the bf16 exchange arena themselves
         self._micro = 0                      # micro-step index inside the accumulation cycle
@@ -195,7 +198,7 @@ class NativeSDXLTrainer:
         if first and not self._zeroed:       # the small-parameter gradients accumulate with atomics: zero them per cycle
             self.net.zero_grads()
         world = self.sync.world
-        exchange = self._exchange and world > 1
+        exchange = self._exchange and self.sync.active
         self.sync.enabled = exchange
         # per-segment joins (side stream -> caller's stream) only on the micro-step that exchanges gradients
         if exchange:    # bucket casts + collectives ride the engine's side stream, behind the segment's weight gradients
@@ -243,14 +246,14 @@ class NativeSDXLTrainer:
         reduce-scattered slices + one float all-reduced -- the coefficient is then the same bits on every rank."""
         self.sync.finish()                                   # the asynchronous exchange must have landed
         fused = isinstance(self.optimizer, AdamWBF16)        # the coefficient rides into the fused optimizer kernel
-        g = self.sync.reduced() if self.sync.world > 1 else self.net.grads
+        g = self.sync.reduced() if self.sync.active else self.net.grads
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream) if g.is_cuda else None
         if g.is_cuda:                                        # squared norm + coefficient on the device (HIP kernels)
             buf = torch.empty(2, dtype=torch.float32, device=g.device)
             n = (g.numel() // 8) * 8
             lib.check(self.net.L.sdxl_sumsq(C.c_void_p(g.data_ptr()), 0 if g.dtype == torch.float32 else 1, n,
                                             C.c_void_p(buf.data_ptr()), st), "sdxl_sumsq")
-            if self.sharded and self.sync.world > 1:
+            if self.sharded and self.sync.active:
                 self.sync.global_sumsq(buf[0:1])
             lib.check(self.net.L.sdxl_clip_coef(C.c_void_p(buf.data_ptr()), float(max_norm),
                                                 C.c_void_p(buf.data_ptr() + 4), st), "sdxl_clip_coef")
@@ -260,7 +263,7 @@ class NativeSDXLTrainer:
                 g.mul_(buf[1])
             return float(buf[0].sqrt())                      # the reference logs the norm (one read-back)
         sq = g.float().pow(2).sum().reshape(1)               # host-logic tests with a stand-in net (no GPU)
-        if self.sharded and self.sync.world > 1:
+        if self.sharded and self.sync.active:
             self.sync.global_sumsq(sq)
         norm = float(sq.sqrt())
         coef = max_norm / (norm + 1e-6) if norm > max_norm else 1.0
@@ -277,11 +280,11 @@ class NativeSDXLTrainer:
             gn = self.clip_grad_norm_(float(self.config.training.clip_grad_norm))
         if self.optimizer is not None:
             if isinstance(self.optimizer, AdamWBF16):
-                if self.sync.world > 1 and self.sharded:     # ZeRO-1: update this rank's slices, then all-gather the parameters
+                if self.sync.active and self.sharded:        # ZeRO-1: update this rank's slices, then all-gather the parameters
                     self.optimizer.step(self.sync.reduced(), grad_scale=self._clip_coef, pieces=self.sync.pieces)
                     self.sync.gather_params(self.net.weights)
                 else:
-                    self.optimizer.step(self.sync.reduced() if self.sync.world > 1 else None, grad_scale=self._clip_coef)
+                    self.optimizer.step(self.sync.reduced() if self.sync.active else None, grad_scale=self._clip_coef)
                 self._clip_coef = None
             else:
                 self.optimizer.step()
@@ -330,10 +333,14 @@ class NativeSDXLTrainer:
                     best = mean
                     self.prepare_checkpoint()
                     self.save_checkpoint(epoch + 1, is_final=False)
-        # Every rank leaves train() with the COMPLETE optimizer state in place: the reference's main.py:110-111 calls
-        # save_checkpoint(path) on rank 0 only right after train() returns -- under ZeRO-1 that save would otherwise write rank 0's
-        # slices of the moments (`zero1_partial`, which load_optimizer_state refuses).  One all-gather of three arenas per train() call.
-        self.prepare_checkpoint()
+        # The reference's main.py:108-111 calls save_checkpoint(path) on rank 0 only right after train() returns, when
+        # `training.save_final_model` is set (config.yaml:39, the default).  Under ZeRO-1 that save needs every rank's slices of the
+        # moments, and save_checkpoint itself may hold no collective -- so the gather (three arenas, every rank) happens here, but only
+        # when a save can follow: this loop's own final checkpoint, or the caller's under save_final_model.  Without either, train() ends
+        # without any collective beyond the steps', and a rank-0-only save afterwards fails loudly (save_checkpoint) instead of writing
+        # a state that could not be resumed.
+        if save_checkpoints or bool(getattr(self.config.training, "save_final_model", True)):
+            self.prepare_checkpoint()
         if save_checkpoints:
             self.save_checkpoint(num_epochs, is_final=True)
 
@@ -356,7 +363,7 @@ class NativeSDXLTrainer:
         # No collective in here: the reference calls save_checkpoint on rank 0 only (main.py:110-111, flow_matching_trainer.py:218-219,
         # ddpm_trainer.py:235-237), so a gather at this point would leave rank 0 alone in it.  Under ZeRO-1 the complete optimizer
         # state needs prepare_checkpoint() on EVERY rank first (train() does that); without it optimizer.pt holds rank 0's slices of
-        # exp_avg / exp_avg_sq / shift and says so (`zero1_partial`).
+        # exp_avg / exp_avg_sq / shift only: that raises (after the weights and config.json were written).
         if not D.is_main_process():
             return None
         save_dir = checkpoint_dir(epoch_or_path, is_final)
@@ -369,14 +376,14 @@ class NativeSDXLTrainer:
             (save_dir / "unet").mkdir(exist_ok=True)
             save_file({k: v.cpu().contiguous() for k, v in self.net.state_dict().items()},
                       str(save_dir / "unet" / "diffusion_pytorch_model.safetensors"))
-        if self.optimizer is not None and callable(getattr(self.optimizer, "state_dict", None)):
-            torch.save(self._optimizer_state_for_save(), str(save_dir / "optimizer.pt"))
         with open(save_dir / "config.json", "w") as f:
             json.dump(self.config.to_dict(), f, indent=2)
+        if self.optimizer is not None and callable(getattr(self.optimizer, "state_dict", None)):
+            torch.save(self._optimizer_state_for_save(), str(save_dir / "optimizer.pt"))      # (raises under ZeRO-1 on a stale state)
         return save_dir
 
     def _zero1_active(self) -> bool:
-        return bool(self.sharded and self.sync.world > 1 and isinstance(self.optimizer, AdamWBF16) and getattr(self.sync, "buckets", None))
+        return bool(self.sharded and self.sync.active and isinstance(self.optimizer, AdamWBF16) and getattr(self.sync, "buckets", None))
 
     def prepare_checkpoint(self) -> None:
         """COLLECTIVE -- every rank calls it, at the same point of its loop, before rank 0 calls save_checkpoint().  Under ZeRO-1
@@ -395,11 +402,14 @@ class NativeSDXLTrainer:
         if isinstance(osd.get("state"), dict):
             osd["state"] = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in osd["state"].items()}
         if self._zero1_active() and getattr(self, "_opt_state_step", object()) != self._step_counter():
-            import warnings
-            warnings.warn("save_checkpoint under ZeRO-1 without prepare_checkpoint() on every rank: optimizer.pt holds this rank's "
-                          "slices of the moments only (zero1_partial)")
-            osd["zero1_partial"] = {"rank": int(self.sync.rank), "world": int(self.sync.world),
-                                    "pieces": [(int(a), int(n)) for a, n, _ in self.sync.pieces]}
+            # Surfaces at SAVE time, not at resume time: a file with this rank's slices only could never be loaded again
+            # (load_optimizer_state refuses it), and the run that could still have gathered the state would be long gone.
+            raise RuntimeError(
+                "save_checkpoint under ZeRO-1 without prepare_checkpoint() on every rank since the last optimizer step: this rank "
+                f"(rank {int(self.sync.rank)} of {int(self.sync.world)}) holds only its own slices of exp_avg / exp_avg_sq / shift. "
+                "Call prepare_checkpoint() on EVERY rank first (train() does, before a final save), or train with "
+                "training.shard_optimizer = false when the caller's loop saves on rank 0 only (INTEGRATION.md section 3). "
+                "The model weights and config.json of this checkpoint were written; optimizer.pt was not.")
         return osd
 
     def save_optimizer_state(self, save_dir) -> None:

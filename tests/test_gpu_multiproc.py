@@ -37,7 +37,8 @@ def run_dist(args, port, env, timeout=300, tries=3):
 
 def test_two_ranks_one_device_gloo():
     env = dict(os.environ, SDXL_BENCH_BACKEND="gloo", SDXL_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
-    r = run_dist([str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-optimizer", "--profile-steps", "0"], 29541, env)
+    r = run_dist([str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-optimizer", "--profile-steps", "0",
+                  "--exchange", "allreduce"], 29541, env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints exactly one JSON line
@@ -45,7 +46,7 @@ def test_two_ranks_one_device_gloo():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
     assert out["scaling"] == "weak" and out["value"] > 0 and out["steps"] == 1
     assert 0 < out["loss"] < 1000
-    ex = out["config"]["exchange"]                                  # the timed region holds a COMPLETE exchange (default: all-reduce)
+    ex = out["config"]["exchange"]                                  # the timed region holds a COMPLETE exchange (--exchange allreduce: the reference point)
     assert "all-reduce" in ex["what"] and ex["exchange_bytes_timed"] == 2 * 2567486784 and ex["every_n_micro_steps"] == 1
     st = out["step_time"]
     assert st["n"] == 1 and 0 < st["min_ms"] <= st["median_ms"] <= st["max_ms"]
@@ -53,10 +54,10 @@ def test_two_ranks_one_device_gloo():
 
 def test_two_ranks_mixed_buckets_accum4_zero1_gloo():
     """configs[4] as a bench workload: the two bucket plans alternate per micro-step, gradients are exchanged on every 4th
-    micro-step only; with --exchange zero1 the timed region holds reduce-scatter AND the parameter all-gather."""
+    micro-step only; the default exchange (zero1 = the trainer's default) puts reduce-scatter AND the parameter all-gather in the timed region."""
     env = dict(os.environ, SDXL_BENCH_BACKEND="gloo", SDXL_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
     r = run_dist([str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "0", "--no-optimizer", "--profile-steps", "0",
-                  "--workload", "flow_mixed_accum4", "--exchange", "zero1"], 29545, env)
+                  "--workload", "flow_mixed_accum4"], 29545, env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     ex = out["config"]["exchange"]
