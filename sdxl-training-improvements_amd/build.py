@@ -2,8 +2,8 @@
 
     python sdxl-training-improvements_amd/build.py [--force] [--diag]
 
---diag builds libsdxlstep_diag.so instead: the same sources + csrc/gemm_sk.hip with -DSDXL_DIAG (experiment knobs, stream-K GEMM,
-phase-plane stride-2 convolution, W = 32 three-tap weight gradient: include/sdxlstep_diag.h).  The product library has none of them.
+--diag builds libsdxlstep_diag.so instead: the same sources + csrc/gemm_sk.hip + csrc/attention_pl.hip with -DSDXL_DIAG (experiment knobs,
+stream-K GEMM, software-pipelined attention forward, phase-plane stride-2 convolution, W = 32 three-tap weight gradient: include/sdxlstep_diag.h).  The product library has none of them.
 
 hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with the snapshot.
 """
@@ -21,9 +21,9 @@ OBJ = HERE / "build"
 LIB = HERE / "libsdxlstep.so"
 OBJ_DIAG = HERE / "build_diag"
 LIB_DIAG = HERE / "libsdxlstep_diag.so"
-DIAG_SOURCES = ["gemm_sk.hip"]
+DIAG_SOURCES = ["gemm_sk.hip", "attention_pl.hip"]
 SOURCES = ["gemm.hip", "gemm256.hip", "conv_wgrad3.hip", "wgrad256.hip", "gemm_cr256.hip", "gemm_pl.hip", "attention.hip", "norm.hip", "elementwise.hip", "loss.hip", "optimizer.hip", "engine.hip", "capi.hip"]
-HEADERS = ["common.h", "kernels.h", "gemm_tiles.h", "engine.h", "../../include/sdxlstep.h", "../../include/sdxlstep_diag.h"]
+HEADERS = ["common.h", "kernels.h", "gemm_tiles.h", "attn_tiles.h", "engine.h", "../../include/sdxlstep.h", "../../include/sdxlstep_diag.h"]
 # -fvisibility=hidden: the dynamic symbol table holds the SDXL_API entry points of include/sdxlstep.h / sdxlstep_diag.h and nothing else
 # (no C++ internals, no __device_stub__s); tests/test_host_boundary.py checks `nm -D`
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fvisibility-inlines-hidden", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]

@@ -1,0 +1,532 @@
+// Software-pipelined, one-wave-per-SIMD flash-attention FORWARD (head_dim 64, no mask, softmax scale 1/8) for gfx950.
+// STATUS: diagnostics build only (sdxl_set_knob(33, 2 | 3)).  Parity-green on every forward case of tests/test_gpu_ops.py, and AT PARITY with
+// the tiled kernel of attention.hip on one box, three alternations (profiles/r06f_attn_ab.txt: 4096 x 4096 x 40 pairs 216-221 us tiled,
+// 219-221 us this kernel with 4 waves, 216-219 us with 8; 1024 x 1024 x 80 33.0-33.4 / 34.6 / 34.1-34.2 us): the instruction mix of a
+// 16-query x 64-key unit at d = 64 -- 16 MFMAs + 16 v_exp + 16 v_add + 8 v_cvt_pk -- does NOT fit the MFMA shadow on this chip.  One wave
+// per SIMD issues it in 412-475 cycles against 268 for the sixteen MFMAs alone (16 v_exp alone: 171, 24 adds / conversions alone: 143: a
+// lone wave issues one simple VALU instruction per ~6 cycles; profiles/r06e_attn_step_shadow.txt, tools/attn_step_shadow.hip), two waves per
+// SIMD in 171-190 ns per unit against 117; inside the kernel PMC counts 598 wave-cycles per unit (VALU pipe active 345, MFMA busy 256,
+// dependency and counter waits ~200; profiles/r06b_pmc_attn_fwd_pl.txt), and two rounds of 256 workgroups lose another 16 % between them.
+// The tiled kernel's three co-resident waves per SIMD reach the same 340 ns per unit by a different road.  What this file keeps: the
+// structure, its hazard rules (below) and the measurements; the step runs attention.hip.
+// Written to replace, for self-attention-shaped problems (Nk >= 256), the multi-wave-per-SIMD attn_fwd_kernel of attention.hip, which relies
+// on three co-resident workgroups per CU to overlap one wave's softmax arithmetic (VALU) with another wave's products (matrix pipe) and
+// measures 1 390 cycles per 32-query x 64-key wave tile against 512 cycles of MFMA (profiles/r02g_attention_anatomy.txt).  Reference semantics:
+// the fused attention the reference asks its toolchain for (flow_matching_trainer.py:69-76), called inside unet(...) (ddpm_trainer.py:320-325).
+//
+// Structure (the gemm_pl.hip treatment):
+//   * ONE 4-wave workgroup per CU (launch bounds 256 x 1: the whole 512-register file per wave), each wave owns up to NQ = 5 query blocks of
+//     16 rows and runs an explicit software pipeline over UNITS u = (key tile t, query block i):
+//         phase(u):   matrix pipe: S^T(u + 1) = K . Q^T   (8 x v_mfma_f32_16x16x32_bf16)  and  O^T(u - 1) += V^T . P^T(u - 1)   (8 x)
+//                     VALU:        P^T(u) = exp2(S^T(u))  (16 v_exp, 16 adds for the row sums, 8 v_cvt_pk)  -- between the MFMAs, two
+//                                  or three instructions per MFMA, pinned by sched_barrier
+//     so every MFMA has independent VALU work of ANOTHER unit to hide under it and vice versa: no wave waits for its own softmax.
+//   * Orientation as in attention.hip (scores transposed: a lane owns one query column and 4 keys per 16-key block; P^T feeds the second
+//     product as its B operand without data movement; V^T by ds_read_b64_tr_b16).  The K (8 x b128) and V^T (16 x tr_b64) fragments of a
+//     tile are read ONCE per wave and tile and serve all its query blocks: 24 LDS reads per 80 MFMAs.
+//   * K | V tiles by LDS-DMA into a 4-deep ring (64 KiB), three tiles ahead, counted s_waitcnt vmcnt(4) + ONE barrier per key tile.
+//   * NO softmax reference in the loop: P = exp2(score) with the score straight from the matrix pipe (Q pre-scaled by scale * log2 e).
+//     Softmax is shift-invariant and fp32 sums / bf16 P carry 8 exponent bits, so this is exact to rounding whenever a row's largest score
+//     (log2 domain) lies within (-100, 100); the row sum shows after the loop whether it did (2^-100 < l < 2^100), and a workgroup holding
+//     a row outside redoes the phase with the running-maximum form (rare: |q . k| / 8 > 69).  No maximum, no rescale, no pre-pass.
+//   * Work split in the FLATTENED (batch-head pair, 16-row query block) space: workgroup c owns blocks [4 NQ c, 4 NQ (c + 1)), block
+//     4 j + w of them is wave w's j-th.  A range that crosses a pair boundary is processed pair by pair ("phases": the waves' blocks of
+//     the first pair against that pair's keys, then the rest against the next pair's).  With NQ = 5 (320 rows per workgroup) the model's
+//     shapes are whole rounds of the chip: 80 pairs x 1024 rows = 256 workgroups, 40 x 4096 = 512, 80 x 1008 = 252, 40 x 4032 = 504 --
+//     the 2.5-waves-per-SIMD quantisation of the 128-row workgroups at N = 1024 (profiles/r05o_attn_quantisation.txt) is gone.
+//   * XCD-aware: workgroup ids are mapped so that an XCD owns a contiguous range of the flattened space = a few whole pairs, whose K / V
+//     tiles then live in that XCD's L2.
+#include "attn_tiles.h"
+
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+constexpr int APL_RING = 4;                       // K | V tile pairs in the LDS ring
+constexpr int APL_SLOT = 2 * TILE_ELEMS;          // elements per ring slot: K tile, then V tile (16 KiB)
+constexpr int APL_SMEM = APL_RING * APL_SLOT * 2 + 64;      // + the overflow flag
+
+template <typename F, int... I>
+__device__ __forceinline__ void apl_sfor_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void apl_sfor(F&& f) { apl_sfor_impl(f, std::make_integer_sequence<int, N>{}); }
+
+struct AplK { bf16x8 f[4][2]; };      // K fragments of a tile: [16-key block][k half of d]
+struct AplV { bf16x8 f[4][2]; };      // V^T fragments: [16-column block of d][32-key step]
+typedef __attribute__((ext_vector_type(2))) __bf16 apl_bf16x2;
+typedef unsigned apl_u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void apl_read_k(AplK& k, const bf16* Kt, int l16, int g) {
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    k.f[kb][0] = ld_frag(Kt, kb * 16 + l16, g * 8);
+    k.f[kb][1] = ld_frag(Kt, kb * 16 + l16, 32 + g * 8);
+  }
+}
+__device__ __forceinline__ void apl_read_v(AplV& v, const bf16* Vt, int l16, int g) {
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) v.f[db][t2] = tr_frag(Vt, t2, db * 16, l16, g);
+}
+__device__ __forceinline__ unsigned apl_pack2(float a, float b) {
+  apl_bf16x2 v;
+  v[0] = (bf16)a;
+  v[1] = (bf16)b;
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ bf16x8 apl_as_frag(const apl_u4& u) { return __builtin_bit_cast(bf16x8, u); }
+
+// The products are issued from inline asm so that their register classes are the author's choice (hipcc, given more than 256 registers,
+// keeps MFMA results in AGPRs and shuttles them: 16 v_accvgpr_read per unit for the scores, 16 v_accvgpr_mov for the two-address O^T
+// accumulators): scores in VGPRs (the VALU reads them), O^T in AGPRs (only the matrix pipe touches it until the epilogue), A / B operands
+// in VGPRs.  hipcc does not pad hazards around asm statements: a score block is consumed by the VALU a whole phase (>= 8 MFMAs) after the
+// product that completes it, a P fragment is consumed by the matrix pipe a phase after the VALU wrote it, and the epilogue reads O^T behind
+// explicit wait states (apl_mfma_drain).  The other direction bit once: hipcc moves an O^T quad between AGPRs (v_accvgpr_mov) or copies an
+// operand (v_mov) wherever its allocation changes between code paths, also right in front of a statement whose MFMA reads it -- a VALU write
+// needs two wait states before an MFMA reads the register (wrong O^T, right row sums: N = 4 blocks on a ragged key length).  Hence: the
+// stand-alone MFMA statements open with s_nop 1, the merged step statement (apl_step) opens with its two exponentials.
+__device__ __forceinline__ void apl_mfma_s0(f32x4& d, const bf16x8& a, const bf16x8& b) {      // d = a . b
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void apl_mfma_s1(f32x4& d, const bf16x8& a, const bf16x8& b) {      // d += a . b (VGPR accumulator)
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+}
+template <bool OA>
+__device__ __forceinline__ void apl_mfma_o(f32x4& d, const bf16x8& a, const bf16x8& b) {       // d += a . b (OA: AGPR accumulator)
+  if (OA) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
+  else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+}
+// The softmax fillers are asm statements as well: volatile asm statements keep their program order, so the instruction stream of a phase is
+// the one written below -- MFMA, two exponentials, MFMA, two adds, one conversion -- where hipcc, left to itself, gathers the sixteen
+// exponentials of a unit behind the sixteen products (its SLP pass packs the row-sum adds and drags their operands along).
+// gfx950: a VALU instruction must not read a transcendental's result in the very next issue slot (one wait state): an MFMA sits between.
+__device__ __forceinline__ void apl_exp2x2(float& e0, float& e1, const float s0, const float s1) {
+  asm volatile("v_exp_f32 %0, %2\n\tv_exp_f32 %1, %3" : "=&v"(e0), "=v"(e1) : "v"(s0), "v"(s1));
+}
+__device__ __forceinline__ void apl_add2(float& a, float& b, const float x, const float y) {
+  asm volatile("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3" : "+v"(a), "+v"(b) : "v"(x), "v"(y));
+}
+__device__ __forceinline__ unsigned apl_cvt_pk(const float lo, const float hi) {
+  unsigned r;
+  asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// One step of a phase as ONE statement (hipcc pads a wait state behind every asm statement that ends in an MFMA; seven separate statements per
+// step cost eight s_nop issue slots per unit): the two exponentials of unit u's score pair k, the S^T(u + 1) product, the two row-sum adds of
+// pair k - 1, the O^T(u - 1) product, the conversion of pair k - 1 -- the consumers run ONE STEP behind the exponentials: a transcendental's result read two
+// issue slots later stalls the wave (one wave per SIMD: nobody fills the slot; PMC: 124 of 598 cycles per unit were such dependency stalls).
+// KS0: first half of the reduction over d (the score block starts from 0), else accumulate.  CONS: a pair k - 1 exists (not in step 0).
+template <bool KS0, bool OA, bool CONS>
+__device__ __forceinline__ void apl_step(f32x4& s, const bf16x8& ka, const bf16x8& qb, const float x0, const float x1, f32x4& o, const bf16x8& va,
+                                         const bf16x8& pb, float& e0, float& e1, const float pe0, const float pe1, float& la, float& lb, unsigned& pd) {
+#define APL_HEAD(C0) "v_exp_f32 %1, %9\n\tv_exp_f32 %2, %10\n\tv_mfma_f32_16x16x32_bf16 %0, %7, %8, " C0
+#define APL_O "\n\tv_mfma_f32_16x16x32_bf16 %3, %11, %12, %3"
+#define APL_ADD "\n\tv_add_f32 %4, %4, %13\n\tv_add_f32 %5, %5, %14"
+#define APL_TAIL APL_ADD APL_O "\n\tv_cvt_pk_bf16_f32 %6, %13, %14"
+#define APL_INS : "v"(ka), "v"(qb), "v"(x0), "v"(x1), "v"(va), "v"(pb), "v"(pe0), "v"(pe1)
+  if (CONS) {
+    if (KS0 && OA) asm volatile(APL_HEAD("0") APL_TAIL : "=&v"(s), "=&v"(e0), "=&v"(e1), "+a"(o), "+v"(la), "+v"(lb), "=&v"(pd) APL_INS);
+    else if (KS0) asm volatile(APL_HEAD("0") APL_TAIL : "=&v"(s), "=&v"(e0), "=&v"(e1), "+v"(o), "+v"(la), "+v"(lb), "=&v"(pd) APL_INS);
+    else if (OA) asm volatile(APL_HEAD("%0") APL_TAIL : "+v"(s), "=&v"(e0), "=&v"(e1), "+a"(o), "+v"(la), "+v"(lb), "=&v"(pd) APL_INS);
+    else asm volatile(APL_HEAD("%0") APL_TAIL : "+v"(s), "=&v"(e0), "=&v"(e1), "+v"(o), "+v"(la), "+v"(lb), "=&v"(pd) APL_INS);
+  } else {
+    if (KS0 && OA) asm volatile(APL_HEAD("0") APL_O : "=&v"(s), "=&v"(e0), "=&v"(e1), "+a"(o), "+v"(la), "+v"(lb), "=&v"(pd) APL_INS);
+    else if (KS0) asm volatile(APL_HEAD("0") APL_O : "=&v"(s), "=&v"(e0), "=&v"(e1), "+v"(o), "+v"(la), "+v"(lb), "=&v"(pd) APL_INS);
+    else if (OA) asm volatile(APL_HEAD("%0") APL_O : "+v"(s), "=&v"(e0), "=&v"(e1), "+a"(o), "+v"(la), "+v"(lb), "=&v"(pd) APL_INS);
+    else asm volatile(APL_HEAD("%0") APL_O : "+v"(s), "=&v"(e0), "=&v"(e1), "+v"(o), "+v"(la), "+v"(lb), "=&v"(pd) APL_INS);
+  }
+#undef APL_HEAD
+#undef APL_O
+#undef APL_ADD
+#undef APL_TAIL
+#undef APL_INS
+}
+// the consumers of a unit's last score pair (behind step 7)
+__device__ __forceinline__ void apl_consume(const float pe0, const float pe1, float& la, float& lb, unsigned& pd) {
+  asm volatile("v_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %4\n\tv_cvt_pk_bf16_f32 %2, %3, %4" : "+v"(la), "+v"(lb), "=&v"(pd) : "v"(pe0), "v"(pe1));
+}
+// half sets of a tile's fragments (k half ks of every K block / key step t2 of every V^T block): the registers of one half are free as soon as
+// the four products of the running phase that use them have been issued, four steps before the other half's
+__device__ __forceinline__ void apl_read_k_half(AplK& k, const bf16* Kt, int ks, int l16, int g) {
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) k.f[kb][ks] = ld_frag(Kt, kb * 16 + l16, ks * 32 + g * 8);
+}
+__device__ __forceinline__ void apl_read_v_half(AplV& v, const bf16* Vt, int t2, int l16, int g) {
+#pragma unroll
+  for (int db = 0; db < 4; ++db) v.f[db][t2] = tr_frag(Vt, t2, db * 16, l16, g);
+}
+__device__ __forceinline__ void apl_mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory"); }      // 24 wait states: MFMA result -> VALU / v_accvgpr_read
+
+// One phase: this wave's N query blocks qb0, qb0 + 4, ... of pair bh against all key tiles of that pair.  N = 0: the wave only stages tiles
+// and joins the barriers (every wave of the workgroup executes the same barrier sequence whatever its N).
+// NW: waves per workgroup (4: one per SIMD, 512 registers, O^T in AGPRs | 8: two per SIMD, 256 registers); the wave's blocks are NW apart.
+template <int N, int NW>
+__device__ __forceinline__ void apl_phase(const AttnP& p, bf16* sm, const int bh, const int qb0, const int lane, const int wave) {
+  constexpr bool OA = NW == 4;
+  constexpr int PPW = 8 / NW;               // 1 KiB pieces of a [64][64] tile per wave
+  const int l16 = lane & 15, g = lane >> 4;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const bf16* Qb = p.Q + (long)b * p.Nq * p.ldq + h * HD;
+  const bf16* Kb = p.K + (long)b * p.Nk * p.ldk + h * HD;
+  const bf16* Vb = p.V + (long)b * p.Nk * p.ldv + h * HD;
+  const int ntiles = (p.Nk + 63) >> 6;                 // >= 4 (launcher)
+  unsigned* flag = (unsigned*)(sm + APL_RING * APL_SLOT);
+  // K | V tiles by LDS-DMA through raw buffer descriptors: one constant per-lane byte offset per piece (row 8 (2 wave + j) + lane / 8 of the tile,
+  // 16-byte vector (lane % 8) ^ (row % 8): the tile image's swizzle on the SOURCE side) + the tile's offset; rows beyond Nk and whole
+  // tiles beyond the last lie beyond num_records: zeros, no memory traffic.
+  const i32x4 ksrd = make_srd(Kb, (unsigned)((((long)p.Nk - 1) * p.ldk + HD) * 2));
+  const i32x4 vsrd = make_srd(Vb, (unsigned)((((long)p.Nk - 1) * p.ldv + HD) * 2));
+  unsigned kvo[PPW], vvo[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int r = (wave * PPW + j) * 8 + (lane >> 3);
+    kvo[j] = (unsigned)((r * p.ldk + (((lane & 7) ^ (r & 7)) << 3)) * 2);
+    vvo[j] = (unsigned)((r * p.ldv + (((lane & 7) ^ (r & 7)) << 3)) * 2);
+  }
+  const unsigned ktile_bytes = (unsigned)(64 * p.ldk * 2), vtile_bytes = (unsigned)(64 * p.ldv * 2);
+  const unsigned lds0 = lds_addr_of(sm);
+  auto stage = [&](int t) {      // K | V tiles t -> ring slot t % 4: 4 LDS-DMA pieces of 1 KiB per wave
+    const unsigned slot = lds0 + (unsigned)(t & (APL_RING - 1)) * (APL_SLOT * 2) + (unsigned)wave * (PPW * 1024u);
+    // (the tile's offset rides in the per-lane offset, not in the scalar one: only the per-lane offset is range-checked against num_records)
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) lds_dma16_buffer(ksrd, kvo[j] + (unsigned)t * ktile_bytes, 0u, slot + j * 1024);
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) lds_dma16_buffer(vsrd, vvo[j] + (unsigned)t * vtile_bytes, 0u, slot + TILE_ELEMS * 2 + j * 1024);
+  };
+  auto Kt_of = [&](int t) -> const bf16* { return sm + (t & (APL_RING - 1)) * APL_SLOT; };
+  auto Vt_of = [&](int t) -> const bf16* { return sm + (t & (APL_RING - 1)) * APL_SLOT + TILE_ELEMS; };
+
+  // The stores of a previous phase must have drained before the counted waits below mean anything (vector-memory reads and writes return
+  // out of order relative to each other), and every wave must be done with the ring.
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  stage(0);
+  stage(1);
+  stage(2);
+  if (wave == 0 && lane == 0) *flag = 0u;
+
+  bf16x8 qf[N > 0 ? N : 1][2];
+  float lrow[N > 0 ? N : 1], mref[N > 0 ? N : 1];
+  f32x4 ot[N > 0 ? N : 1][4];
+  const float c = SCALE * LOG2E;
+  if constexpr (N > 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int q = (qb0 + NW * i) * 16 + l16;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        qf[i][ks] = q < p.Nq ? *(const bf16x8*)(Qb + (long)q * p.ldq + ks * 32 + g * 8) : z8();
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { qf[i][0] = scale8(qf[i][0], c); qf[i][1] = scale8(qf[i][1], c); }      // Q^T * (scale * log2 e), once
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      landed(qf[i][0]); landed(qf[i][1]);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) ot[i][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      lrow[i] = 0.f;
+      mref[i] = 0.f;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of tiles 0 .. 2 (issued before the Q loads: they are in by now)
+  __builtin_amdgcn_s_barrier();
+
+  AplK kf;
+  AplV vf;
+  f32x4 Snxt[4];
+  apl_u4 Pprev[2];
+  if constexpr (N > 0) {
+    apl_read_k(kf, Kt_of(0), l16, g);
+    // unit (0, 0).  No softmax reference in the loop at all: softmax is shift-invariant and fp32 / bf16 carry 8 exponent bits, so
+    // P = exp2(score) itself is exact enough whenever a row's largest score (log2 domain) lies in (-100, 100) -- any sane attention input;
+    // the row sum tells after the loop whether it did (0 < l < 2^100), and a workgroup with a row outside redoes the phase in the tracking form.
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ks = k >> 2, kb = k & 3;
+      if (ks == 0) apl_mfma_s0(Snxt[kb], kf.f[kb][0], qf[0][0]);
+      else apl_mfma_s1(Snxt[kb], kf.f[kb][1], qf[0][1]);
+    }
+  }
+
+  // one key tile: N phases.  FIRST: no unit precedes (t = 0); LAST: no tile follows; MASK: the tile holds keys beyond Nk.
+  auto tile = [&](const int t, auto FIRSTC, auto MASKC, auto LASTC) {
+    constexpr bool FIRST = decltype(FIRSTC)::value, MASK = decltype(MASKC)::value, LAST = decltype(LASTC)::value;
+    // my pieces of tile t + 1 have landed (those of t + 2 may be in flight), my LDS reads have retired ...
+    if (PPW == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();        // ... everyone's; the slot of tile t - 1 is free (its K was read in tile t - 2's phases, its V in t - 1's first)
+    stage(t + 3);
+    if constexpr (N > 0) {
+    const bf16* Kn = Kt_of(t + 1);
+    const bf16* Vt = Vt_of(t);
+    apl_sfor<N>([&](auto IC) {
+      constexpr int i = decltype(IC)::value;
+      constexpr bool NEXT_IN_TILE = i + 1 < N;
+      constexpr int inext = NEXT_IN_TILE ? i + 1 : 0;
+      constexpr bool HAS_NEXT = NEXT_IN_TILE || !LAST;
+      constexpr bool HAS_PREV = i > 0 || !FIRST;
+      constexpr int iprev = i > 0 ? i - 1 : N - 1;
+      f32x4 Scur[4];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) Scur[kb] = Snxt[kb];
+      apl_u4 Pcur[2];
+      if (N == 1 && !LAST) apl_read_k(kf, Kn, l16, g);      // one block per wave: the next tile's K fragments are needed right here (exposed; boundary phases only)
+      float lsa = 0.f, lsb = 0.f, lsc = 0.f, lsd = 0.f;      // (two accumulator pairs, alternating by step: consecutive statements share no register)
+      float pe0 = 0.f, pe1 = 0.f;
+      constexpr bool STEADY = HAS_NEXT && HAS_PREV && !MASK;
+      apl_sfor<8>([&](auto KC) {
+        constexpr int k = decltype(KC)::value;
+        constexpr int ks = k >> 2, kb = k & 3;          // products: S^T(u + 1) block kb, k half ks | O^T(u - 1) block db = kb, key step t2 = ks
+        if (HAS_NEXT && !(HAS_NEXT && HAS_PREV && !MASK)) {
+          if (ks == 0) apl_mfma_s0(Snxt[kb], kf.f[kb][0], qf[inext][0]);
+          else apl_mfma_s1(Snxt[kb], kf.f[kb][1], qf[inext][1]);
+        }
+        // softmax of unit u, chunk k: scores (key block kq, register pair hh)
+        constexpr int kq = k >> 1, hh = k & 1;
+        if constexpr (HAS_NEXT && HAS_PREV && !MASK) {      // the steady state: the whole step in one statement
+          // consumers of pair k - 1 (k = 0: none; the last pair's follow the loop); accumulators alternate by pair
+          constexpr int kp = k > 0 ? k - 1 : 0, kqp = kp >> 1, hp = kp & 1;
+          unsigned pd = 0u;
+          float ne0, ne1;
+          float& la = (kp & 1) ? lsc : lsa;
+          float& lb = (kp & 1) ? lsd : lsb;
+          if (k == 0) apl_step<true, OA, false>(Snxt[kb], kf.f[kb][0], qf[inext][0], Scur[kq][2 * hh], Scur[kq][2 * hh + 1], ot[iprev][kb], vf.f[kb][0], apl_as_frag(Pprev[0]), ne0, ne1, 0.f, 0.f, la, lb, pd);
+          else if (ks == 0) apl_step<true, OA, true>(Snxt[kb], kf.f[kb][0], qf[inext][0], Scur[kq][2 * hh], Scur[kq][2 * hh + 1], ot[iprev][kb], vf.f[kb][0], apl_as_frag(Pprev[0]), ne0, ne1, pe0, pe1, la, lb, pd);
+          else apl_step<false, OA, true>(Snxt[kb], kf.f[kb][1], qf[inext][1], Scur[kq][2 * hh], Scur[kq][2 * hh + 1], ot[iprev][kb], vf.f[kb][1], apl_as_frag(Pprev[1]), ne0, ne1, pe0, pe1, la, lb, pd);
+          if (k > 0) Pcur[kqp >> 1][(kqp & 1) * 2 + hp] = pd;
+          pe0 = ne0;
+          pe1 = ne1;
+          if (k == 7) {
+            unsigned pl;
+            apl_consume(pe0, pe1, lsc, lsd, pl);
+            Pcur[1][3] = pl;
+          }
+          // fragment prefetch, a half set at a time, right behind the last product of this phase that uses the old half
+          if (k == 3 || k == 7) {
+            if (i == 0) apl_read_v_half(vf, Vt, k >> 2, l16, g);                              // V^T of tile t: O^T(t, *) starts in the next phase
+            if (N >= 2 && i == N - 2 && !LAST) apl_read_k_half(kf, Kn, k >> 2, l16, g);     // K of tile t + 1: S^T(t + 1, 0) is issued in this tile's last phase
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          return;
+        }
+        float e0, e1;
+        apl_exp2x2(e0, e1, Scur[kq][2 * hh], Scur[kq][2 * hh + 1]);
+        if (HAS_PREV) apl_mfma_o<OA>(ot[iprev][kb], vf.f[kb][ks], apl_as_frag(Pprev[ks]));
+        if (MASK) {
+          const int key = t * 64 + kq * 16 + g * 4 + 2 * hh;
+          if (key >= p.Nk) e0 = 0.f;
+          if (key + 1 >= p.Nk) e1 = 0.f;
+        }
+        apl_add2(lsa, lsb, e0, e1);
+        Pcur[kq >> 1][(kq & 1) * 2 + hh] = apl_cvt_pk(e0, e1);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      lrow[i] += (lsa + lsb) + (lsc + lsd);
+      // (the boundary forms -- first / last / masked tile -- read their fragments behind the whole phase)
+      if (!STEADY) {
+        if (i == 0) apl_read_v(vf, Vt, l16, g);                                 // V^T of tile t: O^T(t, *) starts in the next phase
+        if (N >= 2 && i == N - 2 && !LAST) apl_read_k(kf, Kn, l16, g);        // K of tile t + 1: S^T(t + 1, 0) is issued in this tile's last phase
+      }
+      Pprev[0] = Pcur[0];
+      Pprev[1] = Pcur[1];
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    }
+  };
+  tile(0, std::true_type{}, std::false_type{}, std::false_type{});
+  {
+    int t = 1;
+    for (; t + 2 < ntiles; t += 2) {        // two tiles per iteration: the S / P register pairs alternate per unit, an odd N ends a tile on the other pair
+      tile(t, std::false_type{}, std::false_type{}, std::false_type{});
+      tile(t + 1, std::false_type{}, std::false_type{}, std::false_type{});
+    }
+    if (t + 1 < ntiles) tile(t, std::false_type{}, std::false_type{}, std::false_type{});
+  }
+  // A ragged last tile needs no mask: its missing keys arrive as zero rows of K and V (out-of-range LDS-DMA), so each contributes
+  // exp2(0) = 1 to the row sum -- exactly, in every rounding -- and 1 x 0 to O^T: the count is subtracted from the row sums below.
+  tile(ntiles - 1, std::false_type{}, std::false_type{}, std::true_type{});
+  bool bad = false;
+  float lsum[N > 0 ? N : 1];
+  const float npad = (float)(ntiles * 64 - p.Nk);
+  if constexpr (N > 0) {
+    // drain: O^T of the last unit
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ks = k >> 2, kb = k & 3;
+      apl_mfma_o<OA>(ot[N - 1][kb], vf.f[kb][ks], apl_as_frag(Pprev[ks]));
+    }
+    apl_mfma_drain();
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      lsum[i] = sum_over_g(lrow[i]) - npad;
+      const bool valid = (qb0 + NW * i) * 16 + l16 < p.Nq;                 // (rows beyond Nq: zero queries, l = Nk -- fine, but never stored)
+      // NaN-safe; with padding keys in the sum the true sum must also stand clear of the subtracted count's rounding (2^-24 of it)
+      bad = bad || (valid && !(lsum[i] > fmaxf(1e-30f, 1e-3f * npad) && lsum[i] < 1e30f));
+    }
+  }
+  // range check, workgroup-wide (the tiles are shared: all four waves redo the phase together)
+  if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) *flag = 1u;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (also: the dummy tail pieces must not outlive the phase)
+  __builtin_amdgcn_s_barrier();
+  const bool redo = *(volatile unsigned*)flag != 0u;
+  if (redo) {
+    // tracking form, one tile at a time through ring slot 0 (no pipeline: this path exists for correctness)
+    if constexpr (N > 0) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        mref[i] = 0.f;
+        lrow[i] = 0.f;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) ot[i][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    for (int t = 0; t < ntiles; ++t) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                       // everyone is done reading slot 0
+      {
+        const unsigned slot = lds0 + (unsigned)wave * (PPW * 1024u);
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) lds_dma16_buffer(ksrd, kvo[j] + (unsigned)t * ktile_bytes, 0u, slot + j * 1024);
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) lds_dma16_buffer(vsrd, vvo[j] + (unsigned)t * vtile_bytes, 0u, slot + TILE_ELEMS * 2 + j * 1024);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if constexpr (N > 0) {
+        apl_read_k(kf, sm, l16, g);
+        apl_read_v(vf, sm + TILE_ELEMS, l16, g);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          f32x4 s[4];
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) {
+            const f32x4 a0 = (f32x4){-mref[i], -mref[i], -mref[i], -mref[i]};
+            s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.f[kb][0], qf[i][0], a0, 0, 0, 0);
+            s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.f[kb][1], qf[i][1], s[kb], 0, 0, 0);
+          }
+          float mx = -1e30f;
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (t * 64 + kb * 16 + g * 4 + r >= p.Nk) s[kb][r] = -1e30f;
+              mx = fmaxf(mx, s[kb][r]);
+            }
+          mx = max_over_g(mx);
+          const float shift = t == 0 ? mx : fmaxf(mx, 0.f);            // s holds score - reference: the reference only moves up
+          const float alpha = t == 0 ? 1.f : __builtin_amdgcn_exp2f(-shift);
+          mref[i] += shift;
+          lrow[i] *= alpha;
+#pragma unroll
+          for (int db = 0; db < 4; ++db) ot[i][db] *= alpha;
+          float ls = 0.f;
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r] - shift); ls += s[kb][r]; }
+          lrow[i] += ls;
+          const bf16x8 p0 = pack8(s[0], s[1]), p1 = pack8(s[2], s[3]);
+#pragma unroll
+          for (int db = 0; db < 4; ++db) {
+            ot[i][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.f[db][0], p0, ot[i][db], 0, 0, 0);
+            ot[i][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.f[db][1], p1, ot[i][db], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if constexpr (N > 0) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) lsum[i] = sum_over_g(lrow[i]);
+    }
+  }
+  // finalize: O = O^T / l (bf16), LSE = reference * ln 2 + ln l (reference 0 unless the phase was redone)
+  if constexpr (N > 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const float l = lsum[i];
+      const float inv = 1.f / l;
+      const int q = (qb0 + NW * i) * 16 + l16;
+      if (q < p.Nq) {
+        bf16* orow = p.O + ((long)b * p.Nq + q) * p.ldo + h * HD;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          bf16x4 o;
+          o[0] = (bf16)(ot[i][db][0] * inv); o[1] = (bf16)(ot[i][db][1] * inv);
+          o[2] = (bf16)(ot[i][db][2] * inv); o[3] = (bf16)(ot[i][db][3] * inv);
+          *(bf16x4*)(orow + db * 16 + g * 4) = o;
+        }
+        if (g == 0 && p.LSE) p.LSE[(long)bh * p.Nq + q] = mref[i] * (1.f / LOG2E) + logf(l);
+      }
+    }
+  }
+}
+
+// NW waves per workgroup, G query blocks per workgroup (block NW j + w of the range is wave w's j-th: at most NQ = ceil(G / NW) per wave)
+template <int NW, int G>
+__global__ __launch_bounds__(NW * 64, NW / 4) void attn_fwd_pl_kernel(const AttnP p, const int QBP, const int F, const int nwg) {
+  constexpr int NQ = (G + NW - 1) / NW;
+  static_assert(NQ <= 5 && (NW == 4 || NW == 8), "pipelined attention forward: 4 or 8 waves, at most 5 query blocks per wave");
+  extern __shared__ __attribute__((aligned(16))) char apl_smem[];
+  bf16* sm = (bf16*)apl_smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // consecutive workgroup ids go round the 8 XCDs: XCD x owns a contiguous range of chunks (bijective for any nwg)
+  int c;
+  {
+    const int i = blockIdx.x, x = i & 7, q = nwg >> 3, r = nwg & 7;
+    c = p.xcd ? (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (i >> 3) : i;
+  }
+  const int f_lo = c * G, f_hi = min(F, f_lo + G);
+  const int pA = f_lo / QBP, pB = (f_hi - 1) / QBP;
+  for (int pr = pA; pr <= pB; ++pr) {
+    const int lo = max(f_lo, pr * QBP), hi = min(f_hi, (pr + 1) * QBP);
+    // this wave's blocks f = f_lo + NW j + wave inside [lo, hi): j in [j0, j1)
+    int j0 = lo - f_lo - wave, j1 = hi - f_lo - wave;
+    j0 = j0 > 0 ? (j0 + NW - 1) / NW : 0;
+    j1 = j1 > 0 ? (j1 + NW - 1) / NW : 0;
+    const int n = j1 - j0;
+    const int qb0 = f_lo + NW * j0 + wave - pr * QBP;
+    switch (n) {
+      case 0: apl_phase<0, NW>(p, sm, pr, qb0, lane, wave); break;
+      case 1: apl_phase<1, NW>(p, sm, pr, qb0, lane, wave); break;
+      case 2: apl_phase<(NQ >= 2 ? 2 : 0), NW>(p, sm, pr, qb0, lane, wave); break;
+      case 3: apl_phase<(NQ >= 3 ? 3 : 0), NW>(p, sm, pr, qb0, lane, wave); break;
+      case 4: apl_phase<(NQ >= 4 ? 4 : 0), NW>(p, sm, pr, qb0, lane, wave); break;
+      default: apl_phase<(NQ >= 5 ? 5 : 0), NW>(p, sm, pr, qb0, lane, wave); break;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int NW, int G>
+int apl_launch(const AttnP& p, int QBP, int F, hipStream_t st) {
+  const int nwg = cdiv(F, G);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_fwd_pl_kernel<NW, G>, hipFuncAttributeMaxDynamicSharedMemorySize, APL_SMEM));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_fwd_pl_kernel<NW, G>), dim3(nwg), dim3(NW * 64), APL_SMEM, st, p, QBP, F, nwg);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+bool attn_fwd_pl_applicable(const AttnP& p) {
+  return p.Nk >= 256 && p.Nq >= 16 && p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0;
+}
+
+int launch_attn_fwd_pl(const AttnP& pin, hipStream_t st) {
+  ARG_CHECK(attn_fwd_pl_applicable(pin), "attention (pipelined forward): Nq=%d Nk=%d does not fit", pin.Nq, pin.Nk);
+  AttnP p = pin;
+  const int QBP = cdiv(p.Nq, 16), F = QBP * p.B * p.H;
+  p.xcd = KNOB(32) != 1;
+  if (FILE* f = launch_log()) { fprintf(f, "A,0,%d,%d,%d,%d\n", p.B, p.H, p.Nq, p.Nk); fflush(f); }
+  // 20 query blocks (320 rows) per workgroup: the model's shapes are whole rounds of 256 CUs (see the header).  knob 33 = 2: 4 waves, one per
+  // SIMD (5 blocks each), 512 registers, O^T in AGPRs; knob 33 = 3: 8 waves, two per SIMD (3 + 2 blocks), 256 registers.
+  if (KNOB(33) == 3) return apl_launch<8, 20>(p, QBP, F, st);
+  return apl_launch<4, 20>(p, QBP, F, st);
+}

@@ -64,11 +64,14 @@ struct PlGeom {
 // read inside this one statement and NOT restored: it is declared clobbered, so a value hipcc might ever keep in M0 (s_movrel-style indexing
 // after some future edit) is not silently lost (hipcc warns that m0 is a reserved register: that warning is the point, -Wno-inline-asm is
 // not set).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // "clobber list contains reserved registers: m0" -- intended, see above
 template <int OFF>
 __device__ __forceinline__ void pl_dma(i32x4 srd, unsigned voff, unsigned soff, unsigned slot_base) {
   asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
                :: "v"(voff), "s"(srd), "s"(soff), "s"(slot_base), "n"(OFF) : "memory", "scc", "m0");
 }
+#pragma clang diagnostic pop
 
 __device__ __forceinline__ bf16x8 pl_z8() {
   bf16x8 z;

@@ -667,6 +667,38 @@ def test_attention_fwd_bwd(L, B, heads, Nq, Nk, self_attn):
     report("attn dV", dv, vr.grad, 1.5e-2)
 
 
+@pytest.mark.diag
+@pytest.mark.parametrize("form", [2, 3])
+@pytest.mark.parametrize("B,heads,Nq,Nk", [(2, 2, 256, 256), (1, 4, 1008, 1008), (1, 10, 4096, 4096), (1, 10, 4032, 4032), (1, 20, 1024, 1024),
+                                            (1, 1, 256, 1008), (1, 1, 64, 1024), (1, 3, 336, 320), (2, 1, 40, 257)])
+def test_attention_fwd_pipelined(L, form, B, heads, Nq, Nk):
+    """csrc/attention_pl.hip (diagnostics build, knob 33 = 2: 4 waves / 3: 8 waves): the software-pipelined forward against fp32 softmax AND
+    against the shipped tiled kernel on the same inputs.  Shapes: the model's (1024 / 4096 / 1008 / 4032: workgroup ranges that cross
+    (batch, head) boundaries, 1 .. 5 query blocks per wave, ragged last key tile = the padding-count correction of the row sums), one
+    block per wave (64 queries), ragged query count (40: rows beyond Nq never stored), Nk = 257 (63 padding keys in the last tile)."""
+    Cc = heads * 64
+    q = rnd(B, Nq, Cc, seed=61)
+    kv = rnd(B, Nk, 2 * Cc, seed=62)
+    k, v = kv[..., :Cc], kv[..., Cc:]
+    ref, lse_ref = _attn_ref(q.float(), k.float(), v.float(), heads)
+    outs = []
+    for kv_ in (0, form):
+        assert knob(L, 33, kv_)
+        try:
+            o = torch.full((B, Nq, Cc), float("nan"), dtype=torch.bfloat16, device=dev())
+            lse = torch.full((B * heads, Nq), float("nan"), dtype=torch.float32, device=dev())
+            lib.check(L.sdxl_op_attention_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), B, heads, Nq, Nk, Cc, 2 * Cc, 2 * Cc, Cc, stream()))
+            torch.cuda.synchronize()
+        finally:
+            knob(L, 33, 0)
+        outs.append((o, lse))
+    (o0, l0), (o1, l1) = outs
+    assert torch.isfinite(o1.float()).all() and torch.isfinite(l1).all()
+    report(f"attn fwd pipelined form {form} B{B} h{heads} {Nq}x{Nk}", o1, ref, 8e-3)
+    report("attn lse pipelined", l1.view(B, heads, Nq), lse_ref, 1e-3)
+    report("attn fwd pipelined vs tiled", o1, o0, 8e-3)
+
+
 @pytest.mark.parametrize("B,Nq,N,K,addend", [(1, 1024, 1280, 1280, True), (4, 1024, 1280, 1280, False), (1, 1000, 1280, 1280, True),
                                              (2, 200, 256, 128, False), (3, 70, 128, 64, True)])
 def test_linear_dgrad_delta_epilogue(L, B, Nq, N, K, addend):
