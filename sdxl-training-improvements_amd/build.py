@@ -22,7 +22,7 @@ LIB = HERE / "libsdxlstep.so"
 OBJ_DIAG = HERE / "build_diag"
 LIB_DIAG = HERE / "libsdxlstep_diag.so"
 DIAG_SOURCES = ["gemm_sk.hip", "attention_pl.hip"]
-SOURCES = ["gemm.hip", "gemm256.hip", "conv_wgrad3.hip", "wgrad256.hip", "gemm_cr256.hip", "gemm_pl.hip", "attention.hip", "norm.hip", "elementwise.hip", "loss.hip", "optimizer.hip", "engine.hip", "capi.hip"]
+SOURCES = ["gemm.hip", "gemm256.hip", "conv_wgrad3.hip", "wgrad256.hip", "gemm_cr256.hip", "gemm_pl.hip", "attention.hip", "attention_bwd_pl.hip", "norm.hip", "elementwise.hip", "loss.hip", "optimizer.hip", "engine.hip", "capi.hip"]
 HEADERS = ["common.h", "kernels.h", "gemm_tiles.h", "attn_tiles.h", "engine.h", "../../include/sdxlstep.h", "../../include/sdxlstep_diag.h"]
 # -fvisibility=hidden: the dynamic symbol table holds the SDXL_API entry points of include/sdxlstep.h / sdxlstep_diag.h and nothing else
 # (no C++ internals, no __device_stub__s); tests/test_host_boundary.py checks `nm -D`

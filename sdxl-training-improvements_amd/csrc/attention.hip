@@ -720,7 +720,7 @@ static int check_attn(const AttnP& p) {
 int launch_attn_fwd(const AttnP& p, hipStream_t st) {
   if (int e = check_attn(p)) return e;
 #ifdef SDXL_DIAG      // the software-pipelined forward (attention_pl.hip): built, parity-green, measured at parity with this kernel -- diagnostics build only
-  if ((KNOB(33) == 2 || KNOB(33) == 3) && attn_fwd_pl_applicable(p)) return launch_attn_fwd_pl(p, st);
+  if (KNOB(33) == 2 && attn_fwd_pl_applicable(p)) return launch_attn_fwd_pl(p, st);
 #endif
   return launch_attn_fwd_tiled(p, st);
 }
@@ -778,6 +778,10 @@ int launch_attn_bwd_fused(const AttnP& p, hipStream_t st) {
   q.xcd = (p.B * p.H) % 8 == 0 && KNOB(32) != 1;
   const long total = (long)p.B * p.Nq * p.H;
   if (!p.delta_ready) hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, q);
+  // the software-pipelined backward (attention_bwd_pl.hip) for long sequences: 4096 x 4096 x 40 pairs 546 -> 506 us on identical buffers
+  // (profiles/r06l_attn_bwd_ab.txt); at 1024 tokens (16 key tiles per range: its prologue and epilogue are a seventh of a workgroup's life,
+  // and the two co-resident workgroups of this kernel hide theirs) it is 3 % behind and not used.  knob 35 = 1: never, = 2: wherever it applies.
+  if (KNOB(35) != 1 && ((p.Nq >= 2048 && p.Nk >= 2048) || KNOB(35) == 2) && attn_bwd_pl_applicable(q)) return launch_attn_bwd_pl(q, st);
   const int nkb = cdiv(p.Nk, 128), nqb = cdiv(p.Nq, 128), nbh = p.B * p.H;
   hipLaunchKernelGGL(attn_bwd_fused_kernel<2>, dim3(nkb * nbh + nqb * nbh), dim3(256), 0, st, q, nkb * nbh, nkb, nqb);
   HIP_CHECK_RET(hipGetLastError());

@@ -525,8 +525,8 @@ int launch_attn_fwd_pl(const AttnP& pin, hipStream_t st) {
   const int QBP = cdiv(p.Nq, 16), F = QBP * p.B * p.H;
   p.xcd = KNOB(32) != 1;
   if (FILE* f = launch_log()) { fprintf(f, "A,0,%d,%d,%d,%d\n", p.B, p.H, p.Nq, p.Nk); fflush(f); }
-  // 20 query blocks (320 rows) per workgroup: the model's shapes are whole rounds of 256 CUs (see the header).  knob 33 = 2: 4 waves, one per
-  // SIMD (5 blocks each), 512 registers, O^T in AGPRs; knob 33 = 3: 8 waves, two per SIMD (3 + 2 blocks), 256 registers.
-  if (KNOB(33) == 3) return apl_launch<8, 20>(p, QBP, F, st);
+  // 20 query blocks (320 rows) per workgroup: the model's shapes are whole rounds of 256 CUs (see the header); 4 waves, one per SIMD (5 blocks
+  // each), 512 registers, O^T in AGPRs, nothing spilled.  (The 8-wave form -- two waves per SIMD, 3 + 2 blocks, 256 registers -- measured the
+  // same time and is no longer instantiated: hipcc spills 58 registers in it, and scratch traffic invalidates the counted vmcnt waits.)
   return apl_launch<4, 20>(p, QBP, F, st);
 }

@@ -619,10 +619,10 @@ struct AttnOp : Op {
       a.Q = p.P(q); a.ldq = C;
       a.K = p.P(kv); a.V = p.P(kv) + C; a.ldk = a.ldv = kv->ld();   // (a column slice of the grouped K | V projection)
     }
-    a.O = p.P(o); a.ldo = C;
+    a.O = p.P(o); a.ldo = o->ld();
     a.LSE = p.F(lse_off);
     if (grads) {
-      a.dO = p.GP(do_off); a.lddo = C;
+      a.dO = p.GP(do_off); a.lddo = o->ld();
       a.Delta = p.F(delta_off);
       a.qsplit = qsplit;
       a.part = p.F(self ? p.apart_off : p.apart_side_off);
@@ -672,7 +672,7 @@ struct AttnOp : Op {
 static bool attn_delta_wanted(const AttnOp* a) { return a->self && a->qsplit <= 1 && a->Nk >= 256 && a->C % 128 == 0 && a->delta_fused; }
 static void attn_set_delta_fused(AttnOp* a, bool on) { a->delta_fused = on; }
 static void attn_delta_target(AttnOp* a, Plan& p, GemmP& g) {
-  g.delta_o = p.P(a->o); g.delta_ldo = a->C;
+  g.delta_o = p.P(a->o); g.delta_ldo = a->o->ld();
   g.delta_out = p.F(a->delta_off);
   g.delta_nq = a->Nq; g.delta_heads = a->heads;
 }

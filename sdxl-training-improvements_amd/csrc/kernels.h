@@ -31,15 +31,16 @@
 //      4 = the one-round 3x3 convolutions forward on gemm.hip's configuration 5 / 6 (unsplit instead of two co-resident halves), 8 = their dgrads
 //   31 = 1: gemm_pl.hip WITH its L2 prefetch wave (measured: no gain)
 //   32 = 1: attention workgroups in plain (block, pair) order instead of the XCD-aware one
-//   33 attention forward kernel (Nk >= 256): 0 = the tiled kernel of attention.hip (shipped), 2 = the software-pipelined kernel of attention_pl.hip with
-//      4 waves (one per SIMD, 512 registers), 3 = with 8 waves (two per SIMD, 256 registers): parity-green, at parity in time (profiles/r06f_attn_ab.txt)
+//   33 attention forward kernel (Nk >= 256): 0 = the tiled kernel of attention.hip (shipped), 2 = the software-pipelined kernel of attention_pl.hip
+//      (4 waves, one per SIMD, 512 registers): parity-green, at parity in time (profiles/r06f_attn_ab.txt)
+//   35 self-attention backward: 0 policy (attention_bwd_pl.hip for Nq, Nk >= 2048, attn_bwd_fused_kernel below), 1 = attn_bwd_fused_kernel everywhere, 2 = pipelined wherever it applies
 //   34 = 1: no generic XCD order (xcd_seq_map) in the weight-gradient kernels: identity where no XCD rectangle fits, = 2: the generic order also where a rectangle fits (cr256)
 //   29 = 1: weight-gradient GEMMs that use no split-K slab and whose operands come from the caller's stream are launched any-order on the side stream
 // The product library has NO knobs: KNOB(i) is the constant 0 (= the shipped policy) and every experiment branch below it folds away.
 // The diagnostics build (`build.py --diag`: -DSDXL_DIAG -> libsdxlstep_diag.so, include/sdxlstep_diag.h) keeps the table, sdxl_set_knob,
 // the stream-K kernel (gemm_sk.hip), the stride-2 forward / weight gradient on phase planes (GemmP::up2 == 3) and the W = 32 three-tap form:
 // measured, parity-tested experiments the step does not run (DESIGN.md sections 10, 11).
-#define SDXL_NKNOBS 38
+#define SDXL_NKNOBS 40
 #ifdef SDXL_DIAG
 extern int g_knobs[SDXL_NKNOBS];
 #define KNOB(i) (g_knobs[(i)])
@@ -256,6 +257,8 @@ int launch_attn_fwd(const AttnP& p, hipStream_t st);
 int launch_attn_fwd_tiled(const AttnP& p, hipStream_t st); // attention.hip: 128-query workgroups, three per CU (what launch_attn_fwd runs)
 bool attn_fwd_pl_applicable(const AttnP& p);               // diagnostics build (attention_pl.hip): software-pipelined forward, Nk >= 256
 int launch_attn_fwd_pl(const AttnP& p, hipStream_t st);
+bool attn_bwd_pl_applicable(const AttnP& p);               // attention_bwd_pl.hip: software-pipelined dQ | dK | dV in one grid (Nq, Nk >= 256; Delta in place)
+int launch_attn_bwd_pl(const AttnP& p, hipStream_t st);
 int launch_attn_bwd(const AttnP& p, hipStream_t st);       // = dq, then dkv
 int launch_attn_bwd_dq(const AttnP& p, hipStream_t st);
 int launch_attn_bwd_dkv(const AttnP& p, hipStream_t st);

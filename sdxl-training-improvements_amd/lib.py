@@ -162,6 +162,12 @@ def load() -> C.CDLL:
         fn.argtypes = args
         fn.restype = C.c_int
     _lib = lib
+    if DIAG:      # diagnostics build: SDXL_KNOBS=id=value,id=value preset the experiment knobs for the whole process (A/B runs of tools AND tests)
+        for kv in os.environ.get("SDXL_KNOBS", "").split(","):
+            if kv:
+                rc = lib.sdxl_set_knob(int(kv.split("=")[0]), int(kv.split("=")[1]))
+                if rc != 0:
+                    raise SdxlError(f"SDXL_KNOBS: sdxl_set_knob({kv}) failed")
     return lib
 
 

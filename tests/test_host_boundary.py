@@ -181,3 +181,23 @@ def test_accumulation_semantics_d9_d10():
     assert len(zeros) == 2 and len(bwds) == 8
     assert [b[2] for b in bwds] == [True, False, False, False] * 2 and all(b[1] == 0.25 for b in bwds)
     assert net.calls[0] == ("zero",) and net.calls[zeros[1] - 1][0] == "bwd"
+
+
+def test_counted_vmcnt_attention_kernels_spill_nothing(tmp_path):
+    """csrc/attention_bwd_pl.hip (product) and csrc/attention_pl.hip (diagnostics build) order their LDS-DMA tiles by COUNTED s_waitcnt vmcnt(N).
+    A register spilled to scratch is a vector-memory store / load the author did not count, and stores complete out of order with loads: with 24
+    spilled registers the dQ body read tiles that had not landed (wrong dQ on every shape, round 6).  hipcc's resource report for gfx950 must say
+    ScratchSize 0 and 0 spilled VGPRs for every kernel of the two files (cross-compiles without a GPU, ~20 s)."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    csrc = ROOT / "sdxl-training-improvements_amd" / "csrc"
+    for src, defs in (("attention_bwd_pl.hip", []), ("attention_pl.hip", ["-DSDXL_DIAG"])):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-Rpass-analysis=kernel-resource-usage",
+                            "-c", str(csrc / src), "-o", str(tmp_path / (src + ".o"))] + defs, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+        spills = [int(x) for x in re.findall(r"VGPRs Spill: (\d+)", r.stderr)]
+        assert scratch and spills, r.stderr[-2000:]
+        assert all(x == 0 for x in scratch) and all(x == 0 for x in spills), (src, scratch, spills)
