@@ -482,12 +482,13 @@ struct GroupNormOp : Op {
   PRef gm, bt;
   int Bn, HW, C, G, silu;
   float eps;
-  size_t stats_off;
+  size_t stats_off, prow_off;
   size_t dy_off = NONE;
   Plan::GradDst dx;
   GroupNormOp(Plan& p, Act* x_, Act* y_, PRef g_, PRef b_, int B_, int HW_, int C_, int G_, float eps_, int silu_)
       : x(x_), y(y_), gm(g_), bt(b_), Bn(B_), HW(HW_), C(C_), G(G_), silu(silu_), eps(eps_) {
     stats_off = p.alloc(sizeof(float) * Bn * G * 2);
+    prow_off = p.alloc(sizeof(float) * Bn * 2 * C);      // per-sample rows of dgamma | dbeta partial sums, folded by the segment's flush_ln_params
     size_t need = groupnorm_ws_floats(Bn, C, G);
     if (need > p.gn_ws_floats) p.gn_ws_floats = need;  // one scratch, sized for the widest norm, allocated in build()
   }
@@ -500,8 +501,11 @@ struct GroupNormOp : Op {
   void plan_bwd(Plan& p) override { dy_off = y->goff; dx = p.grad_dst(x); }
   int bwd(Plan& p, hipStream_t st, bool) override {
     if (KNOB(27) & 1) return 0;
+    LnRedEntry r;      // dgamma | dbeta: B partial rows, added in a fixed order by the batched reduce (no atomics: bitwise reproducible)
+    r.part = p.F(prow_off); r.dgamma = p.eng->Gp(gm); r.dbeta = p.eng->Gp(bt); r.C = C; r.nblk = Bn;
+    p.eng->ln_pending.push_back(r);
     return launch_groupnorm_bwd(p.P(x), p.GP(dy_off), p.eng->Wp(gm), p.eng->Wp(bt), p.F(stats_off), p.GP(dx.out),
-                                p.GP(dx.addend), p.eng->Gp(gm), p.eng->Gp(bt), p.F(p.gn_ws_off), Bn, HW, C, G, silu, st);
+                                p.GP(dx.addend), p.eng->Gp(gm), p.eng->Gp(bt), p.F(p.gn_ws_off), Bn, HW, C, G, silu, st, p.F(prow_off));
   }
 };
 

@@ -277,7 +277,7 @@ int launch_groupnorm_fwd(const bf16* x, bf16* y, const bf16* gamma, const bf16* 
 // dx = (addend ? addend : 0) + grad   (addend may alias dx; a distinct addend keeps gradient buffers write-once)
 int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const bf16* beta,
                          const float* stats, bf16* dx, const bf16* addend, float* dgamma, float* dbeta, float* ws,
-                         int B, int HW, int C, int G, int silu, hipStream_t st);
+                         int B, int HW, int C, int G, int silu, hipStream_t st, float* prow = nullptr);
 // LayerNorm over rows of [M][C]; stats [M][2] = mean, rstd
 int launch_layernorm_fwd(const bf16* x, bf16* y, const bf16* gamma, const bf16* beta, float* stats, int M,
                          int C, float eps, hipStream_t st);

@@ -269,7 +269,7 @@ __global__ void gn_bwd_reduce_nolds_kernel(const bf16* __restrict__ x, const bf1
 // (Was two launches: a chunk sum over 64-channel blocks and a per-sample finalize; 46 of each per step.)
 __global__ __launch_bounds__(1024) void gn_bwd_group_kernel(const float* __restrict__ part, int chunks, const bf16* __restrict__ gamma,
                                                             const float* __restrict__ stats, float* __restrict__ coef,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int HW, int C, int G) {
+                                                            float* __restrict__ prow, int HW, int C, int G) {
   __shared__ float ps[1024][2];
   __shared__ float wa[128], wb[128];
   const int g = blockIdx.x, b = blockIdx.y, B = gridDim.y;
@@ -289,8 +289,10 @@ __global__ __launch_bounds__(1024) void gn_bwd_group_kernel(const float* __restr
   float A = 0.f, Bs = 0.f, ga = 0.f;
   if (sl == 0) {
     for (int k = 0; k < nsl; ++k) { A += ps[k * cpg + cl][0]; Bs += ps[k * cpg + cl][1]; }
-    atomicAdd(&dbeta[c], A);     // parameter gradients: fp32 sum over the batch (order-insensitive to ~1e-7)
-    atomicAdd(&dgamma[c], Bs);
+    // parameter gradients: this sample's row of partial sums [b][dgamma | dbeta][C], plain stores; the samples are added in a fixed order by
+    // ln_param_reduce_kernel (bitwise reproducible; until round 6: B fp32 atomics per channel, whose order the hardware chose)
+    prow[((long)b * 2) * C + c] = Bs;
+    prow[((long)b * 2 + 1) * C + c] = A;
     ga = (float)gamma[c];
     wa[cl] = ga * A;
     wb[cl] = ga * Bs;
@@ -357,7 +359,7 @@ __global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __re
 
 int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const bf16* beta, const float* stats,
                          bf16* dx, const bf16* addend, float* dgamma, float* dbeta, float* ws, int B, int HW, int C,
-                         int G, int silu, hipStream_t st) {
+                         int G, int silu, hipStream_t st, float* prow) {
   const int accumulate = addend != nullptr;
   ARG_CHECK(C % 8 == 0 && C % G == 0 && G <= 64 && C / G <= 128, "groupnorm bwd: C=%d G=%d unsupported", C, G);
   GnGeom g = gn_geom(HW, C);
@@ -386,7 +388,15 @@ int launch_groupnorm_bwd(const bf16* x, const bf16* dy, const bf16* gamma, const
       hipLaunchKernelGGL(gn_bwd_reduce_kernel<false>, dim3(g.chunks, B), dim3(g.threads), sh, st, x, dy, gamma, beta,
                          stats, part, HW, C, G, g.vpr, g.rpi, g.rows_per_chunk);
   }
-  hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(G, B), dim3(1024), 0, st, part, red_chunks, gamma, stats, coef, dgamma, dbeta, HW, C, G);
+  // per-sample partial rows of dgamma | dbeta: the caller's buffer (it folds them later: Engine::flush_ln_params), or the tail of ws + a reduce right here
+  float* rows = prow ? prow : coef + (size_t)B * C * 3;
+  hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(G, B), dim3(1024), 0, st, part, red_chunks, gamma, stats, coef, rows, HW, C, G);
+  if (!prow) {
+    LnRedBatch rb;
+    rb.n = 1;
+    rb.e[0].part = rows; rb.e[0].dgamma = dgamma; rb.e[0].dbeta = dbeta; rb.e[0].nblk = B; rb.e[0].C = C;
+    if (int e = launch_ln_param_reduce(rb, st)) return e;
+  }
 #define GN_BWD_APPLY(S, A)                                                                                          \
   hipLaunchKernelGGL((gn_bwd_apply_kernel<S, A>), dim3(g.chunks, B), dim3(g.threads), 0, st, x, dy, gamma, beta, stats, \
                      coef, dx, addend, HW, C, G, g.vpr, g.rpi, g.rows_per_chunk)
