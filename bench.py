@@ -33,7 +33,7 @@ FLOP_PER_IMAGE_1344x768 = 19.93e12          # 1344x768 (lat
 FLOP_PER_IMAGE_512 = 4.77e12
 PEAK_BF16_TFLOPS = 2516.6           # 256 CU x 2.4 GHz x 4096 FLOP/clk/CU (MI355X dense bf16 MFMA)
 ATTN_FLOP_PER_IMAGE_1024 = 2.351e12   # of those, attention QK^T / PV fwd + bwd (3.135 of 27.045 TFLOP per B = 4 forward)
-PMC_SUMMARY = "r05_pmc_step_summary.json"     # committed PMC passes (profiles/tools/measure_step.sh), stamped with the commit they were taken at
+PMC_SUMMARY = "r06_pmc_step_summary.json"     # committed PMC passes (profiles/tools/measure_step.sh), stamped with the commit they were taken at
 
 
 def kernels_changed_since(commit):
