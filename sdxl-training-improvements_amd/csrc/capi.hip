@@ -268,6 +268,7 @@ static void fill_loss(Engine& e, const sdxl_loss_config* lc, const sdxl_batch* b
   L.unet_in = p.P(p.x_in); L.pred = p.P(p.pred); L.dpred = p.G(p.pred);
   L.grad_scale = grad_scale;
   L.out = p.F(p.loss_off);
+  L.part = p.F(p.loss_part_off);
 }
 
 
@@ -860,6 +861,7 @@ int sdxl_op_loss(const sdxl_loss_config* lc, const sdxl_batch* b, void* unet_in,
   L.latents = b->latents; L.noise = b->noise; L.sigma = b->sigma_or_t; L.tag_w = b->tag_weights;
   L.unet_in = (bf16*)unet_in; L.pred = (const bf16*)pred; L.dpred = (bf16*)dpred;
   L.grad_scale = grad_scale; L.out = out8;
+  if (phase == 1) CHK(test_slab(loss_part_floats(L.B, L.HW), &L.part));
   if (phase == 0) return launch_loss_prepare(L, (hipStream_t)st);
   if (phase == 1) return launch_loss_fwd(L, (hipStream_t)st);
   if (phase == 2) return launch_loss_bwd(L, (hipStream_t)st);

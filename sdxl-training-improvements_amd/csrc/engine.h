@@ -75,7 +75,7 @@ struct Plan {
                                             // every resnet's conv1 backward adds its per-sample column sums into its slice)
   // well-known buffers
   Act *x_in = nullptr, *pred = nullptr, *ehs = nullptr, *aug_in = nullptr, *te_sin = nullptr, *tid_emb = nullptr;
-  size_t t_off = NONE, tid_off = NONE, loss_off = NONE;
+  size_t t_off = NONE, tid_off = NONE, loss_off = NONE, loss_part_off = NONE;
   size_t in_lat_off = NONE, in_noise_off = NONE, in_sig_off = NONE, in_tag_off = NONE;   // staged copies of the step's inputs (fixed
                                                                                           // addresses for the captured graphs)
   size_t gn_ws_off = NONE, gn_ws_floats = 0;  // GroupNorm scratch shared by all (stream-ordered) norm ops
@@ -148,11 +148,12 @@ struct Engine {
   // one of their own (LayerNorm parameter gradients, cross-attention dK / dV: 280 events per step)
   std::vector<std::function<int(hipStream_t)>> side_leaves;
   std::vector<LnRedEntry> ln_pending;     // LayerNorm backward launches whose dgamma | dbeta partials are not reduced yet
+  std::vector<LnRedEntry> cs_pending;     // per-sample column sums (time-embedding row vectors) whose partial rows are not reduced yet: the consumer's cast flushes them
   int flush_ln_params(Plan& p, hipStream_t main);
   // Everything queued for a later launch holds raw workspace pointers of the plan and step it was queued in: dropped at the start of a
   // forward / of a backward, when a backward segment fails half way, and when the current plan changes (never launched against another
   // step's or plan's buffers).
-  void drop_pending() { side_leaves.clear(); wg_pending.clear(); ln_pending.clear(); }
+  void drop_pending() { side_leaves.clear(); wg_pending.clear(); ln_pending.clear(); cs_pending.clear(); }
   bool side_dirty = false;       // the side stream has work the caller's stream has not joined yet
   // hipGraph replay of the step (sdxl_set_graph_mode, OFF by default): forward (+ loss) and backward are captured once per
   // (plan, configuration) -- both streams, every event edge -- and replayed with one hipGraphLaunch, on an engine-owned

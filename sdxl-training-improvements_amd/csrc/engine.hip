@@ -256,7 +256,17 @@ struct LinearOp : Op {
   int bwd(Plan& p, hipStream_t st, bool first) override {
     const bf16* dy = p.GP(dy_off);
     const int M = (int)x->rows;
-    if (dy32_off != NONE) CHK(launch_f32_to_bf16(p.F(dy32_off), p.GP(dy_off), (long)M * N, 1.f, st));
+    if (dy32_off != NONE) {
+      auto& cs = p.eng->cs_pending;      // the convolutions' per-sample column sums: partial rows -> the fp32 buffer, LN_RED_MAX sums per launch
+      for (size_t i = 0; i < cs.size();) {
+        LnRedBatch rb;
+        rb.n = 0;
+        while (i < cs.size() && rb.n < LN_RED_MAX) rb.e[rb.n++] = cs[i++];
+        CHK(launch_ln_param_reduce(rb, st));
+      }
+      cs.clear();
+      CHK(launch_f32_to_bf16(p.F(dy32_off), p.GP(dy_off), (long)M * N, 1.f, st));
+    }
     if (gu && dx.addend != NONE) { sdxl_set_error("geglu: pre-activation gradient has another writer"); return 3; }
     if (resid && !resid_alias) CHK(launch_add(p.GP(dres.addend), dy, p.GP(dres.out), (long)M * N, st));
     {
@@ -322,6 +332,7 @@ struct ConvOp : Op {
   int fsplit = 1, dsplit = 1;   // split-K of the forward / dgrad launch (small images, gemm_pick_splitk_small)
   size_t rv32_off = NONE;  // rowvec gradient: this conv's column slice of the plan's fp32 [B][sum Cout] buffer
   long rv32_ld = 0;
+  size_t cs_part_off = NONE;   // partial rows of the fixed-order column sums (time-embedding row vector; the up-sampler's bias gradient)
   size_t dy_off = NONE;
   Plan::GradDst dx, dres, drv;
   // x is the nearest-2x upsampling of x_low (the `Upsample2D` pair): forward and dgrad run on x_low with 2 x 2 phase stencils
@@ -350,6 +361,7 @@ struct ConvOp : Op {
       dweff_off = p.alloc(sizeof(float) * (size_t)Cout * 16 * Cin);
       up_ws = pick_splitk(Cout, Cin, 16, (long)Bn * (H / 2) * (W / 2));
       want_slab(p, Cout, Cin, 16, up_ws);
+      cs_part_off = p.alloc(sizeof(float) * colsum_part_floats(1, Bn * H * W, Cout));      // (rowvec excludes up2: one buffer serves either)
     }
   }
   ConvOp(Act* x_, Act* y_, PRef w_, PRef b_, int B_, int H_, int W_, int Cin_, int Cout_, int stride_, Act* resid_,
@@ -391,6 +403,7 @@ struct ConvOp : Op {
       drv = p.grad_dst(rowvec);     // (allocates the grouped projection's bf16 output gradient; written by its cast, not here)
       rv32_off = p.tp32_off + (size_t)rowvec->col0 * sizeof(float);
       rv32_ld = rowvec->ld();
+      cs_part_off = p.alloc(sizeof(float) * colsum_part_floats(Bn, Ho * Wo, Cout));
     }
     if (x->need_grad) dx = p.grad_dst(x);
     if (SDXL_UP2_3 && stride == 2 && H % 2 == 0 && W % 2 == 0 && Cin % 64 == 0 && Cout % 8 == 0 && !resid && !rowvec && (Bn * Ho * Wo) % 64 == 0)
@@ -422,7 +435,9 @@ struct ConvOp : Op {
 #endif
     if (upw) {
       CHK(on_side(p, st, [&](hipStream_t s2) -> int {
-        return launch_upconv3x3_wgrad((const bf16*)p.F(planar_off), p.P(x_low), p.F(dweff_off), p.eng->Gp(w), p.eng->Gp(b),
+        // (bias gradient: the four phase planes would add in launch order -- a fixed-order column sum of dy instead, 10 - 20 us on this stream)
+        CHK(launch_colsum_f32_batched(dy, p.eng->Gp(b), 1, (int)Mo, Cout, Cout, 0, p.F(cs_part_off), s2));
+        return launch_upconv3x3_wgrad((const bf16*)p.F(planar_off), p.P(x_low), p.F(dweff_off), p.eng->Gp(w), nullptr,
                                       p.eng->emit_base ? p.eng->emit_base + w.off : nullptr, p.eng->emit_scale, first ? 0 : 1, Bn, H / 2, W / 2,
                                       Cin, Cout, up_ws, p.F(p.slab_off), s2);
       }));
@@ -447,7 +462,10 @@ struct ConvOp : Op {
     }));
     if (rowvec) {   // d(time-embedding projection)[b][c] = sum over the pixels of sample b of dy: one launch, into the fp32 slice
       if (drv.addend != NONE) { sdxl_set_error("conv: time-embedding row vector has another gradient writer"); return 3; }
-      CHK(launch_colsum_f32_batched(dy, p.F(rv32_off), Bn, Ho * Wo, Cout, Cout, rv32_ld, st));
+      // (partial rows now, on this stream; the fixed-order reduce of ALL the resnets' sums runs once, right before the grouped projection's cast)
+      const size_t k0 = p.eng->cs_pending.size();
+      p.eng->cs_pending.resize(k0 + Bn);
+      CHK(launch_colsum_partials(dy, p.F(rv32_off), Bn, Ho * Wo, Cout, Cout, rv32_ld, p.F(cs_part_off), &p.eng->cs_pending[k0], st));
     }
     if (x->need_grad && s2_planar_off != NONE && KNOB(2) != 256) {
       CHK(launch_conv3x3_s2_dgrad(dy, p.eng->Wp(w), (bf16*)p.F(s2_planar_off), p.GP(dx.out), dx.addend != NONE ? p.GP(dx.addend) : nullptr, Bn, H, W,
@@ -972,6 +990,7 @@ struct Builder {
       pl->t_off = pl->alloc(sizeof(float) * B);
       pl->tid_off = pl->alloc(sizeof(float) * B * 6);
       pl->loss_off = pl->alloc(sizeof(float) * 8);
+      pl->loss_part_off = pl->alloc(sizeof(float) * loss_part_floats(B, H * W));
       pl->in_lat_off = pl->alloc(sizeof(float) * (size_t)B * 4 * H * W);
       pl->in_noise_off = pl->alloc(sizeof(float) * (size_t)B * 4 * H * W);
       pl->in_sig_off = pl->alloc(sizeof(float) * B);

@@ -723,7 +723,10 @@ __global__ __launch_bounds__(NW * 64, PL ? 2 : gemm_occupancy(BN, S, BK, NW)) vo
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * (MI * 16) + i * 16 + g * 4 + r;
-        if (m < p.M) atomicAdd(p.bias_grad + m, accb[i][r]);
+        if (m < p.M) {
+          if (p.up2 == 1) atomicAdd(p.bias_grad + m, accb[i][r]);      // (four phase planes add: the plan takes the up-sampler's bias gradient from its own column-sum pass)
+          else gemm_bias_out(p.bias_grad, p.slab, p.slab_ld, p.splitk, split, p.M, m, accb[i][r]);
+        }
       }
   }
   // ---- epilogue, registers -> global.  The products were issued with the operands swapped (D^T layout), so lane
@@ -1137,12 +1140,20 @@ __global__ __launch_bounds__(NW * 64, PL ? 2 : gemm_occupancy(BN, S, BK, NW)) vo
 }
 
 // C[m][0..cols) (+)= sum_s slab[s][m][0..cols)   (fixed summation order)
+// bias_grad (optional): bias_grad[m] += sum_s tail[s][m], the splits' bias-gradient partials behind the tiles (gemm_bias_out), same fixed order
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, int M, int cols, long ldc,
-                                     long slab_ld, int splitk, int accumulate, bf16* __restrict__ Cb, float cb_scale) {
+                                     long slab_ld, int splitk, int accumulate, bf16* __restrict__ Cb, float cb_scale,
+                                     float* __restrict__ bias_grad) {
   const int vpr = cols / 4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)M * vpr; i += (long)gridDim.x * blockDim.x) {
     long m = i / vpr;
     int c = (int)(i - m * vpr) * 4;
+    if (bias_grad && c == 0) {
+      const float* tail = slab + (long)splitk * M * slab_ld + m;
+      float b = 0.f;
+      for (int s = 0; s < splitk; ++s) b += tail[(long)s * M];
+      bias_grad[m] += b;
+    }
     f32x4 a = accumulate ? *(const f32x4*)(C + m * ldc + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < splitk; ++s) {
       f32x4 v = *(const f32x4*)(slab + ((long)s * M + m) * slab_ld + c);
@@ -1217,7 +1228,7 @@ int gemm_ln_error(unsigned* out) {      // != 0: a LayerNorm-backward epilogue g
   return 0;
 }
 #endif
-size_t gemm_slab_floats(int M, int N, int taps, int splitk) { return splitk > 1 ? (size_t)splitk * M * N * taps : 0; }
+size_t gemm_slab_floats(int M, int N, int taps, int splitk) { return splitk > 1 ? (size_t)splitk * M * N * taps + (size_t)splitk * M : 0; }   // tiles + bias tail
 
 void gemm_defaults(GemmP* p) {
   memset(p, 0, sizeof(*p));
@@ -1630,7 +1641,7 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
         int g = (int)((nv + 255) / 256);
         if (g > 2048) g = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, st, p.slab, (float*)p.C, p.M, p.N, p.ldc, p.slab_ld,
-                           p.splitk, p.accumulate, p.Cb, p.cb_scale);
+                           p.splitk, p.accumulate, p.Cb, p.cb_scale, p.bias_grad);
         HIP_CHECK_RET(hipGetLastError());
       }
       return rc;
@@ -1656,7 +1667,7 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
           int g = (int)((nv + 255) / 256);
           if (g > 2048) g = 2048;
           hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, st, p.slab, (float*)p.C, p.M, p.N, p.ldc, p.slab_ld,
-                             p.splitk, p.accumulate, p.Cb, p.cb_scale);
+                             p.splitk, p.accumulate, p.Cb, p.cb_scale, p.bias_grad);
           HIP_CHECK_RET(hipGetLastError());
         }
         return rc;
@@ -1690,7 +1701,7 @@ static int launch_gemm_impl(const GemmP& pin, hipStream_t st) {
         int g = (int)((nv + 255) / 256);
         if (g > 2048) g = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, st, p.slab, (float*)p.C, p.M, cols, p.ldc,
-                           p.slab_ld, p.splitk, p.accumulate, p.Cb, p.cb_scale);
+                           p.slab_ld, p.splitk, p.accumulate, p.Cb, p.cb_scale, p.up2 == 1 ? nullptr : p.bias_grad);      // (up2 == 1: gemm_kernel's own adds)
         HIP_CHECK_RET(hipGetLastError());
       }
       return rc;

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmP p) {
   if (FORM == GEMM_TN) {
     if (BIAS && do_bias && g == 0) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) atomicAdd(p.bias_grad + mrow + 16 * i, accb[BIAS ? i : 0][0]);
+      for (int i = 0; i < 8; ++i) gemm_bias_out(p.bias_grad, p.slab, p.slab_ld, p.splitk, split, p.M, mrow + 16 * i, accb[BIAS ? i : 0][0]);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {

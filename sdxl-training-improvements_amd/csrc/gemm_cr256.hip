@@ -294,7 +294,7 @@ __global__ __launch_bounds__(512, S != CR_S ? 2 : (PH && (BIASG || BN == 160)) ?
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = m0 + wm * 64 + i * 16 + g * 4 + r;
-          if (m < M) atomicAdd(bias_grad + m, accb[BIASG ? i : 0][r]);
+          if (m < M) gemm_bias_out(bias_grad, pin.slab, pin.slab_ld, pin.splitk, split, M, m, accb[BIASG ? i : 0][r]);
         }
     }
 #pragma unroll

@@ -119,7 +119,7 @@ struct GemmP {
   int out_f32;
   int accumulate;
   int splitk;
-  float* slab;     // splitk * M * N * taps floats
+  float* slab;     // gemm_slab_floats(M, N, taps, splitk): splitk * M * N * taps partial tiles + a [splitk][M] tail (bias-gradient partials)
   long slab_ld;    // set by the launcher
   // TN only, optional: the FINAL value (acc [+ C when accumulate]) * cb_scale goes out as bf16 to Cb (same [M][ldc] geometry as C)
   // and C itself is not written -- the gradient-exchange micro-step under data parallelism wants the bf16 comm arena, and
@@ -127,7 +127,9 @@ struct GemmP {
   bf16* Cb;
   float cb_scale;
   float* bias_grad;  // TN only, optional: bias_grad[m] += sum_k A(k, m)  (column sums of dY, computed on the matrix pipe
-                     // by the n-tile-0 / tap-0 workgroups with an all-ones B fragment; fp32 atomics, 128 per workgroup)
+                     // by the n-tile-0 / tap-0 workgroups with an all-ones B fragment).  Bitwise reproducible: an unsplit launch adds ONE
+                     // value per element; a split launch stores the splits' sums as rows of the slab's tail and splitk_reduce_kernel adds
+                     // them in a fixed order (gemm_bias_out below)
   // NN (bf16 output), 128-column tiles of the 4-wave kernel only (a wave then owns whole 64-column heads): the output is an attention
   // layer's dO; also write Delta[b * delta_heads + head][q] = sum_d dO[m][64 head + d] * O[m][64 head + d] (m = b * delta_nq + q, O = delta_o,
   // row stride delta_ldo) from the bf16-rounded output -- what attn_delta_kernel would compute in a pass of its own
@@ -170,6 +172,13 @@ struct GemmP {
   float* gbias_grad[GEMM_MAX_GROUP];
   bf16* gCb[GEMM_MAX_GROUP];
 };
+
+// Bias-gradient value of row m from reduction split `split` (the kernels' epilogues call this from the one workgroup per row block and split
+// that owns it).  Unsplit: the only writer of the element in this launch.  Split: row `split` of the slab's tail, folded by splitk_reduce_kernel.
+__device__ __forceinline__ void gemm_bias_out(float* bias_grad, float* slab, long slab_ld, int splitk, int split, int M, int m, float v) {
+  if (splitk > 1) slab[(long)splitk * M * slab_ld + (long)split * M + m] = v;
+  else atomicAdd(bias_grad + m, v);
+}
 int gemm_pick_group(int M, int N, int taps, long red, int splitk);   // problems per grouped wgrad launch (1 = launch alone)
 size_t gemm_slab_floats(int M, int N, int taps, int splitk);
 void gemm_defaults(GemmP* p);
@@ -302,8 +311,9 @@ int launch_ln_param_reduce(const LnRedBatch& b, hipStream_t st);
 int launch_silu_fwd(const bf16* x, bf16* y, long n, hipStream_t st);
 int launch_silu_bwd(const bf16* x, const bf16* dy, bf16* dx, const bf16* addend, long n, hipStream_t st);
 int launch_add(const bf16* a, const bf16* b, bf16* o, long n, hipStream_t st);           // o = a + b
-int launch_colsum_f32(const bf16* x, float* out, int M, int N, long ldx, hipStream_t st);
-int launch_colsum_f32_batched(const bf16* x, float* out, int batches, int rows, int N, long ldx, long ld_out, hipStream_t st);  // out[n] += sum_m
+size_t colsum_part_floats(int batches, int rows, int N);
+int launch_colsum_f32_batched(const bf16* x, float* out, int batches, int rows, int N, long ldx, long ld_out, float* part, hipStream_t st);  // out[b][n] += sum_m, fixed order
+int launch_colsum_partials(const bf16* x, float* out, int batches, int rows, int N, long ldx, long ld_out, float* part, LnRedEntry* entries, hipStream_t st);
 int launch_concat(const bf16* a, int Ca, const bf16* b, int Cb, bf16* o, long rows, hipStream_t st);
 int launch_split_add(const bf16* g, bf16* ga, int Ca, const bf16* add_a, bf16* gb, int Cb, const bf16* add_b,
                      long rows, hipStream_t st);                                                  // concat backward
@@ -359,7 +369,9 @@ struct LossP {
   float grad_scale;       // multiplies d(loss)/d(pred) (1/grad_accum, 1/world)
   float* out;             // device: [0]=loss [1]=raw loss [2]=sum|pred| [3]=sum pred^2 [4]=sum|noise|
                           //         [5]=sum x0^2 [6]=sum x1^2 [7]=gate
+  float* part;            // device scratch, loss_part_floats(B, HW): the blocks' partial sums (no atomics: the loss is bitwise reproducible)
 };
+static inline size_t loss_part_floats(int B, int HW) { return 6 * (((size_t)B * HW + 255) / 256); }
 int launch_loss_prepare(const LossP& p, hipStream_t st);
 int launch_loss_fwd(const LossP& p, hipStream_t st);
 int launch_loss_bwd(const LossP& p, hipStream_t st);

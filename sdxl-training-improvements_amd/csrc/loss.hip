@@ -94,13 +94,26 @@ __global__ void loss_fwd_kernel(const LossP p) {
     if (lane == 0) sred[wv][k] = s;
   }
   __syncthreads();
-  if (threadIdx.x < 6) {
-    float s = sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] + sred[3][threadIdx.x];
-    atomicAdd(&p.out[1 + threadIdx.x], s);
-  }
+  if (threadIdx.x < 6)      // the block's six sums as a partial row: loss_finalize_kernel adds the rows in a fixed order (bitwise reproducible loss)
+    p.part[(long)blockIdx.x * 6 + threadIdx.x] = sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] + sred[3][threadIdx.x];
 }
 
+// one wave: lane l adds the partial rows l, l + 64, ... in order, lane 0 then adds the 64 lane sums in order
 __global__ void loss_finalize_kernel(const LossP p) {
+  __shared__ float sl[6][64];
+  const long nb = ((long)p.B * p.HW + 255) / 256;
+  for (int k = 0; k < 6; ++k) {
+    float s = 0.f;
+    for (long r = threadIdx.x; r < nb; r += 64) s += p.part[r * 6 + k];
+    sl[k][threadIdx.x] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  for (int k = 0; k < 6; ++k) {
+    float s = 0.f;
+    for (int l = 0; l < 64; ++l) s += sl[k][l];
+    p.out[1 + k] = s;
+  }
   float numel = (float)p.B * 4.f * (float)p.HW;
   float l = p.out[1] / numel;
   float tm = 1.f;
@@ -150,9 +163,9 @@ int launch_loss_prepare(const LossP& p, hipStream_t st) {
 int launch_loss_fwd(const LossP& p, hipStream_t st) {
   if (int e = check_loss(p)) return e;
   long n = (long)p.B * p.HW;
-  HIP_CHECK_RET(hipMemsetAsync(p.out, 0, 8 * sizeof(float), st));
+  ARG_CHECK(p.part != nullptr, "loss: missing partial-row scratch (loss_part_floats)");
   hipLaunchKernelGGL(loss_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, p);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -666,7 +666,7 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const LnRedBatch b
 __global__ __launch_bounds__(256) void col_reduce_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, long ld,
                                   const float* __restrict__ stats, float* __restrict__ out_g,
                                   float* __restrict__ out_b, int M, int C, int rows_per_chunk, long batch_stride,
-                                  long out_ld) {
+                                  long out_ld, float* __restrict__ part) {
   __shared__ float sred[2][8][256 + 8];
   dy += blockIdx.z * batch_stride;       // batched plain column sums (x == nullptr): batch z = rows [z*M, z*M + M) -> out_b + z*out_ld
   out_b += blockIdx.z * out_ld;
@@ -703,6 +703,10 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const bf16* __restrict_
     float g = 0.f, b = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { g += sred[0][k][threadIdx.x]; b += sred[1][k][threadIdx.x]; }
+    if (part) {      // plain column sums as partial rows part[batch][chunk][C]: folded in a fixed order by ln_param_reduce_kernel (launch_colsum_f32_batched)
+      part[((long)blockIdx.z * gridDim.y + blockIdx.y) * C + c] = b;
+      return;
+    }
     if (x) atomicAdd(&out_g[c], g);
     atomicAdd(&out_b[c], b);
   }
@@ -871,7 +875,7 @@ int launch_layernorm_param_grads(const bf16* x, const bf16* dy, const float* sta
   ARG_CHECK(C % 8 == 0, "layernorm param grads: C=%d must be a multiple of 8", C);
   dim3 g2; int rpc;
   col_reduce_geom(M, C, &g2, &rpc);
-  hipLaunchKernelGGL(col_reduce_kernel, g2, dim3(256), 0, st, x, dy, (long)C, stats, dgamma, dbeta, M, C, rpc, 0L, 0L);
+  hipLaunchKernelGGL(col_reduce_kernel, g2, dim3(256), 0, st, x, dy, (long)C, stats, dgamma, dbeta, M, C, rpc, 0L, 0L, (float*)nullptr);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -885,27 +889,46 @@ int launch_layernorm_param_partials(const bf16* x, const bf16* dy, const float* 
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-int launch_colsum_f32(const bf16* x, float* out, int M, int N, long ldx, hipStream_t st) {
-  ARG_CHECK(N % 8 == 0 && ldx % 8 == 0, "colsum: N=%d ld=%ld must be multiples of 8", N, ldx);
+static void colsum_geom(int batches, int rows, int N, dim3* g2, int* rpc) {
+  col_reduce_geom(rows, N, g2, rpc);
+  if (batches > 1 && g2->y >= 2u * batches) {          // keep the total number of blocks
+    *rpc *= batches;
+    g2->y = cdiv(rows, *rpc);
+  }
+  g2->z = batches;
+}
+// floats of the partial rows launch_colsum_f32_batched wants for these sizes
+size_t colsum_part_floats(int batches, int rows, int N) {
   dim3 g2; int rpc;
-  col_reduce_geom(M, N, &g2, &rpc);
+  colsum_geom(batches, rows, N, &g2, &rpc);
+  return (size_t)batches * g2.y * N;
+}
+// out[b][n] += sum over the rows of batch b of x[b*rows + r][n], all batches in one launch (out row stride ld_out).  Bitwise reproducible:
+// the blocks store partial rows part[b][chunk][N] (colsum_part_floats) and a launch of the fixed-order reduce adds them (an entry per batch:
+// the two column halves play dgamma | dbeta) -- no atomics.  launch_colsum_partials leaves the reduce to the caller (`entries`[batches], to be
+// handed to launch_ln_param_reduce on the same stream, any number of column sums per launch); launch_colsum_f32_batched reduces right away.
+int launch_colsum_partials(const bf16* x, float* out, int batches, int rows, int N, long ldx, long ld_out, float* part, LnRedEntry* entries,
+                           hipStream_t st) {
+  ARG_CHECK(N % 8 == 0 && ldx % 8 == 0 && part != nullptr, "colsum: N=%d ld=%ld must be multiples of 8 (and the partial rows given)", N, ldx);
+  dim3 g2; int rpc;
+  colsum_geom(batches, rows, N, &g2, &rpc);
   hipLaunchKernelGGL(col_reduce_kernel, g2, dim3(256), 0, st, (const bf16*)nullptr, x, ldx, (const float*)nullptr,
-                     (float*)nullptr, out, M, N, rpc, 0L, 0L);
+                     (float*)nullptr, out, rows, N, rpc, (long)rows * ldx, ld_out, part);
   HIP_CHECK_RET(hipGetLastError());
+  for (int b = 0; b < batches; ++b) {
+    LnRedEntry& e = entries[b];
+    e.part = part + (size_t)b * g2.y * N;
+    e.dgamma = out + (size_t)b * ld_out;
+    e.dbeta = e.dgamma + N / 2;
+    e.nblk = (int)g2.y;
+    e.C = N / 2;
+  }
   return 0;
 }
-// out[b][n] += sum over the rows of batch b of x[b*rows + r][n], all batches in one launch (out row stride ld_out)
-int launch_colsum_f32_batched(const bf16* x, float* out, int batches, int rows, int N, long ldx, long ld_out, hipStream_t st) {
-  ARG_CHECK(N % 8 == 0 && ldx % 8 == 0, "colsum: N=%d ld=%ld must be multiples of 8", N, ldx);
-  dim3 g2; int rpc;
-  col_reduce_geom(rows, N, &g2, &rpc);
-  if (batches > 1 && g2.y >= 2u * batches) {          // keep the total number of blocks
-    rpc *= batches;
-    g2.y = cdiv(rows, rpc);
-  }
-  g2.z = batches;
-  hipLaunchKernelGGL(col_reduce_kernel, g2, dim3(256), 0, st, (const bf16*)nullptr, x, ldx, (const float*)nullptr,
-                     (float*)nullptr, out, rows, N, rpc, (long)rows * ldx, ld_out);
-  HIP_CHECK_RET(hipGetLastError());
-  return 0;
+int launch_colsum_f32_batched(const bf16* x, float* out, int batches, int rows, int N, long ldx, long ld_out, float* part, hipStream_t st) {
+  ARG_CHECK(batches >= 1 && batches <= LN_RED_MAX, "colsum: %d batches", batches);
+  LnRedBatch rb;
+  rb.n = batches;
+  if (int e = launch_colsum_partials(x, out, batches, rows, N, ldx, ld_out, part, rb.e, st)) return e;
+  return launch_ln_param_reduce(rb, st);
 }

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const GemmP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * 64 + i * 16 + g * 4 + r;
-        if (m < p.M) atomicAdd(p.bias_grad + m, accb[i][r]);
+        if (m < p.M) gemm_bias_out(p.bias_grad, p.slab, p.slab_ld, p.splitk, split, p.M, m, accb[i][r]);
       }
   }
   // ---- epilogue: lane (l16, g) holds C[m = 16 i + l16][n = 16 j + 4 g .. + 3] of its wave tile ----
