@@ -48,6 +48,15 @@ def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
+    if len(sys.argv) > 2 and sys.argv[2].startswith("b"):      # `... 10 b8`: one handle at another batch size (the ceiling argument of DESIGN.md section 10)
+        B = int(sys.argv[2][1:])
+        n, bt = make(B, dev, 0)
+
+        def stepB():
+            fwd(n, bt); n.backward(1.0, True)
+        t = timed(stepB, steps)
+        print(f"one handle  B={B}: {t:8.2f} ms per step  ({B * 1e3 / t:.2f} img/s, {B * 20.28 / t / 2.5166 * 100:.1f} % of the bf16 MFMA roofline)", flush=True)
+        return
     n4, b4 = make(4, dev, 0)
 
     def step4():
