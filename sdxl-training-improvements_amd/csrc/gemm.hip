@@ -1242,10 +1242,13 @@ void gemm_defaults(GemmP* p) {
 template <int FORM, bool CONV, int BN, int S, int BK, bool FAST, int NW, bool KSP = false, bool PL = false>
 static int launch_k(const GemmP& p, hipStream_t st) {
   static bool attr_set = false;
-  constexpr int smem = gemm_smem_bytes(BN, S, BK, NW);
+  constexpr int smem0 = gemm_smem_bytes(BN, S, BK, NW);
+  // knob 39 (experiment) = a + 1000 b: a KiB of LDS per workgroup for the NN (dgrad) launches, b KiB for the TN ones -- at most one of them per CU
+  const int kreq = FORM == GEMM_NN ? KNOB(39) % 1000 : FORM == GEMM_TN ? KNOB(39) / 1000 : 0;
+  const int smem = (kreq * 1024 > smem0 && kreq <= 100 && smem0 <= 80 * 1024) ? kreq * 1024 : smem0;
   if (!attr_set) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<FORM, CONV, BN, S, BK, FAST, NW, KSP, PL>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem0 > 100 * 1024 ? smem0 : 100 * 1024));
     attr_set = true;
   }
   dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), FORM == GEMM_TN ? (p.group > 1 ? p.group : p.taps * p.splitk) : p.splitk);

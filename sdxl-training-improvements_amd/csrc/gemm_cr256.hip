@@ -402,11 +402,18 @@ int launch_cr(const GemmP& p, hipStream_t st) {
   using G = CrGeom<BN>;
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)cr256_kernel<FORM, BN, BIASG, S, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, G::smem(S)));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)cr256_kernel<FORM, BN, BIASG, S, PH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      G::smem(S) > 100 * 1024 ? G::smem(S) : 100 * 1024));
     attr_set = true;
   }
   dim3 grid(cdiv(p.N, BN), cdiv(p.M, CR_BM), p.group > 1 ? p.group : p.splitk);
-  GEMM_LAUNCH((cr256_kernel<FORM, BN, BIASG, S, PH>), grid, dim3(512), G::smem(S), st, p);
+  // The co-resident form asks for 84 KiB of LDS, not the 72 - 78 KiB its ring needs: ONE of these workgroups per CU, and 76 KiB + half the
+  // registers stay free for a workgroup of the other stream (the 73 KiB dgrad kernel, the norms, attention).  With the ring's own size two of
+  // them fit a CU and fill its register file: the caller's stream -- the backward's critical path -- then finds no room there until one of
+  // them retires (step -0.1 ... -0.55 ms over four boxes, profiles/r06q_ab_cr_one_per_cu.txt).  knob 38 = 1: the ring's own size, N: N KiB.
+  const int kib = KNOB(38) == 0 ? (S == CR_S ? 84 : 0) : KNOB(38) == 1 ? 0 : KNOB(38);
+  const int smem = (kib * 1024 > G::smem(S) && kib <= 100) ? kib * 1024 : G::smem(S);
+  GEMM_LAUNCH((cr256_kernel<FORM, BN, BIASG, S, PH>), grid, dim3(512), smem, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

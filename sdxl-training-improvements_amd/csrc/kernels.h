@@ -35,6 +35,8 @@
 //      (4 waves, one per SIMD, 512 registers): parity-green, at parity in time (profiles/r06f_attn_ab.txt)
 //   35 self-attention backward: 0 policy (attention_bwd_pl.hip for Nq, Nk >= 2048, attn_bwd_fused_kernel below), 1 = attn_bwd_fused_kernel everywhere, 2 = pipelined wherever it applies
 //   34 = 1: no generic XCD order (xcd_seq_map) in the weight-gradient kernels: identity where no XCD rectangle fits, = 2: the generic order also where a rectangle fits (cr256)
+//   38 LDS KiB requested per workgroup of the co-resident 256-row weight-gradient kernel (0: the shipped 84 = one per CU + room for the other stream; 1: its ring's own size = two per CU; N: N KiB)
+//   39 = a + 1000 b: a KiB of LDS per workgroup of the 128-row kernel's NN (dgrad) launches, b KiB for its TN launches (one per CU; measured: +12 / +1.1 ms)
 //   29 = 1: weight-gradient GEMMs that use no split-K slab and whose operands come from the caller's stream are launched any-order on the side stream
 // The product library has NO knobs: KNOB(i) is the constant 0 (= the shipped policy) and every experiment branch below it folds away.
 // The diagnostics build (`build.py --diag`: -DSDXL_DIAG -> libsdxlstep_diag.so, include/sdxlstep_diag.h) keeps the table, sdxl_set_knob,
