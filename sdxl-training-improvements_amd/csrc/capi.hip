@@ -217,7 +217,7 @@ static int ready(Engine& e) {
   return 0;
 }
 
-// zero the gradient ranges that are accumulated with atomics (bias / norm vectors: ~2.6 M of the 2.57 G elements);
+// zero the gradient ranges that are accumulated with += by every backward (bias / norm vectors: ~2.6 M of the 2.57 G elements; one writer per element and launch);
 // the weight matrices are overwritten by the first micro-step's wgrad GEMMs (first_micro) and need no zeroing
 static int small_ranges_on_device(Engine& e);
 __global__ void zero_ranges_kernel(float* __restrict__ g, const unsigned long long* __restrict__ ranges) {
@@ -527,7 +527,7 @@ int sdxl_grads_to_bf16(sdxl_handle* h, size_t off, size_t n, void* dst, float sc
   return launch_f32_to_bf16(h->e.grads + off, (bf16*)dst, (long)n, scale, (hipStream_t)st);
 }
 
-// bf16 cast of the SMALL parameter ranges (biases, norm weights: the fp32-atomic accumulators) inside [off, off + n): what is
+// bf16 cast of the SMALL parameter ranges (biases, norm weights: the fp32 += accumulators) inside [off, off + n): what is
 // left to cast when the weight-gradient GEMMs emit bf16 themselves (sdxl_set_grad_emit)
 __global__ void cast_small_ranges_kernel(const float* __restrict__ g, bf16* __restrict__ dst, const unsigned long long* __restrict__ ranges,
                                          unsigned long long lo, unsigned long long hi, float scale) {
